@@ -1,0 +1,250 @@
+/*
+ * laenerf.h -- C ABI of the MI355X-native LAENeRF / torch-ngp hot path.
+ *
+ * One symbol per backend function of the reference's four pybind11 modules
+ * (_raymarching, _gridencoder, _shencoder, _ffmlp).  Every entry point
+ *   - takes raw DEVICE pointers + sizes + scalars (no torch types),
+ *   - borrows the pointers for the duration of the call only (the caller owns
+ *     and pre-allocates every output / workspace, exactly like the reference's
+ *     autograd.Functions do),
+ *   - enqueues its kernels on `stream` (a hipStream_t passed as void*; NULL =
+ *     the legacy default stream, which is what the reference launched on),
+ *   - never synchronises the host, never allocates device memory,
+ *   - returns LAE_OK (0) or a negative LAE_E* code; the Python shim turns a
+ *     non-zero code into RuntimeError (the reference threw c10::Error /
+ *     std::runtime_error for the same conditions).
+ *
+ * All tensors are dense row-major ("contiguous") exactly as the reference
+ * requires (CHECK_CONTIGUOUS, gridencoder.cu:455-459).
+ *
+ * Reference interface replaced, per symbol: see the comment above each
+ * prototype (paths relative to the reference checkout).
+ */
+#ifndef LAENERF_H
+#define LAENERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported from liblaenerf_hip.so (the library is built with -fvisibility=hidden) */
+#if defined(__GNUC__) || defined(__clang__)
+#define LAE_API __attribute__((visibility("default")))
+#else
+#define LAE_API
+#endif
+
+#define LAE_OK 0
+#define LAE_EINVAL (-1)     /* unsupported template parameter / bad argument  */
+#define LAE_ELAUNCH (-2)    /* hipGetLastError() != hipSuccess after a launch */
+#define LAE_ENULL (-3)      /* required pointer is NULL                       */
+
+/* element type of the hash table / encoder outputs / encoder grads */
+#define LAE_F32 0
+#define LAE_F16 1
+
+/* grid types / interpolation (gridencoder/grid.py:14-22) */
+#define LAE_GRID_HASH 0
+#define LAE_GRID_TILED 1
+#define LAE_INTERP_LINEAR 0
+#define LAE_INTERP_SMOOTHSTEP 1
+
+/* ffmlp activations (ffmlp/ffmlp.py:89-96, ffmlp/src/utils.h:29-37) */
+#define LAE_ACT_RELU 0
+#define LAE_ACT_EXPONENTIAL 1
+#define LAE_ACT_SINE 2
+#define LAE_ACT_SIGMOID 3
+#define LAE_ACT_SQUAREPLUS 4
+#define LAE_ACT_SOFTPLUS 5
+#define LAE_ACT_NONE 6
+
+/* library identification: returns a static string "laenerf-hip gfx950 <abi>" */
+LAE_API const char* lae_version(void);
+/* last HIP error string recorded by a failed launch in this thread (or "") */
+LAE_API const char* lae_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* _raymarching  (raymarching/src/raymarching.h:7-20, bindings.cpp:5-20) */
+/* ------------------------------------------------------------------ */
+
+/* raymarching.cu:148-156  near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars) */
+LAE_API int lae_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
+                           uint32_t N, float min_near, float* nears, float* fars, void* stream);
+
+/* raymarching.cu:201-209  sph_from_ray(rays_o, rays_d, radius, N, coords[N,2]) */
+LAE_API int lae_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N,
+                     float* coords, void* stream);
+
+/* raymarching.cu:229-232  morton3D(coords[N,3] i32, N, indices[N] i32) */
+LAE_API int lae_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+
+/* raymarching.cu:257-260  morton3D_invert(indices[N], N, coords[N,3]) */
+LAE_API int lae_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+
+/* raymarching.cu:292-300  packbits(grid[8N] f32, N bytes, thresh, bitfield[N] u8) */
+LAE_API int lae_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,
+                 void* stream);
+
+/* raymarching.cu:482-490  march_rays_train(...)
+ * rays[N,3] = (ray id, offset, count).  Rows are written in RAY-ID order with
+ * offsets = exclusive prefix sum of counts (the reference's atomicAdd
+ * reservation order is non-deterministic; sequential execution of the
+ * reference gives exactly this order).  counter[0] += sum(count),
+ * counter[1] += N, like the reference's atomicAdds on a pre-zeroed counter.
+ * `scratch` : caller-provided device workspace of lae_march_rays_train_scratch_bytes(N)
+ * bytes (may be NULL only when N == 0). */
+LAE_API uint64_t lae_march_rays_train_scratch_bytes(uint32_t N);
+LAE_API int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid,
+                         float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float* nears, const float* fars,
+                         float* xyzs, float* dirs, float* deltas,
+                         int32_t* rays, int32_t* counter, const float* noises,
+                         void* scratch, void* stream);
+
+/* raymarching.cu:580-588 */
+LAE_API int lae_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                     const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                     float* weights_sum, float* depth, float* image, void* stream);
+
+/* raymarching.cu:685-693 */
+LAE_API int lae_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                      const float* sigmas, const float* rgbs, const float* deltas,
+                                      const int32_t* rays, const float* weights_sum,
+                                      const float* image, uint32_t M, uint32_t N, float T_thresh,
+                                      float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* raymarching.cu:929-936 */
+LAE_API int lae_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
+                   const float* rays_t, const float* rays_o, const float* rays_d,
+                   float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                   const uint8_t* grid, const float* nears, const float* fars,
+                   float* xyzs, float* dirs, float* deltas, const float* noises, void* stream);
+
+/* raymarching.cu:938-945  (edit_occ is a torch.bool tensor = 1 byte / sample) */
+LAE_API int lae_march_rays_distill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
+                           const float* rays_t, const float* rays_o, const float* rays_d,
+                           float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                           const uint8_t* grid, const uint8_t* edit_grid,
+                           const float* nears, const float* fars,
+                           float* xyzs, float* dirs, float* deltas, uint8_t* edit_occ,
+                           const float* noises, void* stream);
+
+/* raymarching.cu:1145-1151 */
+LAE_API int lae_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                       int32_t* rays_alive, float* rays_t,
+                       const float* sigmas, const float* rgbs, const float* deltas,
+                       float* weights_sum, float* depth, float* image, void* stream);
+
+/* raymarching.cu:1153-1159 */
+LAE_API int lae_composite_rays_distill(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                               int32_t* rays_alive, float* rays_t,
+                               const float* sigmas, const float* rgbs, const float* deltas,
+                               float* weights_sum, float* weights_edit_sum,
+                               float* depth, float* depth_edit,
+                               const uint8_t* edit_occ, float* image, void* stream);
+
+/* MI355X-native extension (no reference counterpart; replaces the host-side
+ * `rays_alive = rays_alive[rays_alive >= 0]` + size sync at renderer.py:375,459):
+ * order-preserving device-side compaction of the alive list.
+ * out_alive[0..n_out) = entries of rays_alive that are >= 0, in order;
+ * *n_out_dev (device int32) receives n_out.  scratch: lae_compact_scratch_bytes(n_alive). */
+LAE_API uint64_t lae_compact_scratch_bytes(uint32_t n_alive);
+LAE_API int lae_compact_rays_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_alive,
+                           int32_t* n_out_dev, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* _gridencoder  (gridencoder/src/gridencoder.h:12-15)                */
+/* ------------------------------------------------------------------ */
+
+/* gridencoder.cu:448-471  grid_encode_forward(inputs[B,D] f32, embeddings[sO,C],
+ * offsets[L+1] i32, outputs[L,B,C], B, D, C, L, S, H, dy_dx[B,L*D*C] or NULL,
+ * gridtype, align_corners, interp).  `dtype` selects the element type of
+ * embeddings / outputs / dy_dx (the reference dispatches on
+ * embeddings.scalar_type(), gridencoder.cu:467). */
+LAE_API int lae_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
+                            void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            float S, uint32_t H, void* dy_dx, uint32_t gridtype,
+                            int align_corners, uint32_t interp, int dtype, void* stream);
+
+/* MI355X-native variant: writes outputs as [B, L*C] directly (what grid.py:57
+ * produces with an extra permute+reshape copy).  Same arithmetic. */
+LAE_API int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings,
+                                const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
+                                uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                void* stream);
+
+/* gridencoder.cu:473-503  grid_encode_backward(grad[L,B,C], inputs, embeddings, offsets,
+ * grad_embeddings[sO,C] (pre-zeroed, accumulated into), B, D, C, L, S, H,
+ * dy_dx or NULL, grad_inputs[B,D] or NULL, gridtype, align_corners, interp) */
+LAE_API int lae_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
+                             const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                             int align_corners, uint32_t interp, int dtype, void* stream);
+
+/* MI355X-native variant: grad given as [B, L*C] (no permute copy, grid.py:75). */
+LAE_API int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const void* embeddings,
+                                 const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                 const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                                 int align_corners, uint32_t interp, int dtype, void* stream);
+
+/* gridencoder.cu:639-645  grad_total_variation(inputs[B,D], embeddings, grad, offsets,
+ * weight, B, D, C, L, S, H, gridtype, align_corners); inputs has the table dtype. */
+LAE_API int lae_grad_total_variation(const void* inputs, const void* embeddings, void* grad,
+                             const int32_t* offsets, float weight, uint32_t B, uint32_t D,
+                             uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                             int align_corners, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* _shencoder  (shencoder/src/shencoder.h:9-10)                       */
+/* ------------------------------------------------------------------ */
+
+/* shencoder.cu:400-417  sh_encode_forward(inputs[B,3], outputs[B,C*C], B, D=3, C=degree, dy_dx[B,3*C*C] or NULL) */
+LAE_API int lae_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D,
+                          uint32_t C, float* dy_dx, void* stream);
+
+/* shencoder.cu:419-439  sh_encode_backward(grad[B,C*C], inputs, B, D, C, dy_dx, grad_inputs[B,3] accumulated into) */
+LAE_API int lae_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D,
+                           uint32_t C, const float* dy_dx, float* grad_inputs, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* _ffmlp  (ffmlp/src/ffmlp.h:8-14).  All tensors fp16 (uint16 storage) */
+/* ------------------------------------------------------------------ */
+
+/* ffmlp.cu:635-671  ffmlp_forward(inputs[B,in], weights, B, input_dim, output_dim(=16 padded),
+ * hidden_dim, num_layers, activation, output_activation, forward_buffer[num_layers,B,hidden], outputs[B,16]) */
+LAE_API int lae_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                      uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                      uint32_t activation, uint32_t output_activation, void* forward_buffer,
+                      void* outputs, void* stream);
+
+/* ffmlp.cu:673-709  (inference_buffer[B,hidden] is scratch the reference never reads back) */
+LAE_API int lae_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                        uint32_t activation, uint32_t output_activation, void* inference_buffer,
+                        void* outputs, void* stream);
+
+/* ffmlp.cu:749-895  ffmlp_backward(grad[B,16], inputs, weights, forward_buffer, B, ...,
+ * calc_grad_inputs, backward_buffer[num_layers,B,hidden], grad_inputs[B,in] or dummy, grad_weights) */
+LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights,
+                       const void* forward_buffer, uint32_t B, uint32_t input_dim,
+                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                       void* backward_buffer, void* grad_inputs, void* grad_weights,
+                       void* stream);
+
+/* ffmlp.cu:721-740: the reference keeps process-global side streams for its
+ * split-K CUTLASS GEMMs.  The MFMA backward reduces dW inside one stream, so
+ * these are accepted and ignored (kept so FFMLP.__init__ runs unmodified). */
+LAE_API int lae_allocate_splitk(uint64_t size);
+LAE_API int lae_free_splitk(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAENERF_H */

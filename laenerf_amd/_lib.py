@@ -1,0 +1,106 @@
+"""ctypes binding of liblaenerf_hip.so (the C ABI declared in include/laenerf.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised (the reference raised c10::Error / RuntimeError
+for the same conditions).  `backend_module(name)` builds objects that expose the
+exact function names/argument order of the reference's pybind11 modules
+`_raymarching`, `_gridencoder`, `_shencoder`, `_ffmlp` (tensor arguments), so the
+reference's own wrappers can use them via `sys.modules`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "liblaenerf_hip.so")
+
+u32, u64, f32, i32, vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p
+
+# name -> argtypes (everything returns int unless listed in _RESTYPES); mirrors include/laenerf.h
+SIGNATURES = {
+    "lae_near_far_from_aabb": [vp, vp, vp, u32, f32, vp, vp, vp],
+    "lae_sph_from_ray": [vp, vp, f32, u32, vp, vp],
+    "lae_morton3D": [vp, u32, vp, vp],
+    "lae_morton3D_invert": [vp, u32, vp, vp],
+    "lae_packbits": [vp, u32, f32, vp, vp],
+    "lae_march_rays_train_scratch_bytes": [u32],
+    "lae_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, vp],
+    "lae_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, vp],
+    "lae_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_march_rays_distill": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays_distill": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_compact_scratch_bytes": [u32],
+    "lae_compact_rays_alive": [vp, u32, vp, vp, vp, vp],
+    "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
+    "lae_grid_encode_forward_blc": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
+    "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
+    "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
+    "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
+    "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
+    "lae_sh_encode_backward": [vp, vp, u32, u32, u32, vp, vp, vp],
+    "lae_ffmlp_forward": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
+    "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
+    "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],
+    "lae_allocate_splitk": [u64],
+    "lae_free_splitk": [],
+    "lae_version": [],
+    "lae_last_error": [],
+}
+_RESTYPES = {
+    "lae_march_rays_train_scratch_bytes": u64,
+    "lae_compact_scratch_bytes": u64,
+    "lae_version": ctypes.c_char_p,
+    "lae_last_error": ctypes.c_char_p,
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (after torch, so its libamdhip64 is the one already mapped)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"laenerf_amd: HIP library not built ({SO_PATH}); run `python -m laenerf_amd.build` "
+            "(there is no CPU fallback)")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lae_last_error().decode() if rc == -2 else {-1: "invalid argument / unsupported configuration",
+                                                                 -3: "null pointer"}.get(rc, "error")
+        raise RuntimeError(f"laenerf_amd.{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    """raw hipStream_t of torch's CURRENT stream (the reference used the legacy default stream)"""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("laenerf_amd: tensor must be on the GPU (HIP backend, no CPU fallback)")
+
+
+def need_contig(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("laenerf_amd: tensor must be contiguous")

@@ -1,0 +1,288 @@
+"""Tensor-level backends with the exact function names / argument order of the reference's
+four pybind11 modules, implemented on the C ABI (include/laenerf.h).
+
+    _raymarching  raymarching/src/bindings.cpp:5-20
+    _gridencoder  gridencoder/src/bindings.cpp:5-8
+    _shencoder    shencoder/src/bindings.cpp:5-7
+    _ffmlp        ffmlp/src/bindings.cpp:5-10
+
+`install_as_reference_backends()` registers them in sys.modules under those names, which
+is what the reference's wrappers import first (`try: import _raymarching as _backend`,
+raymarching/raymarching.py:9-12), so nerf/renderer.py and editing/* run unmodified.
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, need_contig, need_cuda, ptr, stream
+
+_F16 = torch.float16
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.float16:
+        return 1
+    raise RuntimeError(f"laenerf_amd: unsupported dtype {t.dtype} (float32 / float16 only)")
+
+
+def _need_f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("laenerf_amd.raymarching: float32 tensors required (the reference's wrappers cast to fp32)")
+
+
+_scratch = {}
+
+
+def _workspace(device, nbytes):
+    """grow-only per-device scratch buffer for scans/compaction (stream-ordered reuse)"""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- _raymarching
+class _RayMarching:
+    @staticmethod
+    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        need_cuda(rays_o, rays_d, aabb, nears, fars); need_contig(rays_o, rays_d, aabb, nears, fars)
+        _need_f32(rays_o, rays_d, aabb, nears, fars)
+        check(_lib.load().lae_near_far_from_aabb(ptr(rays_o), ptr(rays_d), ptr(aabb), N, min_near, ptr(nears), ptr(fars),
+                                                 stream()), "near_far_from_aabb")
+
+    @staticmethod
+    def sph_from_ray(rays_o, rays_d, radius, N, coords):
+        need_cuda(rays_o, rays_d, coords); need_contig(rays_o, rays_d, coords); _need_f32(rays_o, rays_d, coords)
+        check(_lib.load().lae_sph_from_ray(ptr(rays_o), ptr(rays_d), radius, N, ptr(coords), stream()), "sph_from_ray")
+
+    @staticmethod
+    def morton3D(coords, N, indices):
+        need_cuda(coords, indices); need_contig(coords, indices)
+        assert coords.dtype == torch.int32 and indices.dtype == torch.int32
+        check(_lib.load().lae_morton3D(ptr(coords), N, ptr(indices), stream()), "morton3D")
+
+    @staticmethod
+    def morton3D_invert(indices, N, coords):
+        need_cuda(coords, indices); need_contig(coords, indices)
+        assert coords.dtype == torch.int32 and indices.dtype == torch.int32
+        check(_lib.load().lae_morton3D_invert(ptr(indices), N, ptr(coords), stream()), "morton3D_invert")
+
+    @staticmethod
+    def packbits(grid, N, density_thresh, bitfield):
+        need_cuda(grid, bitfield); need_contig(grid, bitfield); _need_f32(grid)
+        assert bitfield.dtype == torch.uint8
+        check(_lib.load().lae_packbits(ptr(grid), N, float(density_thresh), ptr(bitfield), stream()), "packbits")
+
+    @staticmethod
+    def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
+                         rays, counter, noises):
+        need_cuda(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+        need_contig(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+        _need_f32(rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises)
+        assert grid.dtype == torch.uint8 and rays.dtype == torch.int32 and counter.dtype == torch.int32
+        lib = _lib.load()
+        ws = _workspace(rays_o.device, lib.lae_march_rays_train_scratch_bytes(N))
+        check(lib.lae_march_rays_train(ptr(rays_o), ptr(rays_d), ptr(grid), bound, dt_gamma, max_steps, N, C, H, M,
+                                       ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
+                                       ptr(counter), ptr(noises), ptr(ws), stream()), "march_rays_train")
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+        need_cuda(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        need_contig(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        _need_f32(sigmas, rgbs, deltas, weights_sum, depth, image)
+        check(_lib.load().lae_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh,
+                                                           ptr(weights_sum), ptr(depth), ptr(image), stream()),
+              "composite_rays_train_forward")
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                      T_thresh, grad_sigmas, grad_rgbs):
+        ts = (grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, grad_sigmas, grad_rgbs)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, grad_sigmas, grad_rgbs)
+        check(_lib.load().lae_composite_rays_train_backward(ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs),
+                                                            ptr(deltas), ptr(rays), ptr(weights_sum), ptr(image), M, N,
+                                                            T_thresh, ptr(grad_sigmas), ptr(grad_rgbs), stream()),
+              "composite_rays_train_backward")
+
+    @staticmethod
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears,
+                   fars, xyzs, dirs, deltas, noises):
+        ts = (rays_alive, rays_t, rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, noises)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(rays_t, rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises)
+        check(_lib.load().lae_march_rays(n_alive, n_step, ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d), bound,
+                                         dt_gamma, max_steps, C, H, ptr(grid), ptr(nears), ptr(fars), ptr(xyzs),
+                                         ptr(dirs), ptr(deltas), ptr(noises), stream()), "march_rays")
+
+    @staticmethod
+    def march_rays_distill(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid,
+                           edit_grid, nears, fars, xyzs, dirs, deltas, int_edit, noises):
+        ts = (rays_alive, rays_t, rays_o, rays_d, grid, edit_grid, nears, fars, xyzs, dirs, deltas, int_edit, noises)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(rays_t, rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises)
+        assert int_edit.dtype in (torch.bool, torch.uint8)
+        check(_lib.load().lae_march_rays_distill(n_alive, n_step, ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d),
+                                                 bound, dt_gamma, max_steps, C, H, ptr(grid), ptr(edit_grid), ptr(nears),
+                                                 ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(int_edit), ptr(noises),
+                                                 stream()), "march_rays_distill")
+
+    @staticmethod
+    def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights, depth, image):
+        ts = (rays_alive, rays_t, sigmas, rgbs, deltas, weights, depth, image)
+        need_cuda(*ts); need_contig(*ts); _need_f32(rays_t, sigmas, rgbs, deltas, weights, depth, image)
+        check(_lib.load().lae_composite_rays(n_alive, n_step, T_thresh, ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs),
+                                             ptr(deltas), ptr(weights), ptr(depth), ptr(image), stream()), "composite_rays")
+
+    @staticmethod
+    def composite_rays_distill(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights, weights_edit,
+                               depth, depth_edit, int_edit, image):
+        ts = (rays_alive, rays_t, sigmas, rgbs, deltas, weights, weights_edit, depth, depth_edit, int_edit, image)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(rays_t, sigmas, rgbs, deltas, weights, weights_edit, depth, depth_edit, image)
+        check(_lib.load().lae_composite_rays_distill(n_alive, n_step, T_thresh, ptr(rays_alive), ptr(rays_t), ptr(sigmas),
+                                                     ptr(rgbs), ptr(deltas), ptr(weights), ptr(weights_edit), ptr(depth),
+                                                     ptr(depth_edit), ptr(int_edit), ptr(image), stream()),
+              "composite_rays_distill")
+
+    # MI355X-native extension (no reference counterpart): device-side alive-list compaction
+    @staticmethod
+    def compact_rays_alive(rays_alive, n_alive, out_alive, n_out_dev):
+        need_cuda(rays_alive, out_alive, n_out_dev)
+        lib = _lib.load()
+        ws = _workspace(rays_alive.device, lib.lae_compact_scratch_bytes(n_alive))
+        check(lib.lae_compact_rays_alive(ptr(rays_alive), n_alive, ptr(out_alive), ptr(n_out_dev), ptr(ws), stream()),
+              "compact_rays_alive")
+
+
+# --------------------------------------------------------------------------- _gridencoder
+class _GridEncoder:
+    @staticmethod
+    def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+                            interp, blc=False):
+        need_cuda(inputs, embeddings, offsets, outputs, dy_dx); need_contig(inputs, embeddings, offsets, outputs, dy_dx)
+        if inputs.dtype != torch.float32 or offsets.dtype != torch.int32:
+            raise RuntimeError("grid_encode_forward: inputs must be float32, offsets int32")   # gridencoder.cu:461-463
+        if outputs.dtype != embeddings.dtype or (dy_dx is not None and dy_dx.dtype != embeddings.dtype):
+            raise RuntimeError("grid_encode_forward: outputs/dy_dx must have the embeddings dtype")
+        lib = _lib.load()
+        fn = lib.lae_grid_encode_forward_blc if blc else lib.lae_grid_encode_forward
+        check(fn(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype,
+                 int(bool(align_corners)), interp, _dtype_code(embeddings), stream()), "grid_encode_forward")
+
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                             gridtype, align_corners, interp, blc=False):
+        ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
+        need_cuda(*ts); need_contig(*ts)
+        if grad.dtype != grad_embeddings.dtype:
+            raise RuntimeError("grid_encode_backward: grad and grad_embeddings dtypes differ")
+        lib = _lib.load()
+        fn = lib.lae_grid_encode_backward_blc if blc else lib.lae_grid_encode_backward
+        check(fn(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad), stream()),
+              "grid_encode_backward")
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
+        need_cuda(inputs, embeddings, grad, offsets); need_contig(inputs, embeddings, grad, offsets)
+        check(_lib.load().lae_grad_total_variation(ptr(inputs), ptr(embeddings), ptr(grad), ptr(offsets), float(weight), B, D,
+                                                   C, L, float(S), H, gridtype, int(bool(align_corners)),
+                                                   _dtype_code(embeddings), stream()), "grad_total_variation")
+
+
+# --------------------------------------------------------------------------- _shencoder
+class _SHEncoder:
+    @staticmethod
+    def sh_encode_forward(inputs, outputs, B, D, C, dy_dx):
+        need_cuda(inputs, outputs, dy_dx); need_contig(inputs, outputs, dy_dx)
+        if inputs.dtype != torch.float32 or outputs.dtype != torch.float32:
+            raise RuntimeError("sh_encode_forward: float32 required (sphere_harmonics.py:16 casts to fp32)")
+        check(_lib.load().lae_sh_encode_forward(ptr(inputs), ptr(outputs), B, D, C, ptr(dy_dx), stream()), "sh_encode_forward")
+
+    @staticmethod
+    def sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs):
+        need_cuda(grad, inputs, dy_dx, grad_inputs); need_contig(grad, inputs, dy_dx, grad_inputs)
+        if grad.dtype != torch.float32:
+            raise RuntimeError("sh_encode_backward: float32 required")
+        check(_lib.load().lae_sh_encode_backward(ptr(grad), ptr(inputs), B, D, C, ptr(dy_dx), ptr(grad_inputs), stream()),
+              "sh_encode_backward")
+
+
+# --------------------------------------------------------------------------- _ffmlp
+class _FFMLP:
+    @staticmethod
+    def _half(*ts):
+        for t in ts:
+            if t is not None and t.dtype != _F16:
+                raise RuntimeError("ffmlp: float16 tensors required (CHECK_IS_HALF, ffmlp.cu:638-642)")
+
+    @staticmethod
+    def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                      forward_buffer, outputs):
+        need_cuda(inputs, weights, forward_buffer, outputs); need_contig(inputs, weights, forward_buffer, outputs)
+        _FFMLP._half(inputs, weights, forward_buffer, outputs)
+        check(_lib.load().lae_ffmlp_forward(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
+                                            activation, output_activation, ptr(forward_buffer), ptr(outputs), stream()),
+              "ffmlp_forward")
+
+    @staticmethod
+    def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                        inference_buffer, outputs):
+        need_cuda(inputs, weights, outputs); need_contig(inputs, weights, outputs)
+        _FFMLP._half(inputs, weights, outputs)
+        check(_lib.load().lae_ffmlp_inference(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
+                                              activation, output_activation, ptr(inference_buffer), ptr(outputs), stream()),
+              "ffmlp_inference")
+
+    @staticmethod
+    def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                       output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+        ts = (grad, inputs, weights, forward_buffer, backward_buffer, grad_inputs, grad_weights)
+        need_cuda(*ts); need_contig(*ts); _FFMLP._half(*ts)
+        check(_lib.load().lae_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim,
+                                             output_dim, hidden_dim, num_layers, activation, output_activation,
+                                             int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
+                                             ptr(grad_weights), stream()), "ffmlp_backward")
+
+    @staticmethod
+    def allocate_splitk(size):
+        check(_lib.load().lae_allocate_splitk(int(size)), "allocate_splitk")
+
+    @staticmethod
+    def free_splitk():
+        check(_lib.load().lae_free_splitk(), "free_splitk")
+
+
+raymarching_backend = _RayMarching
+gridencoder_backend = _GridEncoder
+shencoder_backend = _SHEncoder
+ffmlp_backend = _FFMLP
+
+
+def _as_module(name, cls):
+    m = types.ModuleType(name)
+    for k, v in vars(cls).items():
+        if not k.startswith("_") and isinstance(v, staticmethod):
+            setattr(m, k, v.__func__)
+    m.__doc__ = f"laenerf_amd HIP backend standing in for the reference's `{name}` extension"
+    return m
+
+
+def install_as_reference_backends():
+    """Make `import _raymarching / _gridencoder / _shencoder / _ffmlp` resolve to the HIP backend, so the
+    reference's own Python (raymarching.py, grid.py, sphere_harmonics.py, ffmlp.py, nerf/renderer.py,
+    editing/*) runs on it unmodified."""
+    _lib.load()
+    for name, cls in (("_raymarching", _RayMarching), ("_gridencoder", _GridEncoder), ("_shencoder", _SHEncoder),
+                      ("_ffmlp", _FFMLP)):
+        sys.modules[name] = _as_module(name, cls)

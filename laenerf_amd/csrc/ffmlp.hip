@@ -1,0 +1,495 @@
+// ffmlp.hip -- fully fused bias-free fp16 MLP on the CDNA4 matrix cores.
+//
+// Replaces ffmlp/src/ffmlp.cu (+ the vendored CUTLASS split-K GEMMs) of the
+// reference.  Layout contract (ffmlp.cu:631-634): weights = W0[hidden,in] |
+// W1..[hidden,hidden] | Wout[16,hidden], every matrix [out,in] row-major, no
+// bias; activations row-major [B, width] fp16; forward_buffer[l] holds the
+// post-activation output of matmul l; backward_buffer[k] holds dL/d(output of
+// matmul num_layers-1-k).
+//
+// MFMA mapping (v_mfma_f32_16x16x16_f16, wave64): the network is evaluated
+// TRANSPOSED, H^T = W * X^T, i.e. the weight matrix is the A operand
+// (M = out features) and the batch is the N dimension.  In that orientation the
+// C/D fragment of M-tile t (lane = batch column, 4 regs = 4 consecutive features)
+// is bit-for-bit the B fragment of K-step t of the next layer, so activations
+// chain through all layers in registers: no LDS, no shuffles.  Accumulation is
+// fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
+#include <mutex>
+#include "lae_common.h"
+
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+
+#define K_ACT 10.0f   // ffmlp/src/utils.h:41
+__device__ __forceinline__ float act_fwd(uint32_t a, float v) {           // utils.h:424-470
+    switch (a) {
+        case LAE_ACT_RELU: return v > 0.0f ? v : 0.0f;
+        case LAE_ACT_EXPONENTIAL: return expf(v);
+        case LAE_ACT_SINE: return sinf(v);
+        case LAE_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case LAE_ACT_SQUAREPLUS: { const float x = v * K_ACT; return 0.5f * (x + sqrtf(x * x + 4)) / K_ACT; }
+        case LAE_ACT_SOFTPLUS: return logf(expf(v * K_ACT) + 1.0f) / K_ACT;
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_bwd(uint32_t a, float g, float fwd) { // utils.h:537-582
+    switch (a) {
+        case LAE_ACT_RELU: return fwd > 0.0f ? g : 0.0f;
+        case LAE_ACT_EXPONENTIAL: return g * fwd;
+        case LAE_ACT_SINE: return g;
+        case LAE_ACT_SIGMOID: return g * (fwd * (1 - fwd));
+        case LAE_ACT_SQUAREPLUS: { const float y = fwd * K_ACT; return g * (y * y / (y * y + 1)); }
+        case LAE_ACT_SOFTPLUS: return g * (1.0f - expf(-fwd * K_ACT));
+        default: return g;
+    }
+}
+
+constexpr int MLP_BLOCK = 256;   // 4 waves
+
+// store a D-layout tile set (features 16*mt + 4g + r of batch row `row`) as row-major halves
+template <int MT>
+__device__ __forceinline__ void store_tiles(half_t* __restrict__ dst, size_t row, uint32_t width, int g, const h4 (&h)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) *reinterpret_cast<h4*>(dst + row * width + mt * 16 + 4 * g) = h[mt];
+}
+
+// ---------------------------------------------------------------- forward / inference
+// ffmlp.cu:331-407 (kernel_mlp_fused).  One wave owns NT tiles of 16 batch rows at a time.
+template <int WIDTH, int NT>
+__global__ __launch_bounds__(MLP_BLOCK) void k_mlp_fwd(
+    const half_t* __restrict__ in, const half_t* __restrict__ W, uint32_t in_dim, uint32_t n_hidden, uint32_t act,
+    uint32_t out_act, half_t* __restrict__ fwd_buf, half_t* __restrict__ out, uint32_t B, uint32_t n_groups) {
+    constexpr int MT = WIDTH / 16;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (MLP_BLOCK / 64);
+    for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
+        const size_t row0 = (size_t)grp * 16 * NT;
+        f4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f4{0, 0, 0, 0};
+        // input layer, K = in_dim
+        for (uint32_t kt = 0; kt < in_dim / 16; kt++) {
+            h4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+                b[nt] = *reinterpret_cast<const h4*>(in + (row0 + nt * 16 + c) * in_dim + kt * 16 + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const h4 a = *reinterpret_cast<const h4*>(W + (size_t)(mt * 16 + c) * in_dim + kt * 16 + 4 * g);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16(a, b[nt], acc[mt][nt]);
+            }
+        }
+        h4 h[NT][MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[nt][mt][r] = (half_t)act_fwd(act, acc[mt][nt][r]);
+            if (fwd_buf) store_tiles<MT>(fwd_buf, row0 + nt * 16 + c, WIDTH, g, h[nt]);
+        }
+        const half_t* Wl = W + (size_t)WIDTH * in_dim;
+        for (uint32_t l = 0; l < n_hidden; l++) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f4{0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < MT; kt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h4 a = *reinterpret_cast<const h4*>(Wl + (size_t)(mt * 16 + c) * WIDTH + kt * 16 + 4 * g);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16(a, h[nt][kt], acc[mt][nt]);
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[nt][mt][r] = (half_t)act_fwd(act, acc[mt][nt][r]);
+                if (fwd_buf) store_tiles<MT>(fwd_buf + (size_t)(l + 1) * B * WIDTH, row0 + nt * 16 + c, WIDTH, g, h[nt]);
+            }
+            Wl += (size_t)WIDTH * WIDTH;
+        }
+        // output layer: 16 padded outputs (ffmlp.cu:242-302)
+        f4 o[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) o[nt] = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int kt = 0; kt < MT; kt++) {
+            const h4 a = *reinterpret_cast<const h4*>(Wl + (size_t)c * WIDTH + kt * 16 + 4 * g);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) o[nt] = mfma16(a, h[nt][kt], o[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            h4 v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = (half_t)act_fwd(out_act, o[nt][r]);
+            *reinterpret_cast<h4*>(out + (row0 + nt * 16 + c) * 16 + 4 * g) = v;
+        }
+    }
+}
+
+// transposed A fragment: A[row = c][k = 4g + j] = Wm[(k0 + 4g + j) * ld + col0 + c]
+__device__ __forceinline__ h4 load_wT(const half_t* __restrict__ Wm, uint32_t ld, uint32_t k0, uint32_t col0, int c, int g) {
+    const half_t* p = Wm + (size_t)(k0 + 4 * g) * ld + col0 + c;
+    h4 a;
+    a[0] = p[0]; a[1] = p[ld]; a[2] = p[2 * (size_t)ld]; a[3] = p[3 * (size_t)ld];
+    return a;
+}
+
+// ---------------------------------------------------------------- backward through the activations
+// ffmlp.cu:410-518 (kernel_mlp_fused_backward) + the dL/dinput GEMM of :880-887
+template <int WIDTH, int NT>
+__global__ __launch_bounds__(MLP_BLOCK) void k_mlp_bwd(
+    const half_t* __restrict__ grad, const half_t* __restrict__ W, const half_t* __restrict__ fwd_buf, uint32_t in_dim,
+    uint32_t n_hidden, uint32_t act, half_t* __restrict__ bwd_buf, half_t* __restrict__ grad_in, uint32_t B,
+    uint32_t n_groups) {
+    constexpr int MT = WIDTH / 16;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (MLP_BLOCK / 64);
+    const half_t* Wout = W + (size_t)WIDTH * in_dim + (size_t)WIDTH * WIDTH * n_hidden;
+    for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
+        const size_t row0 = (size_t)grp * 16 * NT;
+        f4 acc[MT][NT];
+        h4 d[NT][MT];
+        // output layer: dH = Wout^T dY, K = 16 outputs
+        {
+            h4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b[nt] = *reinterpret_cast<const h4*>(grad + (row0 + nt * 16 + c) * 16 + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const h4 a = load_wT(Wout, WIDTH, 0, mt * 16, c, g);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16(a, b[nt], f4{0, 0, 0, 0});
+            }
+            const half_t* f = fwd_buf + (size_t)n_hidden * B * WIDTH;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h4 fv = *reinterpret_cast<const h4*>(f + (row0 + nt * 16 + c) * WIDTH + mt * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) d[nt][mt][r] = (half_t)act_bwd(act, acc[mt][nt][r], (float)fv[r]);
+                }
+                store_tiles<MT>(bwd_buf, row0 + nt * 16 + c, WIDTH, g, d[nt]);
+            }
+        }
+        // hidden layers, last to first
+        for (uint32_t k = 0; k < n_hidden; k++) {
+            const half_t* Wl = W + (size_t)WIDTH * in_dim + (size_t)WIDTH * WIDTH * (n_hidden - 1 - k);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f4{0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < MT; kt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h4 a = load_wT(Wl, WIDTH, kt * 16, mt * 16, c, g);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16(a, d[nt][kt], acc[mt][nt]);
+                }
+            const half_t* f = fwd_buf + (size_t)(n_hidden - 1 - k) * B * WIDTH;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const h4 fv = *reinterpret_cast<const h4*>(f + (row0 + nt * 16 + c) * WIDTH + mt * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) d[nt][mt][r] = (half_t)act_bwd(act, acc[mt][nt][r], (float)fv[r]);
+                }
+                store_tiles<MT>(bwd_buf + (size_t)(k + 1) * B * WIDTH, row0 + nt * 16 + c, WIDTH, g, d[nt]);
+            }
+        }
+        // dL/dinput = W0^T dH0 (no activation)
+        if (grad_in) {
+            for (uint32_t it = 0; it < in_dim / 16; it++) {
+                f4 gi[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) gi[nt] = f4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < MT; kt++) {
+                    const h4 a = load_wT(W, in_dim, kt * 16, it * 16, c, g);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) gi[nt] = mfma16(a, d[nt][kt], gi[nt]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    h4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = (half_t)gi[nt][r];
+                    *reinterpret_cast<h4*>(grad_in + (row0 + nt * 16 + c) * in_dim + it * 16 + 4 * g) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- weight gradients
+// dW[o][i] = sum_b dY[b][o] * A[b][i]  (ffmlp.cu:800-877, the reference's split-K CUTLASS GEMMs).
+// blockIdx.y = job = (matrix, 64x64 output block); blockIdx.x = batch slice.  Each wave
+// accumulates a 4x4 block of 16x16 tiles over its rows, the 4 waves of the group are summed in
+// LDS, and one fp32 slab per (slice, matrix) goes to the workspace; k_dw_reduce sums the slabs
+// in slice order (deterministic) and rounds once to fp16.
+struct DwJob { uint32_t mat, mb, nb; };
+
+__device__ __forceinline__ DwJob decode_job(uint32_t job, uint32_t MB, uint32_t NB0, uint32_t n_hidden) {
+    DwJob j;
+    if (job < MB * NB0) { j.mat = 0; j.mb = job / NB0; j.nb = job % NB0; return j; }
+    job -= MB * NB0;
+    const uint32_t per = MB * MB;
+    if (job < per * n_hidden) { j.mat = 1 + job / per; const uint32_t r = job % per; j.mb = r / MB; j.nb = r % MB; return j; }
+    job -= per * n_hidden;
+    j.mat = n_hidden + 1; j.mb = 0; j.nb = job;
+    return j;
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
+    const half_t* __restrict__ grad, const half_t* __restrict__ inputs, const half_t* __restrict__ fwd_buf,
+    const half_t* __restrict__ bwd_buf, uint32_t B, uint32_t in_dim, uint32_t n_hidden, float* __restrict__ slabs,
+    uint32_t nW, uint32_t rows_per_slice) {
+    constexpr uint32_t MT = WIDTH / 16;
+    constexpr uint32_t MB = (MT + 3) / 4;
+    const uint32_t NB0 = (in_dim / 16 + 3) / 4;
+    const DwJob job = decode_job(blockIdx.y, MB, NB0, n_hidden);
+    // operands of this matrix
+    const half_t* dY; const half_t* A; uint32_t OUT, IN; size_t w_off;
+    if (job.mat == 0) { dY = bwd_buf + (size_t)n_hidden * B * WIDTH; A = inputs; OUT = WIDTH; IN = in_dim; w_off = 0; }
+    else if (job.mat <= n_hidden) {
+        dY = bwd_buf + (size_t)(n_hidden - job.mat) * B * WIDTH; A = fwd_buf + (size_t)(job.mat - 1) * B * WIDTH;
+        OUT = WIDTH; IN = WIDTH; w_off = (size_t)WIDTH * in_dim + (size_t)WIDTH * WIDTH * (job.mat - 1);
+    } else { dY = grad; A = fwd_buf + (size_t)n_hidden * B * WIDTH; OUT = 16; IN = WIDTH;
+             w_off = (size_t)WIDTH * in_dim + (size_t)WIDTH * WIDTH * n_hidden; }
+    const uint32_t mt0 = job.mb * 4, nt0 = job.nb * 4;
+    const uint32_t mt_n = min(4u, OUT / 16 - mt0), nt_n = min(4u, IN / 16 - nt0);
+
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f4{0, 0, 0, 0};
+
+    const size_t r_begin = (size_t)blockIdx.x * rows_per_slice;
+    const size_t r_end = min((size_t)B, r_begin + rows_per_slice);
+    for (size_t b0 = r_begin + (size_t)w * 16; b0 < r_end; b0 += 16 * (MLP_BLOCK / 64)) {
+        h4 a[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if ((uint32_t)i < mt_n) {
+                const half_t* p = dY + (b0 + 4 * g) * OUT + (mt0 + i) * 16 + c;
+                a[i][0] = p[0]; a[i][1] = p[OUT]; a[i][2] = p[2 * (size_t)OUT]; a[i][3] = p[3 * (size_t)OUT];
+            }
+            if ((uint32_t)i < nt_n) {
+                const half_t* q = A + (b0 + 4 * g) * IN + (nt0 + i) * 16 + c;
+                bf[i][0] = q[0]; bf[i][1] = q[IN]; bf[i][2] = q[2 * (size_t)IN]; bf[i][3] = q[3 * (size_t)IN];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((uint32_t)i < mt_n && (uint32_t)j < nt_n) acc[i][j] = mfma16(a[i], bf[j], acc[i][j]);
+    }
+    // sum the 4 waves in LDS (wave order fixed by the barriers -> deterministic)
+    __shared__ float red[16 * 256];
+    for (int ww = 0; ww < MLP_BLOCK / 64; ww++) {
+        if (w == ww) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float* p = &red[(i * 4 + j) * 256 + (4 * g + r) * 16 + c];
+                        *p = (ww == 0) ? acc[i][j][r] : (*p + acc[i][j][r]);
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = slabs + (size_t)blockIdx.x * nW + w_off;
+    for (uint32_t e = threadIdx.x; e < 16 * 256; e += MLP_BLOCK) {
+        const uint32_t t = e >> 8, i = t >> 2, j = t & 3, rr = (e >> 4) & 15, cc = e & 15;
+        if (i < mt_n && j < nt_n) slab[(size_t)((mt0 + i) * 16 + rr) * IN + (nt0 + j) * 16 + cc] = red[e];
+    }
+}
+
+__global__ void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW, half_t* __restrict__ gw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nW) return;
+    float s = 0;
+    for (uint32_t k = 0; k < n_slices; k++) s += slabs[(size_t)k * nW + i];
+    gw[i] = (half_t)s;
+}
+
+// ---------------------------------------------------------------- host side
+// Process-global split-K workspace, the counterpart of the reference's static stream/event
+// vectors + per-stream CUTLASS workspace (ffmlp.cu:711-740, cutlass_matmul.h:335-352).
+std::mutex g_ws_mutex;
+float* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+constexpr size_t WS_DEFAULT_BYTES = 48ull << 20;
+
+int ensure_workspace(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    if (g_ws_bytes >= bytes) return LAE_OK;
+    if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
+    const size_t want = bytes > WS_DEFAULT_BYTES ? bytes : WS_DEFAULT_BYTES;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_ws), want);
+    if (e != hipSuccess) { lae::set_last_error("ffmlp workspace hipMalloc", e); return LAE_ELAUNCH; }
+    g_ws_bytes = want;
+    return LAE_OK;
+}
+
+int n_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+bool shape_ok(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t hidden, uint32_t num_layers) {
+    // ffmlp.py:112-115,157: hidden in {16..256}, in % 16 == 0, out <= 16 (always padded to 16), layers >= 2, B % 128 == 0
+    const bool hid = hidden == 16 || hidden == 32 || hidden == 64 || hidden == 128 || hidden == 256;
+    return hid && in_dim > 0 && in_dim % 16 == 0 && out_dim == 16 && num_layers >= 2 && B % 16 == 0;
+}
+
+template <int WIDTH, int NT>
+void launch_fwd(const half_t* in, const half_t* W, uint32_t B, uint32_t in_dim, uint32_t n_hidden, uint32_t act,
+                uint32_t out_act, half_t* fwd_buf, half_t* out, hipStream_t s) {
+    const uint32_t n_groups = B / (16 * NT);
+    const uint32_t blocks = min(lae::cdiv(n_groups, MLP_BLOCK / 64), (uint32_t)n_cus() * 4);
+    k_mlp_fwd<WIDTH, NT><<<blocks, MLP_BLOCK, 0, s>>>(in, W, in_dim, n_hidden, act, out_act, fwd_buf, out, B, n_groups);
+}
+
+template <int WIDTH>
+void forward_w(const half_t* in, const half_t* W, uint32_t B, uint32_t in_dim, uint32_t n_hidden, uint32_t act,
+               uint32_t out_act, half_t* fwd_buf, half_t* out, hipStream_t s) {
+    constexpr int NT = WIDTH <= 64 ? 2 : 1;
+    if (B % (16 * NT) == 0) launch_fwd<WIDTH, NT>(in, W, B, in_dim, n_hidden, act, out_act, fwd_buf, out, s);
+    else launch_fwd<WIDTH, 1>(in, W, B, in_dim, n_hidden, act, out_act, fwd_buf, out, s);
+}
+
+int forward_any(const void* inputs, const void* weights, uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t hidden,
+                uint32_t num_layers, uint32_t act, uint32_t out_act, void* fwd_buf, void* outputs, void* stream) {
+    if (B == 0) return LAE_OK;
+    if (!inputs || !weights || !outputs) return LAE_ENULL;
+    if (!shape_ok(B, in_dim, out_dim, hidden, num_layers) || act > 6 || out_act > 6) return LAE_EINVAL;
+    const half_t* in = (const half_t*)inputs; const half_t* W = (const half_t*)weights;
+    half_t* fb = (half_t*)fwd_buf; half_t* out = (half_t*)outputs;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t nh = num_layers - 1;
+    switch (hidden) {
+        case 16: forward_w<16>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
+        case 32: forward_w<32>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
+        case 64: forward_w<64>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
+        case 128: forward_w<128>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
+        case 256: forward_w<256>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
+        default: return LAE_EINVAL;       // ffmlp.cu:658
+    }
+    return lae::check_launch("ffmlp_forward");
+}
+
+template <int WIDTH>
+int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half_t* fwd_buf, uint32_t B, uint32_t in_dim,
+               uint32_t n_hidden, uint32_t act, half_t* bwd_buf, half_t* grad_in, half_t* gw, hipStream_t s) {
+    constexpr int NT = WIDTH <= 64 ? 2 : 1;
+    {
+        const bool nt2 = NT == 2 && B % 32 == 0;
+        const uint32_t n_groups = B / (nt2 ? 32 : 16);
+        const uint32_t blocks = min(lae::cdiv(n_groups, MLP_BLOCK / 64), (uint32_t)n_cus() * 4);
+        if (nt2) k_mlp_bwd<WIDTH, NT><<<blocks, MLP_BLOCK, 0, s>>>(grad, W, fwd_buf, in_dim, n_hidden, act, bwd_buf, grad_in, B, n_groups);
+        else k_mlp_bwd<WIDTH, 1><<<blocks, MLP_BLOCK, 0, s>>>(grad, W, fwd_buf, in_dim, n_hidden, act, bwd_buf, grad_in, B, n_groups);
+    }
+    const uint32_t nW = WIDTH * (in_dim + WIDTH * n_hidden + 16);
+    constexpr uint32_t MT = WIDTH / 16, MB = (MT + 3) / 4;
+    const uint32_t NB0 = (in_dim / 16 + 3) / 4;
+    const uint32_t n_jobs = MB * NB0 + MB * MB * n_hidden + MB;
+    // slices: aim for ~4 workgroups per CU in total, at least 64 rows per slice, bounded by the workspace
+    uint32_t n_slices = max(1u, min(B / 64, (uint32_t)(n_cus() * 4) / n_jobs));
+    int rc = ensure_workspace((size_t)n_slices * nW * sizeof(float));
+    if (rc) return rc;
+    uint32_t rows_per_slice = lae::cdiv(B, n_slices);
+    rows_per_slice = (rows_per_slice + 63) / 64 * 64;
+    n_slices = lae::cdiv(B, rows_per_slice);
+    k_mlp_dw<WIDTH><<<dim3(n_slices, n_jobs), MLP_BLOCK, 0, s>>>(grad, in, fwd_buf, bwd_buf, B, in_dim, n_hidden, g_ws, nW,
+                                                                 rows_per_slice);
+    k_dw_reduce<<<lae::cdiv(nW, 256), 256, 0, s>>>(g_ws, n_slices, nW, gw);
+    return LAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lae_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                      void* forward_buffer, void* outputs, void* stream) {
+    if (B > 0 && !forward_buffer) return LAE_ENULL;
+    return forward_any(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                       forward_buffer, outputs, stream);
+}
+
+int lae_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                        void* inference_buffer, void* outputs, void* stream) {
+    (void)inference_buffer;   // activations never leave the registers
+    return forward_any(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                       nullptr, outputs, stream);
+}
+
+int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                       uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
+                       void* grad_inputs, void* grad_weights, void* stream) {
+    (void)output_activation;   // the reference ignores it too (ffmlp.cu:781)
+    if (B == 0) return LAE_OK;
+    if (!grad || !inputs || !weights || !forward_buffer || !backward_buffer || !grad_weights) return LAE_ENULL;
+    if (calc_grad_inputs && !grad_inputs) return LAE_ENULL;
+    if (!shape_ok(B, input_dim, output_dim, hidden_dim, num_layers) || activation > 6) return LAE_EINVAL;
+    const half_t* g = (const half_t*)grad; const half_t* in = (const half_t*)inputs; const half_t* W = (const half_t*)weights;
+    const half_t* fb = (const half_t*)forward_buffer; half_t* bb = (half_t*)backward_buffer;
+    half_t* gi = calc_grad_inputs ? (half_t*)grad_inputs : nullptr; half_t* gw = (half_t*)grad_weights;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t nh = num_layers - 1;
+    int rc;
+    switch (hidden_dim) {
+        case 16: rc = backward_w<16>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
+        case 32: rc = backward_w<32>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
+        case 64: rc = backward_w<64>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
+        case 128: rc = backward_w<128>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
+        case 256: rc = backward_w<256>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
+        default: return LAE_EINVAL;
+    }
+    if (rc) return rc;
+    return lae::check_launch("ffmlp_backward");
+}
+
+int lae_allocate_splitk(uint64_t size) {
+    (void)size;   // number of side streams in the reference; one stream suffices here.
+    return LAE_OK;  // the slab workspace is allocated on the first backward call (needs a device)
+}
+
+int lae_free_splitk(void) {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
+    return LAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,549 @@
+// gridencoder.hip -- multiresolution hash / tiled grid encoder for gfx950.
+//
+// Replaces gridencoder/src/gridencoder.cu of the reference (cited per kernel).
+//
+// MI355X mapping: one lane = one (sample, level).  Blocks are dealt round-robin
+// over the 8 XCDs (block b and b+8 share an XCD, MI355X_MICROARCH "Workgroup
+// dispatch"), and each XCD has a private 4 MiB L2.  When L is a multiple of 8 the
+// blockIdx -> (level, chunk) map sends all blocks of level l to XCD (l mod 8), one
+// level at a time, so a hashed level's table (2 MiB fp16 / 4 MiB fp32 at T=2^19)
+// is gathered out of ONE L2 instead of being replicated into all eight.
+//
+// Per-level scale = exp2(level*S)*H - 1 is evaluated once on the host (the
+// reference evaluates exp2f per thread, gridencoder.cu:138) and passed by value;
+// the oracle uses the same host libm, so fp32 results are bit-identical to it.
+#include <math.h>
+#include "lae_common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 32;
+struct LevelScales { float scale[MAX_LEVELS]; };
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__constant__ uint32_t k_primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+
+// block-uniform description of one level (all derived from scalars -> SGPRs)
+template <int D>
+struct LevelInfo {
+    float scale;
+    uint32_t resolution, hashmap_size, table_off;
+    uint32_t stride[D];      // dense strides of the dims that fit (gridencoder.cu:72-75)
+    uint32_t ndense;         // how many dims the dense loop consumed
+    bool use_hash, pow2;
+};
+
+template <int D>
+__device__ __forceinline__ LevelInfo<D> level_info(const LevelScales& sc, const int32_t* __restrict__ offsets,
+                                                   uint32_t level, uint32_t gridtype, bool align_corners) {
+    LevelInfo<D> li;
+    li.scale = sc.scale[level];
+    li.resolution = (uint32_t)ceilf(li.scale) + 1;
+    li.table_off = (uint32_t)offsets[level];
+    li.hashmap_size = (uint32_t)offsets[level + 1] - li.table_off;
+    uint32_t stride = 1;
+    li.ndense = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        li.stride[d] = 0;
+        if (li.ndense == (uint32_t)d && stride <= li.hashmap_size) {
+            li.stride[d] = stride;
+            stride *= align_corners ? li.resolution : (li.resolution + 1);
+            li.ndense = d + 1;
+        }
+    }
+    li.use_hash = (gridtype == 0) && (stride > li.hashmap_size);
+    li.pow2 = (li.hashmap_size & (li.hashmap_size - 1)) == 0;
+    return li;
+}
+
+// gridencoder.cu:66-84
+template <int D>
+__device__ __forceinline__ uint32_t cell_index(const LevelInfo<D>& li, const uint32_t (&pg)[D]) {
+    uint32_t index = 0;
+    if (li.use_hash) {
+#pragma unroll
+        for (int d = 0; d < D; d++) index ^= pg[d] * k_primes[d];
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; d++) index += pg[d] * li.stride[d];   // stride 0 for dims the loop skipped
+    }
+    return li.pow2 ? (index & (li.hashmap_size - 1)) : (index % li.hashmap_size);
+}
+
+__device__ __forceinline__ void block_to_level_chunk(uint32_t nb, bool xcd_mode, uint32_t& level, uint32_t& chunk) {
+    const uint32_t bid = blockIdx.x;
+    if (xcd_mode) {
+        const uint32_t xcd = bid & 7u, j = bid >> 3;
+        level = xcd + 8u * (j / nb);
+        chunk = j % nb;
+    } else {
+        level = bid / nb;
+        chunk = bid % nb;
+    }
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+
+// accumulate r += w * v with the reference's rounding: fp32 -> one FMA (nvcc contraction of
+// `results[ch] += w * grid[..]`), fp16 -> float product and sum, rounded to half (:187)
+__device__ __forceinline__ void accum(float& r, float w, float v) { r = fmaf(w, v, r); }
+__device__ __forceinline__ void accum(half_t& r, float w, half_t v) { r = (half_t)((float)r + w * (float)v); }
+
+constexpr int GRID_BLOCK = 256;
+
+// ---------------------------------------------------------------- K13
+// gridencoder.cu:87-245.  out index = b*os_b + level*os_l + ch  ([L,B,C]: os_b=C, os_l=B*C; [B,L*C]: os_b=L*C, os_l=C)
+template <typename T, int D, int C>
+__global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
+    const float* __restrict__ inputs, const T* __restrict__ grid, const int32_t* __restrict__ offsets,
+    T* __restrict__ outputs, uint32_t B, uint32_t L, LevelScales sc, T* __restrict__ dy_dx, uint32_t gridtype,
+    bool align_corners, uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t os_b, uint64_t os_l) {
+    uint32_t level, chunk;
+    block_to_level_chunk(nb, xcd_mode, level, chunk);
+    if (level >= L) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
+    const T* __restrict__ tab = grid + (size_t)li.table_off * C;
+
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
+    }
+    T* out = outputs + (size_t)b * os_b + (size_t)level * os_l;
+    T* dout = dy_dx ? dy_dx + (size_t)b * D * L * C + (size_t)level * D * C : nullptr;
+    if (oob) {                                             // :118-135
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) out[ch] = (T)0.0f;
+        if (dout) {
+#pragma unroll
+            for (int i = 0; i < D * C; i++) dout[i] = (T)0.0f;
+        }
+        return;
+    }
+
+    float frac[D], dfrac[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {                          // :146-159
+        float p = fmaf(x[d], li.scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)fl;
+        p -= (float)pg[d];
+        if (interp == 1) { dfrac[d] = 6 * p * (1.0f - p); p = p * p * (3.0f - 2.0f * p); }
+        else dfrac[d] = 1.0f;
+        frac[d] = p;
+    }
+
+    T res[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) res[ch] = (T)0.0f;
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {             // :166-191
+        float w = 1.0f;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) { w *= 1 - frac[d]; pgl[d] = pg[d]; }
+            else { w *= frac[d]; pgl[d] = pg[d] + 1; }
+        }
+        const uint32_t gi = cell_index<D>(li, pgl) * C;
+        T v[C];
+        if constexpr (C == 2 && sizeof(T) == 2) {
+            const half2_t h = *reinterpret_cast<const half2_t*>(tab + gi);
+            v[0] = h[0]; v[1] = h[1];
+        } else if constexpr (C == 2 && sizeof(T) == 4) {
+            const float2 h = *reinterpret_cast<const float2*>(tab + gi);
+            v[0] = h.x; v[1] = h.y;
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) v[ch] = tab[gi + ch];
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) accum(res[ch], w, v[ch]);
+    }
+    if constexpr (C == 2 && sizeof(T) == 2) {
+        half2_t h = {res[0], res[1]};
+        *reinterpret_cast<half2_t*>(out) = h;
+    } else if constexpr (C == 2 && sizeof(T) == 4) {
+        *reinterpret_cast<float2*>(out) = make_float2(res[0], res[1]);
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) out[ch] = res[ch];
+    }
+
+    if (dout) {                                            // :201-243
+#pragma unroll
+        for (int gd = 0; gd < D; gd++) {
+            T rg[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) rg[ch] = (T)0.0f;
+#pragma unroll
+            for (int idx = 0; idx < (1 << (D - 1)); idx++) {
+                float w = li.scale;
+                uint32_t pgl[D];
+#pragma unroll
+                for (int nd = 0; nd < D - 1; nd++) {
+                    const int d = (nd >= gd) ? nd + 1 : nd;
+                    if ((idx & (1 << nd)) == 0) { w *= 1 - frac[d]; pgl[d] = pg[d]; }
+                    else { w *= frac[d]; pgl[d] = pg[d] + 1; }
+                }
+                pgl[gd] = pg[gd];
+                const uint32_t il = cell_index<D>(li, pgl) * C;
+                pgl[gd] = pg[gd] + 1;
+                const uint32_t ir = cell_index<D>(li, pgl) * C;
+#pragma unroll
+                for (int ch = 0; ch < C; ch++) {
+                    if constexpr (sizeof(T) == 2) {
+                        const half_t diff = (half_t)((float)tab[ir + ch] - (float)tab[il + ch]);
+                        rg[ch] = (half_t)((float)rg[ch] + w * (float)diff * dfrac[gd]);
+                    } else {
+                        rg[ch] += w * (tab[ir + ch] - tab[il + ch]) * dfrac[gd];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) dout[gd * C + ch] = rg[ch];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K14
+// gridencoder.cu:248-340: scatter w*grad into grad_grid.  v1: one no-return atomic per
+// (corner, channel pair): global_atomic_add_f32 / global_atomic_pk_add_f16.
+template <typename T, int D, int C>
+__global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
+    const T* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
+    T* __restrict__ grad_grid, uint32_t B, uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners,
+    uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t gs_b, uint64_t gs_l) {
+    uint32_t level, chunk;
+    block_to_level_chunk(nb, xcd_mode, level, chunk);
+    if (level >= L) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
+    T* __restrict__ tab = grad_grid + (size_t)li.table_off * C;
+
+    float frac[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const float xv = inputs[(size_t)b * D + d];
+        if (xv < 0.0f || xv > 1.0f) return;                // :276-281
+        float p = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)fl;
+        p -= (float)pg[d];
+        if (interp == 1) p = p * p * (3.0f - 2.0f * p);
+        frac[d] = p;
+    }
+    const T* g = grad + (size_t)b * gs_b + (size_t)level * gs_l;
+    float gc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) gc[ch] = (float)g[ch];
+
+#pragma unroll
+    for (int idx = 0; idx < (1 << D); idx++) {
+        float w = 1.0f;
+        uint32_t pgl[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if ((idx & (1 << d)) == 0) { w *= 1 - frac[d]; pgl[d] = pg[d]; }
+            else { w *= frac[d]; pgl[d] = pg[d] + 1; }
+        }
+        const uint32_t gi = cell_index<D>(li, pgl) * C;
+        if constexpr (sizeof(T) == 2) {
+            static_assert(C % 2 == 0 || sizeof(T) == 4, "fp16 grads need an even channel count");
+#pragma unroll
+            for (int ch = 0; ch < C; ch += 2) {
+                half2_t v = {(half_t)(w * gc[ch]), (half_t)(w * gc[ch + 1])};      // :329
+                __builtin_amdgcn_global_atomic_fadd_v2f16(
+                    (__attribute__((address_space(1))) half2_t*)(tab + gi + ch), v);
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) atomicAdd(tab + gi + ch, w * gc[ch]);     // :336
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K15
+// gridencoder.cu:343-369
+template <typename T>
+__global__ void k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
+                                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint64_t gs_b, uint64_t gs_l) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* dd = dy_dx + (size_t)b * L * D * C;
+    T r = (T)0.0f;
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const T gv = grad[(size_t)b * gs_b + (size_t)l * gs_l + ch];
+            const T dv = dd[(size_t)l * D * C + d * C + ch];
+            if constexpr (sizeof(T) == 2) r = (half_t)((float)r + (float)(half_t)((float)gv * (float)dv));
+            else r += gv * dv;
+        }
+    grad_inputs[t] = r;
+}
+
+// ---------------------------------------------------------------- K16
+// gridencoder.cu:506-610 (fp32 only: grid.py:165 runs it with autocast disabled)
+template <int D, int C>
+__global__ __launch_bounds__(GRID_BLOCK) void k_grad_tv(const float* __restrict__ inputs, const float* __restrict__ grid,
+                                                         float* __restrict__ grad, const int32_t* __restrict__ offsets,
+                                                         float weight, uint32_t B, uint32_t L, LevelScales sc,
+                                                         uint32_t gridtype, bool align_corners, uint32_t nb) {
+    uint32_t level, chunk;
+    block_to_level_chunk(nb, false, level, chunk);
+    if (level >= L) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    if (b >= B) return;
+    const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
+    const float* tab = grid + (size_t)li.table_off * C;
+    float* gtab = grad + (size_t)li.table_off * C;
+    uint32_t pg[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const float xv = inputs[(size_t)b * D + d];
+        if (xv < 0.0f || xv > 1.0f) return;
+        pg[d] = (uint32_t)floorf(fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f));
+    }
+    float res[C], idelta[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) { res[ch] = 0; idelta[ch] = 0; }
+    const uint32_t index = cell_index<D>(li, pg) * C;
+    const float w = weight / (float)(2 * D);
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t cur = pg[d];
+        if (cur < li.resolution) {
+            pg[d] = cur + 1;
+            const uint32_t ir = cell_index<D>(li, pg) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) { const float gv = tab[index + ch] - tab[ir + ch]; res[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        if (cur > 0) {
+            pg[d] = cur - 1;
+            const uint32_t il = cell_index<D>(li, pg) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) { const float gv = tab[index + ch] - tab[il + ch]; res[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        pg[d] = cur;
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) atomicAdd(gtab + index + ch, w * res[ch] * (1.0f / sqrtf(idelta[ch] + 1e-9f)));
+}
+
+// ---------------------------------------------------------------- host dispatch
+static int fill_scales(LevelScales& sc, uint32_t L, float S, uint32_t H) {
+    if (L == 0 || L > MAX_LEVELS) return LAE_EINVAL;
+    for (uint32_t l = 0; l < L; l++) sc.scale[l] = fmaf(exp2f((float)l * S), (float)H, -1.0f);   // :138
+    for (uint32_t l = L; l < MAX_LEVELS; l++) sc.scale[l] = 0.f;
+    return LAE_OK;
+}
+
+struct FwdArgs {
+    const float* inputs; const void* emb; const int32_t* offsets; void* out; uint32_t B, L; LevelScales sc;
+    void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
+};
+
+template <typename T, int D, int C>
+static void launch_fwd(const FwdArgs& a) {
+    const uint32_t nb = lae::cdiv(a.B, GRID_BLOCK);
+    const bool xcd = (a.L % 8) == 0;
+    k_grid_fwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
+                                                                a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb,
+                                                                xcd, a.os_b, a.os_l);
+}
+template <typename T, int D>
+static int dispatch_fwd_c(const FwdArgs& a, uint32_t C) {
+    switch (C) {
+        case 1: launch_fwd<T, D, 1>(a); return LAE_OK;
+        case 2: launch_fwd<T, D, 2>(a); return LAE_OK;
+        case 4: launch_fwd<T, D, 4>(a); return LAE_OK;
+        case 8: launch_fwd<T, D, 8>(a); return LAE_OK;
+        default: return LAE_EINVAL;     // gridencoder.cu:381 "C must be 1, 2, 4, or 8"
+    }
+}
+template <typename T>
+static int dispatch_fwd_d(const FwdArgs& a, uint32_t D, uint32_t C) {
+    switch (D) {
+        case 2: return dispatch_fwd_c<T, 2>(a, C);
+        case 3: return dispatch_fwd_c<T, 3>(a, C);
+        case 4: return dispatch_fwd_c<T, 4>(a, C);
+        case 5: return dispatch_fwd_c<T, 5>(a, C);
+        default: return LAE_EINVAL;     // gridencoder.cu:398
+    }
+}
+
+struct BwdArgs {
+    const void* grad; const float* inputs; const int32_t* offsets; void* gemb; uint32_t B, L; LevelScales sc;
+    uint32_t gridtype; bool align; uint32_t interp; uint64_t gs_b, gs_l; hipStream_t stream;
+};
+template <typename T, int D, int C>
+static void launch_bwd(const BwdArgs& a) {
+    const uint32_t nb = lae::cdiv(a.B, GRID_BLOCK);
+    const bool xcd = (a.L % 8) == 0;
+    k_grid_bwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.grad ? (const T*)a.grad : nullptr, a.inputs, a.offsets,
+                                                                (T*)a.gemb, a.B, a.L, a.sc, a.gridtype, a.align,
+                                                                a.interp, nb, xcd, a.gs_b, a.gs_l);
+}
+template <typename T, int D>
+static int dispatch_bwd_c(const BwdArgs& a, uint32_t C) {
+    if constexpr (sizeof(T) == 2) {
+        switch (C) {     // odd C in fp16 is rejected, grid.py:42-44 never produces it
+            case 2: launch_bwd<T, D, 2>(a); return LAE_OK;
+            case 4: launch_bwd<T, D, 4>(a); return LAE_OK;
+            case 8: launch_bwd<T, D, 8>(a); return LAE_OK;
+            default: return LAE_EINVAL;
+        }
+    } else {
+        switch (C) {
+            case 1: launch_bwd<T, D, 1>(a); return LAE_OK;
+            case 2: launch_bwd<T, D, 2>(a); return LAE_OK;
+            case 4: launch_bwd<T, D, 4>(a); return LAE_OK;
+            case 8: launch_bwd<T, D, 8>(a); return LAE_OK;
+            default: return LAE_EINVAL;
+        }
+    }
+}
+template <typename T>
+static int dispatch_bwd_d(const BwdArgs& a, uint32_t D, uint32_t C) {
+    switch (D) {
+        case 2: return dispatch_bwd_c<T, 2>(a, C);
+        case 3: return dispatch_bwd_c<T, 3>(a, C);
+        case 4: return dispatch_bwd_c<T, 4>(a, C);
+        case 5: return dispatch_bwd_c<T, 5>(a, C);
+        default: return LAE_EINVAL;
+    }
+}
+
+static int grid_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype,
+                        int align_corners, uint32_t interp, int dtype, bool blc, void* stream) {
+    if (B == 0) return LAE_OK;
+    if (!inputs || !embeddings || !offsets || !outputs) return LAE_ENULL;
+    if (gridtype > 1 || interp > 1) return LAE_EINVAL;
+    FwdArgs a;
+    a.inputs = inputs; a.emb = embeddings; a.offsets = offsets; a.out = outputs; a.B = B; a.L = L;
+    int rc = fill_scales(a.sc, L, S, H);
+    if (rc) return rc;
+    a.dy_dx = dy_dx; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
+    a.os_b = blc ? (uint64_t)L * C : C;
+    a.os_l = blc ? C : (uint64_t)B * C;
+    a.stream = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == LAE_F32) rc = dispatch_fwd_d<float>(a, D, C);
+    else if (dtype == LAE_F16) rc = dispatch_fwd_d<half_t>(a, D, C);
+    else rc = LAE_EINVAL;
+    if (rc) return rc;
+    return lae::check_launch("grid_encode_forward");
+}
+
+static int grid_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                         void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                         int dtype, bool blc, void* stream) {
+    (void)embeddings;
+    if (B == 0) return LAE_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
+    if (gridtype > 1 || interp > 1) return LAE_EINVAL;
+    BwdArgs a;
+    a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
+    int rc = fill_scales(a.sc, L, S, H);
+    if (rc) return rc;
+    a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
+    a.gs_b = blc ? (uint64_t)L * C : C;
+    a.gs_l = blc ? C : (uint64_t)B * C;
+    a.stream = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == LAE_F32) rc = dispatch_bwd_d<float>(a, D, C);
+    else if (dtype == LAE_F16) rc = dispatch_bwd_d<half_t>(a, D, C);
+    else rc = LAE_EINVAL;
+    if (rc) return rc;
+    if (dy_dx && grad_inputs) {                           // :410 kernel_input_backward
+        const uint32_t n = B * D;
+        if (dtype == LAE_F32)
+            k_grid_input_bwd<float><<<lae::cdiv(n, 256), 256, 0, a.stream>>>((const float*)grad, (const float*)dy_dx,
+                                                                            (float*)grad_inputs, B, D, C, L, a.gs_b, a.gs_l);
+        else
+            k_grid_input_bwd<half_t><<<lae::cdiv(n, 256), 256, 0, a.stream>>>((const half_t*)grad, (const half_t*)dy_dx,
+                                                                             (half_t*)grad_inputs, B, D, C, L, a.gs_b, a.gs_l);
+    }
+    return lae::check_launch("grid_encode_backward");
+}
+
+template <int D>
+static int tv_c(const float* inputs, const float* emb, float* grad, const int32_t* offsets, float weight, uint32_t B,
+                uint32_t C, uint32_t L, const LevelScales& sc, uint32_t gridtype, bool align, hipStream_t s) {
+    const uint32_t nb = lae::cdiv(B, GRID_BLOCK);
+    switch (C) {
+        case 1: k_grad_tv<D, 1><<<nb * L, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, sc, gridtype, align, nb); break;
+        case 2: k_grad_tv<D, 2><<<nb * L, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, sc, gridtype, align, nb); break;
+        case 4: k_grad_tv<D, 4><<<nb * L, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, sc, gridtype, align, nb); break;
+        case 8: k_grad_tv<D, 8><<<nb * L, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, sc, gridtype, align, nb); break;
+        default: return LAE_EINVAL;
+    }
+    return LAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lae_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                            uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* stream) {
+    return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                        dtype, false, stream);
+}
+int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* stream) {
+    return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                        dtype, true, stream);
+}
+int lae_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int dtype, void* stream) {
+    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                         gridtype, align_corners, interp, dtype, false, stream);
+}
+int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                                 int align_corners, uint32_t interp, int dtype, void* stream) {
+    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                         gridtype, align_corners, interp, dtype, true, stream);
+}
+
+int lae_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                             float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             uint32_t gridtype, int align_corners, int dtype, void* stream) {
+    if (B == 0) return LAE_OK;
+    if (!inputs || !embeddings || !grad || !offsets) return LAE_ENULL;
+    if (dtype != LAE_F32 || gridtype > 1) return LAE_EINVAL;
+    LevelScales sc;
+    int rc = fill_scales(sc, L, S, H);
+    if (rc) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool al = align_corners != 0;
+    const float* in = (const float*)inputs; const float* e = (const float*)embeddings; float* g = (float*)grad;
+    switch (D) {
+        case 2: rc = tv_c<2>(in, e, g, offsets, weight, B, C, L, sc, gridtype, al, s); break;
+        case 3: rc = tv_c<3>(in, e, g, offsets, weight, B, C, L, sc, gridtype, al, s); break;
+        case 4: rc = tv_c<4>(in, e, g, offsets, weight, B, C, L, sc, gridtype, al, s); break;
+        case 5: rc = tv_c<5>(in, e, g, offsets, weight, B, C, L, sc, gridtype, al, s); break;
+        default: rc = LAE_EINVAL;
+    }
+    if (rc) return rc;
+    return lae::check_launch("grad_total_variation");
+}
+
+}  // extern "C"

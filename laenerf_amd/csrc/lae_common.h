@@ -1,0 +1,56 @@
+// lae_common.h -- shared host/device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/laenerf.h"
+
+#define LAE_WAVE 64
+
+namespace lae {
+
+void set_last_error(const char* what, hipError_t e);
+
+// every launch is followed by this: the reference never checked its launches
+// (SURVEY 8b "Errors"); we do, and surface the error through the return code.
+static inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error(what, e); return LAE_ELAUNCH; }
+    return LAE_OK;
+}
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// wave64 inclusive scan (Hillis-Steele over __shfl_up); returns inclusive sum
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan for blocks of NW waves; returns exclusive prefix, *total = block sum.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total, uint32_t* lds /*NW+1*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) { uint32_t t = lds[i]; lds[i] = s; s += t; }
+        lds[NW] = s;
+    }
+    __syncthreads();
+    uint32_t r = inc - v + lds[w];
+    *total = lds[NW];
+    __syncthreads();
+    return r;
+}
+
+}  // namespace lae

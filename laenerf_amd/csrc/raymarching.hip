@@ -1,0 +1,638 @@
+// raymarching.hip -- occupancy-grid ray marching + alpha compositing for gfx950.
+//
+// Replaces raymarching/src/raymarching.cu of the reference (cited per kernel).
+// Written for wave64: ray compaction uses wavefront scans instead of the
+// reference's two global atomicAdd reservations, which also makes the sample
+// layout deterministic (ray-id order).
+//
+// Arithmetic contract (shared with oracle/lae_oracle.c): compiled with
+// -ffp-contract=off; the a*b+c shapes that nvcc contracts in the reference are
+// explicit fmaf() here, everything else is separate IEEE ops, so t-sequences,
+// voxel indices, sample counts and positions are bit-identical to the oracle.
+#include "lae_common.h"
+
+namespace {
+
+using lae::clampf;
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // raymarching.cu:56-63
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton_encode(uint32_t x, uint32_t y, uint32_t z) {
+    return spread10(x) | (spread10(y) << 1) | (spread10(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton_compact(uint32_t x) {  // raymarching.cu:73-81
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// ---------------------------------------------------------------- K1
+// raymarching.cu:91-145
+__global__ void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                           const float* __restrict__ aabb, uint32_t N, float min_near,
+                           float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float BIG = 3.402823466e+38f;
+    float tn = 0.f, tf = 0.f;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (miss) break;
+        const float o = rays_o[3 * (size_t)n + a];
+        const float r = 1.0f / rays_d[3 * (size_t)n + a];
+        float lo = (aabb[a] - o) * r, hi = (aabb[a + 3] - o) * r;
+        if (lo > hi) { float s = lo; lo = hi; hi = s; }
+        if (a == 0) { tn = lo; tf = hi; }
+        else {
+            if (tn > hi || lo > tf) { miss = true; }
+            else { if (lo > tn) tn = lo; if (hi < tf) tf = hi; }
+        }
+    }
+    if (miss) { nears[n] = BIG; fars[n] = BIG; return; }
+    if (tn < min_near) tn = min_near;
+    nears[n] = tn; fars[n] = tf;
+}
+
+// ---------------------------------------------------------------- K2
+// raymarching.cu:162-198
+__global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                               float radius, uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float RPI = 0.3183098861837907f;
+    const float ox = rays_o[3 * (size_t)n], oy = rays_o[3 * (size_t)n + 1], oz = rays_o[3 * (size_t)n + 2];
+    const float dx = rays_d[3 * (size_t)n], dy = rays_d[3 * (size_t)n + 1], dz = rays_d[3 * (size_t)n + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float Bh = ox * dx + oy * dy + oz * dz;
+    const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    coords[2 * (size_t)n] = 2 * atan2f(sqrtf(x * x + z * z), y) * RPI - 1;
+    coords[2 * (size_t)n + 1] = atan2f(z, x) * RPI;
+}
+
+// ---------------------------------------------------------------- K3 / K4 / K5
+__global__ void k_morton3D(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton_encode((uint32_t)coords[3 * (size_t)n], (uint32_t)coords[3 * (size_t)n + 1],
+                                        (uint32_t)coords[3 * (size_t)n + 2]);
+}
+__global__ void k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t ind = indices[n];
+    coords[3 * (size_t)n + 0] = (int32_t)morton_compact((uint32_t)(ind >> 0));
+    coords[3 * (size_t)n + 1] = (int32_t)morton_compact((uint32_t)(ind >> 1));
+    coords[3 * (size_t)n + 2] = (int32_t)morton_compact((uint32_t)(ind >> 2));
+}
+// raymarching.cu:267-289; one thread per output byte, two 16-byte loads
+__global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[2 * (size_t)n];
+    const float4 b = reinterpret_cast<const float4*>(grid)[2 * (size_t)n + 1];
+    uint32_t bits = (a.x > thresh) | ((a.y > thresh) << 1) | ((a.z > thresh) << 2) | ((a.w > thresh) << 3) |
+                    ((b.x > thresh) << 4) | ((b.y > thresh) << 5) | ((b.z > thresh) << 6) | ((b.w > thresh) << 7);
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ---------------------------------------------------------------- the marcher
+// One probe of the cascaded occupancy bitfield at ray parameter t
+// (raymarching.cu:361-399); see oracle/lae_oracle.c marcher_probe for the
+// arithmetic contract.
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+struct MarchCfg {
+    float bound, dt_gamma, dt_min, dt_max, rH, Hf, Cf, Hm1;
+    uint32_t H3;
+};
+struct Probe {
+    float x, y, z, dt, tt;
+    uint32_t index;
+    bool occ;
+};
+
+__device__ __forceinline__ int cascade_of(float v, float Cf) {
+    int e;
+    (void)frexpf(v, &e);
+    return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e));
+}
+
+__device__ __forceinline__ Probe probe_at(const Ray& r, const MarchCfg& c, const uint8_t* __restrict__ grid, float t) {
+    Probe p;
+    p.x = clampf(fmaf(t, r.dx, r.ox), -c.bound, c.bound);
+    p.y = clampf(fmaf(t, r.dy, r.oy), -c.bound, c.bound);
+    p.z = clampf(fmaf(t, r.dz, r.oz), -c.bound, c.bound);
+    p.dt = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const float amax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
+    const int lp = cascade_of(amax, c.Cf);
+    const int ld = cascade_of(p.dt * c.Hf * 0.5f, c.Cf);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+    const int nx = (int)clampf((0.5f * fmaf(p.x, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    const int ny = (int)clampf((0.5f * fmaf(p.y, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    const int nz = (int)clampf((0.5f * fmaf(p.z, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    p.index = (uint32_t)level * c.H3 + morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    p.occ = (grid[p.index >> 3] >> (p.index & 7u)) & 1u;
+    if (!p.occ) {
+        const float ax = (float)nx + 0.5f + 0.5f * copysignf(1.0f, r.dx);
+        const float ay = (float)ny + 0.5f + 0.5f * copysignf(1.0f, r.dy);
+        const float az = (float)nz + 0.5f + 0.5f * copysignf(1.0f, r.dz);
+        const float tx = fmaf((ax * c.rH) * 2 - 1, mip_bound, -p.x) * r.rdx;
+        const float ty = fmaf((ay * c.rH) * 2 - 1, mip_bound, -p.y) * r.rdy;
+        const float tz = fmaf((az * c.rH) * 2 - 1, mip_bound, -p.z) * r.rdz;
+        p.tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    } else {
+        p.tt = t;
+    }
+    return p;
+}
+
+__device__ __forceinline__ float skip_to(const MarchCfg& c, float t, float tt) {   // :396-398
+    do { t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
+    return t;
+}
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t i) {
+    Ray r;
+    r.ox = rays_o[3 * (size_t)i]; r.oy = rays_o[3 * (size_t)i + 1]; r.oz = rays_o[3 * (size_t)i + 2];
+    r.dx = rays_d[3 * (size_t)i]; r.dy = rays_d[3 * (size_t)i + 1]; r.dz = rays_d[3 * (size_t)i + 2];
+    r.rdx = 1.0f / r.dx; r.rdy = 1.0f / r.dy; r.rdz = 1.0f / r.dz;
+    return r;
+}
+
+static MarchCfg make_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H) {
+    MarchCfg c;
+    const float SQRT3 = 1.7320508075688772f;
+    c.bound = bound; c.dt_gamma = dt_gamma;
+    c.dt_min = 2 * SQRT3 / (float)max_steps;
+    c.dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
+    c.rH = 1.0f / (float)H; c.Hf = (float)H; c.Cf = (float)C; c.Hm1 = (float)(H - 1);
+    c.H3 = H * H * H;
+    return c;
+}
+
+// ---------------------------------------------------------------- K6 (training march)
+// raymarching.cu:311-480, split into count -> scan -> emit.
+constexpr int MARCH_BLOCK = 128;   // 2 waves; N = 4096 rays -> 32 blocks spread over CUs
+
+// pass 1: per-ray sample count + block-local exclusive prefix
+__global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_count(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+    MarchCfg cfg, uint32_t max_steps, uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
+    const float* __restrict__ noises, uint32_t* __restrict__ counts, uint32_t* __restrict__ local_prefix,
+    uint32_t* __restrict__ block_totals) {
+    __shared__ uint32_t lds[MARCH_BLOCK / 64 + 1];
+    const uint32_t n = blockIdx.x * MARCH_BLOCK + threadIdx.x;
+    uint32_t num = 0;
+    if (n < N) {
+        const Ray r = load_ray(rays_o, rays_d, n);
+        const float far = fars[n];
+        float t = nears[n];
+        t = fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t);   // :351
+        while (t < far && num < max_steps) {
+            const Probe p = probe_at(r, cfg, grid, t);
+            if (p.occ) { num++; t += p.dt; }
+            else t = skip_to(cfg, t, p.tt);
+        }
+        counts[n] = num;
+    }
+    uint32_t total;
+    const uint32_t ex = lae::block_excl_scan<MARCH_BLOCK / 64>(num, &total, lds);
+    if (n < N) local_prefix[n] = ex;
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+
+// single-block exclusive scan of the block totals (in place) + counter update (:405-406)
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* __restrict__ totals, uint32_t nblk,
+                                                       int32_t* __restrict__ counter, uint32_t N) {
+    __shared__ uint32_t lds[17];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? totals[i] : 0;
+        uint32_t total;
+        const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
+        if (i < nblk) totals[i] = carry + ex;
+        carry += total;
+    }
+    // reservation bases = counter values before this call (what the reference's atomicAdd returns)
+    if (threadIdx.x == 0) {
+        int32_t b0 = 0, b1 = 0;
+        if (counter) {
+            b0 = atomicAdd(counter, (int32_t)carry);
+            b1 = atomicAdd(counter + 1, (int32_t)N);
+        }
+        totals[nblk] = (uint32_t)b0;
+        totals[nblk + 1] = (uint32_t)b1;
+    }
+}
+
+// pass 2: re-march and emit samples at offset = block prefix + local prefix
+__global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_emit(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+    MarchCfg cfg, uint32_t N, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
+    const float* __restrict__ noises, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ local_prefix,
+    const uint32_t* __restrict__ block_prefix, uint32_t nblk,
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays) {
+    const uint32_t n = blockIdx.x * MARCH_BLOCK + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t num_steps = counts[n];
+    const uint32_t point_index = block_prefix[nblk] + block_prefix[blockIdx.x] + local_prefix[n];
+    const uint32_t row = block_prefix[nblk + 1] + n;
+    rays[3 * (size_t)row + 0] = (int32_t)n;
+    rays[3 * (size_t)row + 1] = (int32_t)point_index;
+    rays[3 * (size_t)row + 2] = (int32_t)num_steps;
+    if (num_steps == 0 || point_index + num_steps > M) return;     // :415-416
+
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t = nears[n];
+    t = fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t);
+    float last_t = t;
+    float* px = xyzs + 3 * (size_t)point_index;
+    float* pd = dirs + 3 * (size_t)point_index;
+    float* pl = deltas + 2 * (size_t)point_index;
+    uint32_t step = 0;
+    while (t < far && step < num_steps) {
+        const Probe p = probe_at(r, cfg, grid, t);
+        if (p.occ) {
+            px[0] = p.x; px[1] = p.y; px[2] = p.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += p.dt;
+            pl[0] = p.dt; pl[1] = t - last_t; last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = skip_to(cfg, t, p.tt);
+    }
+}
+
+// ---------------------------------------------------------------- K7 / K8 (training composite)
+// raymarching.cu:500-577
+__global__ void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                      const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                      uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
+                                      float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    float r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0, T = 1.0f;
+    if (!(num_steps == 0 || offset + num_steps > M)) {
+        const float* s = sigmas + offset;
+        const float* c = rgbs + 3 * (size_t)offset;
+        const float* dl = deltas + 2 * (size_t)offset;
+        for (uint32_t k = 0; k < num_steps; k++) {
+            const float alpha = 1.0f - __expf(-s[k] * dl[2 * k]);
+            const float w = alpha * T;
+            r = fmaf(w, c[3 * k], r); g = fmaf(w, c[3 * k + 1], g); b = fmaf(w, c[3 * k + 2], b);
+            t += dl[2 * k + 1];
+            d = fmaf(w, t, d);
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+// raymarching.cu:601-682
+__global__ void k_composite_train_bwd(const float* __restrict__ grad_ws, const float* __restrict__ grad_image,
+                                      const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                      const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                      const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                      uint32_t M, uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
+                                      float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_ws[index];
+    const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
+    const float rf = image[3 * (size_t)index], gf = image[3 * (size_t)index + 1], bf = image[3 * (size_t)index + 2];
+    const float wsf = weights_sum[index];
+    const float* s = sigmas + offset;
+    const float* c = rgbs + 3 * (size_t)offset;
+    const float* dl = deltas + 2 * (size_t)offset;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + 3 * (size_t)offset;
+    float T = 1.0f, r = 0, g = 0, b = 0;
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const float alpha = 1.0f - __expf(-s[k] * dl[2 * k]);
+        const float w = alpha * T;
+        const float c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
+        r = fmaf(w, c0, r); g = fmaf(w, c1, g); b = fmaf(w, c2, b);
+        T *= 1.0f - alpha;
+        gc[3 * k] = g0 * w; gc[3 * k + 1] = g1 * w; gc[3 * k + 2] = g2 * w;
+        gs[k] = dl[2 * k] * (g0 * (T * c0 - (rf - r)) + g1 * (T * c1 - (gf - g)) + g2 * (T * c2 - (bf - b)) +
+                             gws * (1 - wsf));
+        if (T < T_thresh) break;
+    }
+}
+
+// ---------------------------------------------------------------- K9 / K10 (inference march)
+// raymarching.cu:700-805 and :811-926 (EDIT = distill variant)
+template <bool EDIT>
+__global__ void k_march_infer(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                              const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                              const float* __restrict__ rays_d, MarchCfg cfg, const uint8_t* __restrict__ grid,
+                              const uint8_t* __restrict__ edit_grid, const float* __restrict__ fars,
+                              float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                              uint8_t* __restrict__ edit_occ, const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    const Ray r = load_ray(rays_o, rays_d, (uint32_t)index);
+    float* px = xyzs + 3 * (size_t)n * n_step;
+    float* pd = dirs + 3 * (size_t)n * n_step;
+    float* pl = deltas + 2 * (size_t)n * n_step;
+    uint8_t* pe = EDIT ? edit_occ + (size_t)n * n_step : nullptr;
+    float t = rays_t[index];
+    const float far = fars[index];
+    t = fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t);     // :746
+    float last_t = t;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        const Probe p = probe_at(r, cfg, grid, t);
+        if (p.occ) {
+            px[0] = p.x; px[1] = p.y; px[2] = p.z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += p.dt;
+            pl[0] = p.dt; pl[1] = t - last_t; last_t = t;
+            if (EDIT) {
+                if ((edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u) *pe = 1;
+                pe++;
+            }
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = skip_to(cfg, t, p.tt);
+    }
+}
+
+// ---------------------------------------------------------------- K11 / K12 (inference composite)
+// raymarching.cu:948-1035 and :1037-1142
+template <bool EDIT>
+__global__ void k_composite_infer(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* __restrict__ rays_alive,
+                                  float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                  const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                  float* __restrict__ weights_sum, float* __restrict__ weights_edit_sum,
+                                  float* __restrict__ depth, float* __restrict__ depth_edit,
+                                  const uint8_t* __restrict__ edit_occ, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const int32_t index = rays_alive[n];
+    const float* s = sigmas + (size_t)n * n_step;
+    const float* c = rgbs + 3 * (size_t)n * n_step;
+    const float* dl = deltas + 2 * (size_t)n * n_step;
+    const uint8_t* eo = EDIT ? edit_occ + (size_t)n * n_step : nullptr;
+    float t = rays_t[index];
+    float ws = weights_sum[index], d = depth[index];
+    float wse = 0, de = 0;
+    if (EDIT) { wse = weights_edit_sum[index]; de = depth_edit[index]; }
+    float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const float d0 = dl[2 * step];
+        if (d0 == 0) break;
+        const float alpha = 1.0f - __expf(-s[step] * d0);
+        const float T = 1 - ws;
+        const float w = alpha * T;
+        ws += w;
+        if (EDIT) { if (eo[step]) { wse += w; de = fmaf(w, t, de); } }
+        t += dl[2 * step + 1];
+        d = fmaf(w, t, d);
+        r = fmaf(w, c[3 * step], r); g = fmaf(w, c[3 * step + 1], g); b = fmaf(w, c[3 * step + 2], b);
+        if (T < T_thresh) break;
+        step++;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = ws; depth[index] = d;
+    if (EDIT) { weights_edit_sum[index] = wse; depth_edit[index] = de; }
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+// ---------------------------------------------------------------- alive-list compaction
+constexpr int COMPACT_BLOCK = 256;
+__global__ __launch_bounds__(COMPACT_BLOCK) void k_compact_count(const int32_t* __restrict__ rays_alive, uint32_t n,
+                                                                  uint32_t* __restrict__ local_prefix,
+                                                                  uint32_t* __restrict__ block_totals) {
+    __shared__ uint32_t lds[COMPACT_BLOCK / 64 + 1];
+    const uint32_t i = blockIdx.x * COMPACT_BLOCK + threadIdx.x;
+    const uint32_t keep = (i < n && rays_alive[i] >= 0) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t ex = lae::block_excl_scan<COMPACT_BLOCK / 64>(keep, &total, lds);
+    if (i < n) local_prefix[i] = ex;
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_compact_scan(uint32_t* __restrict__ totals, uint32_t nblk,
+                                                        int32_t* __restrict__ n_out) {
+    __shared__ uint32_t lds[17];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? totals[i] : 0;
+        uint32_t total;
+        const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
+        if (i < nblk) totals[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *n_out = (int32_t)carry;
+}
+__global__ __launch_bounds__(COMPACT_BLOCK) void k_compact_scatter(const int32_t* __restrict__ rays_alive, uint32_t n,
+                                                                    const uint32_t* __restrict__ local_prefix,
+                                                                    const uint32_t* __restrict__ block_prefix,
+                                                                    int32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * COMPACT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = rays_alive[i];
+    if (v >= 0) out[block_prefix[blockIdx.x] + local_prefix[i]] = v;
+}
+
+}  // namespace
+
+// =====================================================================
+// C ABI
+// =====================================================================
+#define STREAM(s) (reinterpret_cast<hipStream_t>(s))
+
+extern "C" {
+
+int lae_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                           float* nears, float* fars, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays_o || !rays_d || !aabb || !nears || !fars) return LAE_ENULL;
+    k_near_far<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return lae::check_launch("near_far_from_aabb");
+}
+
+int lae_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays_o || !rays_d || !coords) return LAE_ENULL;
+    k_sph_from_ray<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(rays_o, rays_d, radius, N, coords);
+    return lae::check_launch("sph_from_ray");
+}
+
+int lae_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!coords || !indices) return LAE_ENULL;
+    k_morton3D<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(coords, N, indices);
+    return lae::check_launch("morton3D");
+}
+
+int lae_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!coords || !indices) return LAE_ENULL;
+    k_morton3D_invert<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(indices, N, coords);
+    return lae::check_launch("morton3D_invert");
+}
+
+int lae_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!grid || !bitfield) return LAE_ENULL;
+    k_packbits<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(grid, N, density_thresh, bitfield);
+    return lae::check_launch("packbits");
+}
+
+uint64_t lae_march_rays_train_scratch_bytes(uint32_t N) {
+    const uint64_t nblk = lae::cdiv(N, MARCH_BLOCK);
+    return 4ull * (2ull * N + nblk + 2) + 64;
+}
+
+int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                         const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                         const float* noises, void* scratch, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !noises || !scratch)
+        return LAE_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return LAE_EINVAL;
+    const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
+    const uint32_t nblk = lae::cdiv(N, MARCH_BLOCK);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* local_prefix = counts + N;
+    uint32_t* totals = local_prefix + N;
+    hipStream_t s = STREAM(stream);
+    k_march_train_count<<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, nears, fars, noises,
+                                                     counts, local_prefix, totals);
+    k_scan_totals<<<1, 1024, 0, s>>>(totals, nblk, counter, N);
+    k_march_train_emit<<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, N, M, nears, fars, noises, counts,
+                                                    local_prefix, totals, nblk, xyzs, dirs, deltas, rays);
+    return lae::check_launch("march_rays_train");
+}
+
+int lae_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                     uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
+                                     float* image, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays || !weights_sum || !depth || !image) return LAE_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas)) return LAE_ENULL;
+    k_composite_train_fwd<<<lae::cdiv(N, 64), 64, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh,
+                                                                        weights_sum, depth, image);
+    return lae::check_launch("composite_rays_train_forward");
+}
+
+int lae_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                      float T_thresh, float* grad_sigmas, float* grad_rgbs, void* stream) {
+    if (N == 0 || M == 0) return LAE_OK;
+    if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image ||
+        !grad_sigmas || !grad_rgbs)
+        return LAE_ENULL;
+    k_composite_train_bwd<<<lae::cdiv(N, 64), 64, 0, STREAM(stream)>>>(grad_weights_sum, grad_image, sigmas, rgbs,
+                                                                        deltas, rays, weights_sum, image, M, N,
+                                                                        T_thresh, grad_sigmas, grad_rgbs);
+    return lae::check_launch("composite_rays_train_backward");
+}
+
+int lae_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                   float* dirs, float* deltas, const float* noises, void* stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return LAE_OK;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas || !noises)
+        return LAE_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return LAE_EINVAL;
+    const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
+    k_march_infer<false><<<lae::cdiv(n_alive, 128), 128, 0, STREAM(stream)>>>(
+        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, cfg, grid, nullptr, fars, xyzs, dirs, deltas, nullptr,
+        noises);
+    return lae::check_launch("march_rays");
+}
+
+int lae_march_rays_distill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                           const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                           uint32_t C, uint32_t H, const uint8_t* grid, const uint8_t* edit_grid, const float* nears,
+                           const float* fars, float* xyzs, float* dirs, float* deltas, uint8_t* edit_occ,
+                           const float* noises, void* stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return LAE_OK;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !edit_grid || !fars || !xyzs || !dirs || !deltas ||
+        !edit_occ || !noises)
+        return LAE_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return LAE_EINVAL;
+    const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
+    k_march_infer<true><<<lae::cdiv(n_alive, 128), 128, 0, STREAM(stream)>>>(
+        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, cfg, grid, edit_grid, fars, xyzs, dirs, deltas, edit_occ,
+        noises);
+    return lae::check_launch("march_rays_distill");
+}
+
+int lae_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                       const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                       float* image, void* stream) {
+    if (n_alive == 0) return LAE_OK;
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !depth || !image) return LAE_ENULL;
+    k_composite_infer<false><<<lae::cdiv(n_alive, 128), 128, 0, STREAM(stream)>>>(
+        n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, nullptr, depth, nullptr,
+        nullptr, image);
+    return lae::check_launch("composite_rays");
+}
+
+int lae_composite_rays_distill(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                               const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                               float* weights_edit_sum, float* depth, float* depth_edit, const uint8_t* edit_occ,
+                               float* image, void* stream) {
+    if (n_alive == 0) return LAE_OK;
+    if (!rays_alive || !rays_t || !sigmas || !rgbs || !deltas || !weights_sum || !weights_edit_sum || !depth ||
+        !depth_edit || !edit_occ || !image)
+        return LAE_ENULL;
+    k_composite_infer<true><<<lae::cdiv(n_alive, 128), 128, 0, STREAM(stream)>>>(
+        n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, weights_edit_sum, depth,
+        depth_edit, edit_occ, image);
+    return lae::check_launch("composite_rays_distill");
+}
+
+uint64_t lae_compact_scratch_bytes(uint32_t n_alive) {
+    return 4ull * ((uint64_t)n_alive + lae::cdiv(n_alive, COMPACT_BLOCK)) + 64;
+}
+
+int lae_compact_rays_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_alive, int32_t* n_out_dev,
+                           void* scratch, void* stream) {
+    if (!n_out_dev) return LAE_ENULL;
+    hipStream_t s = STREAM(stream);
+    if (n_alive == 0) return hipMemsetAsync(n_out_dev, 0, 4, s) == hipSuccess ? LAE_OK : LAE_ELAUNCH;
+    if (!rays_alive || !out_alive || !scratch) return LAE_ENULL;
+    const uint32_t nblk = lae::cdiv(n_alive, COMPACT_BLOCK);
+    uint32_t* local_prefix = reinterpret_cast<uint32_t*>(scratch);
+    uint32_t* totals = local_prefix + n_alive;
+    k_compact_count<<<nblk, COMPACT_BLOCK, 0, s>>>(rays_alive, n_alive, local_prefix, totals);
+    k_compact_scan<<<1, 1024, 0, s>>>(totals, nblk, n_out_dev);
+    k_compact_scatter<<<nblk, COMPACT_BLOCK, 0, s>>>(rays_alive, n_alive, local_prefix, totals, out_alive);
+    return lae::check_launch("compact_rays_alive");
+}
+
+}  // extern "C"

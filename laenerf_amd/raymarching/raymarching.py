@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's `raymarching/raymarching.py` on the HIP backend.
+
+Same public names, argument order, defaults, output shapes and in-place behaviour as the
+reference (cited per function), so `nerf/renderer.py` / `editing/*` written against the
+reference call these unchanged.  Every output/workspace is allocated here and handed to the
+backend, exactly like the reference's autograd.Functions do.  GPU tensors only: there is no
+CPU fallback (the reference's wrappers likewise `.cuda()` everything, raymarching.py:34-35).
+"""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from ..backend import raymarching_backend as _backend
+
+__all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
+           "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
+           "compact_rays_alive"]
+
+
+def _gpu(t):
+    return t if t.is_cuda else t.cuda()
+
+
+def _rays(t):
+    return _gpu(t).contiguous().view(-1, 3)
+
+
+class _near_far_from_aabb(Function):
+    """raymarching.py:19-49"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        N = rays_o.shape[0]
+        nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        _backend.near_far_from_aabb(rays_o, rays_d, _gpu(aabb).contiguous(), N, min_near, nears, fars)
+        return nears, fars
+
+
+near_far_from_aabb = _near_far_from_aabb.apply
+
+
+class _sph_from_ray(Function):
+    """raymarching.py:52-80"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, radius):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        N = rays_o.shape[0]
+        coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+        _backend.sph_from_ray(rays_o, rays_d, radius, N, coords)
+        return coords
+
+
+sph_from_ray = _sph_from_ray.apply
+
+
+class _morton3D(Function):
+    """raymarching.py:83-104: coords [N,3] int in [0,128) -> indices [N] int32"""
+
+    @staticmethod
+    def forward(ctx, coords):
+        coords = _gpu(coords)
+        N = coords.shape[0]
+        indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+        _backend.morton3D(coords.int().contiguous(), N, indices)
+        return indices
+
+
+morton3D = _morton3D.apply
+
+
+class _morton3D_invert(Function):
+    """raymarching.py:106-126"""
+
+    @staticmethod
+    def forward(ctx, indices):
+        indices = _gpu(indices)
+        N = indices.shape[0]
+        coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+        _backend.morton3D_invert(indices.int().contiguous(), N, coords)
+        return coords
+
+
+morton3D_invert = _morton3D_invert.apply
+
+
+class _packbits(Function):
+    """raymarching.py:129-155: grid [C, H^3] float -> bitfield [C*H^3/8] uint8"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, grid, thresh, bitfield=None):
+        grid = _gpu(grid).contiguous()
+        N = grid.shape[0] * grid.shape[1] // 8
+        if bitfield is None:
+            bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+        _backend.packbits(grid, N, thresh, bitfield)
+        return bitfield
+
+
+packbits = _packbits.apply
+
+
+def _round_up_always(m, align):
+    """the reference's `m += align - m % align` (adds a full `align` when already aligned)"""
+    return m + (align - m % align) if align > 0 else m
+
+
+class _march_rays_train(Function):
+    """raymarching.py:161-235.  Differences, all invisible to callers: rows of `rays` come out in ray-id
+    order with offsets = exclusive scan of counts (the reference's order depends on atomic arrival)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        density_bitfield = _gpu(density_bitfield).contiguous()
+        dev, dt = rays_o.device, rays_o.dtype
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            M = _round_up_always(mean_count, align)
+        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
+        _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
+                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)
+        if force_all_rays or mean_count <= 0:
+            m = _round_up_always(int(step_counter[0].item()), align)      # D2H sync, first 16 steps only
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+
+march_rays_train = _march_rays_train.apply
+
+
+class _composite_rays_train(Function):
+    """raymarching.py:238-291"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+        _backend.composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image)
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        ctx.dims = [M, N, T_thresh]
+        return weights_sum, depth, image
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        # grad_depth is not propagated (raymarching.py:275)
+        sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        grad_sigmas = torch.zeros_like(sigmas)
+        grad_rgbs = torch.zeros_like(rgbs)
+        _backend.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
+                                               deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs)
+        return grad_sigmas, grad_rgbs, None, None, None
+
+
+composite_rays_train = _composite_rays_train.apply
+
+
+def _infer_buffers(n_alive, n_step, align, dt, dev):
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    return (M, torch.zeros(M, 3, dtype=dt, device=dev), torch.zeros(M, 3, dtype=dt, device=dev),
+            torch.zeros(M, 2, dtype=dt, device=dev))
+
+
+class _march_rays(Function):
+    """raymarching.py:297-348"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+                align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        dev, dt = rays_o.device, rays_o.dtype
+        M, xyzs, dirs, deltas = _infer_buffers(n_alive, n_step, align, dt, dev)
+        noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
+        _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                            density_bitfield, near, far, xyzs, dirs, deltas, noises)
+        return xyzs, dirs, deltas
+
+
+march_rays = _march_rays.apply
+
+
+class _march_rays_distill(Function):
+    """raymarching.py:355-411"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, edit_bitfield, C, H,
+                near, far, align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+        dev, dt = rays_o.device, rays_o.dtype
+        M, xyzs, dirs, deltas = _infer_buffers(n_alive, n_step, align, dt, dev)
+        edit_occ = torch.zeros(M, dtype=torch.bool, device=dev)
+        noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
+        _backend.march_rays_distill(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
+                                    H, density_bitfield, edit_bitfield, near, far, xyzs, dirs, deltas, edit_occ, noises)
+        return xyzs, dirs, deltas, edit_occ
+
+
+march_rays_distill = _march_rays_distill.apply
+
+
+class _composite_rays(Function):
+    """raymarching.py:413-435 (in place on rays_alive, rays_t, weights_sum, depth, image)"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(),
+                                deltas, weights_sum, depth, image)
+        return tuple()
+
+
+composite_rays = _composite_rays.apply
+
+
+class _composite_rays_distill(Function):
+    """raymarching.py:437-461"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, weights_edit_sum, depth,
+                depth_edit, image, int_edit, T_thresh=1e-2):
+        _backend.composite_rays_distill(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(),
+                                        rgbs.contiguous(), deltas, weights_sum, weights_edit_sum, depth, depth_edit,
+                                        int_edit, image)
+        return tuple()
+
+
+composite_rays_distill = _composite_rays_distill.apply
+
+
+def compact_rays_alive(rays_alive, n_alive=None):
+    """MI355X-native replacement for `rays_alive = rays_alive[rays_alive >= 0]` (renderer.py:375): stable
+    device-side compaction.  Returns (out_alive [n_alive] int32, n_out device int32[1]); the caller may keep
+    n_out on the device (no sync) or read it."""
+    n_alive = rays_alive.shape[0] if n_alive is None else n_alive
+    out = torch.empty(max(n_alive, 1), dtype=torch.int32, device=rays_alive.device)
+    n_out = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
+    _backend.compact_rays_alive(rays_alive, n_alive, out, n_out)
+    return out, n_out
