@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- lego 800x800 train-step throughput of the MI355X hot path (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch of 4096 synthetic rays:
+  near_far_from_aabb -> march_rays_train -> hash-grid encode (L=16, T=2^19, fp16 table under autocast) ->
+  sigma FFMLP (2x64) -> trunc_exp -> SH(4) -> colour FFMLP (3x64) -> sigmoid -> composite_rays_train ->
+  MSE -> backward of all of it (composite, MLPs, grid scatter) -> Adam step + GradScaler
+i.e. the reference's Trainer.train_step/backward/optimizer.step sequence (nerf/utils.py:1474-1482) in steady
+state (mean_count > 0, no host sync inside the step).  Synthetic rays / occupancy / weights:
+no dataset or checkpoint exists offline.  value = all ranks' rays / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GRID_FWD_BYTES_FP16 = 588        # SURVEY.md 8d / BASELINE.md 4: 12 + 16*8*2*2 + 16*2*2 bytes per sample
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=40)
+    p.add_argument("--rays", type=int, default=4096)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
+    p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
+    return p.parse_args()
+
+
+def cpu_baseline(n_rays_hint, n_threads):
+    """The oracle (C restatement of the reference kernels, oracle/lae_oracle.c) timed on the host cores on a
+    bounded sample of the SAME workload: forward + backward of one train step, without the optimizer."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    from laenerf_amd import synthetic as S
+    O.build()
+    bits = S.pack_bits_np(S.sphere_density_grid(), 10.0)
+    offsets, pls = O.grid_offsets(num_levels=16, desired_resolution=2048)
+    rng = np.random.default_rng(0)
+    table_h = O.to_f16_bits(rng.uniform(-1e-4, 1e-4, (int(offsets[-1]), 2)).astype(np.float32))
+    ws = O.to_f16_bits(rng.uniform(-0.2165, 0.2165, O.ffmlp_num_params(32, 64, 2)).astype(np.float32))
+    wc = O.to_f16_bits(rng.uniform(-0.2165, 0.2165, O.ffmlp_num_params(32, 64, 3)).astype(np.float32))
+
+    def one_chunk(o, d, noises):
+        n = o.shape[0]
+        nears, fars = O.near_far_from_aabb(o, d, [-1, -1, -1, 1, 1, 1], 0.2)
+        xyzs, dirs, deltas, rays, counter = O.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, noises, M=n * 1024)
+        m = int(counter[0]); m += 128 - m % 128
+        xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        enc, _ = O.grid_encode_forward((xyzs + 1) / 2, table_h, offsets, pls, 16, f16=True, out_blc=True)
+        h, fb1 = O.ffmlp_forward(enc, ws, 32, 16, 64, 2)
+        hf = O.from_f16_bits(h)
+        sigma = np.exp(hf[:, 0])
+        sh, _ = O.sh_encode_forward(dirs, 4)
+        cin = O.to_f16_bits(np.concatenate([sh, hf[:, 1:], np.zeros((m, 1), np.float32)], 1))
+        oc, fb2 = O.ffmlp_forward(cin, wc, 32, 16, 64, 3)
+        rgb = 1 / (1 + np.exp(-O.from_f16_bits(oc)[:, :3]))
+        wsum, depth, image = O.composite_rays_train_forward(sigma, rgb, deltas, rays, 1e-4)
+        gimg = (2 * (image + (1 - wsum)[:, None] - 0.5) / image.size).astype(np.float32)
+        gws = -gimg.sum(1)
+        gs, gc = O.composite_rays_train_backward(gws, gimg, sigma, rgb, deltas, rays, wsum, image, 1e-4)
+        goc = np.zeros((m, 16), np.float32); goc[:, :3] = gc * rgb * (1 - rgb)
+        _, gcin, _ = O.ffmlp_backward(O.to_f16_bits(goc), cin, wc, fb2, 32, 16, 64, 3, calc_grad_inputs=True)
+        gh = np.zeros((m, 16), np.float32); gh[:, 0] = gs * sigma; gh[:, 1:] = O.from_f16_bits(gcin)[:, 16:31]
+        _, genc, _ = O.ffmlp_backward(O.to_f16_bits(gh), enc, ws, fb1, 32, 16, 64, 2, calc_grad_inputs=True)
+        O.grid_encode_backward(genc, (xyzs + 1) / 2, (int(offsets[-1]), 2), offsets, pls, 16, f16=True, grad_blc=True)
+        return int(counter[0])
+
+    o, d = S.lego_like_rays(4096, seed=0)
+    noises = np.random.default_rng(1).random(4096).astype(np.float32)
+    # calibrate on 64 rays, then size the sample for ~15 s of work on n_threads threads
+    t0 = time.perf_counter(); one_chunk(o[:64], d[:64], noises[:64]); t_cal = time.perf_counter() - t0
+    if n_rays_hint <= 0:
+        n_rays = int(min(4096, max(256, 15.0 / (t_cal / 64) * n_threads)))
+        n_rays -= n_rays % n_threads
+    else:
+        n_rays = n_rays_hint
+    chunks = np.array_split(np.arange(n_rays), n_threads)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n_threads) as ex:
+        tot = sum(ex.map(lambda c: one_chunk(o[c], d[c], noises[c]), chunks))
+    dt = time.perf_counter() - t0
+    return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n_rays} of 4096 rays of the same step ({tot} samples), forward+backward without optimizer, "
+                      f"oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from laenerf_amd import backend, build, synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+
+    torch.manual_seed(1234 + rank)
+    net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
+    r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)      # main_nerf.py:223
+    scaler = torch.amp.GradScaler("cuda")
+    n_batches = 16
+    batches = []
+    for b in range(n_batches):
+        o, d = S.lego_like_rays(args.rays, seed=1000 * rank + b)
+        batches.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev),
+                        torch.rand(args.rays, 3, device=dev)))
+    net.train()
+
+    def step(i):
+        o, d, gt = batches[i % n_batches]
+        with torch.autocast("cuda", dtype=torch.float16):
+            res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
+            loss = torch.nn.functional.mse_loss(res["image"], gt)
+        opt.zero_grad(set_to_none=True)
+        if args.no_optimizer:
+            scaler.scale(loss).backward()
+        else:
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        return res["n_samples"]
+
+    # warm-up: the first 16 steps run in the reference's "mean_count <= 0" mode (sized by a D2H read), then the
+    # running mean is refreshed every 16 steps exactly like update_extra_state does (renderer.py:644-647)
+    n_warm = max(args.warmup, 17)
+    for i in range(n_warm):
+        step(i)
+        if (i + 1) % 16 == 0:
+            r.update_mean_count()
+    r.update_mean_count() if r.local_step > 0 else None
+    samples = []
+    backend.enable_kernel_timing(True)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        samples.append(step(n_warm + i))
+    sync_all()
+    dt = time.perf_counter() - t0
+    timing_grid = backend.collect_kernel_timing()
+    # diagnostic (outside the timed region): per-operator device time of 20 more steps
+    backend.enable_kernel_timing(True, only=None)
+    n_diag = 20
+    for i in range(n_diag):
+        step(n_warm + args.steps + i)
+    timing_all = backend.collect_kernel_timing()
+    backend.enable_kernel_timing(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        gf = timing_grid.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
+        per_launch_bytes = gf["units"] / max(gf["calls"], 1) * GRID_FWD_BYTES_FP16
+        achieved = per_launch_bytes / (gf["ms"] / max(gf["calls"], 1) * 1e-3) / 1e9 if gf["calls"] else float("nan")
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "grid_fwd_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s, lego 800x800 train-step (4096 rays/step)",
+            "value": round(world * args.rays * args.steps / dt / 1e6, 4),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": n_warm,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
+            "config": {"workload": "configs[1]: lego-like 800x800 pinhole rays, 4096 rays/batch, L=16 T=2^19 F=2 hash grid "
+                                   "+ 2x64 / 3x64 ffmlp, cascade 1, analytic occupancy (13% occupied), "
+                                   "steady-state train step incl. backward + Adam",
+                       "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
+                       "optimizer_in_timed_region": not args.no_optimizer,
+                       "parallelism": f"{world} independent ray-batch replicas (no data-path collective)"},
+            "roofline": {"kernel": "k_grid_fwd (hash-grid encode forward, fp16 table)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_sample": GRID_FWD_BYTES_FP16,
+                         "samples_per_launch": int(gf["units"] / max(gf["calls"], 1)),
+                         "avg_launch_us": round(gf["ms"] / max(gf["calls"], 1) * 1e3, 2)},
+            "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

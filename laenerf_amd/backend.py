@@ -263,6 +263,52 @@ class _FFMLP:
         check(_lib.load().lae_free_splitk(), "free_splitk")
 
 
+# --------------------------------------------------------------------------- optional per-kernel timing
+# HIP-event pairs recorded on torch's current stream (= the stream the kernels are launched on) around selected
+# backend calls; used by bench.py for the roofline figure.  Off by default: zero overhead in the product path.
+_timing = {"on": False, "only": None, "events": []}
+_UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "ffmlp_forward": 2, "ffmlp_inference": 2,
+          "ffmlp_backward": 4, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
+          "composite_rays_train_backward": 9}
+
+
+def enable_kernel_timing(on, only=("grid_encode_forward",)):
+    """only = tuple of backend function names to time, or None for all of them"""
+    _timing["on"], _timing["only"], _timing["events"] = bool(on), (set(only) if only else None), []
+
+
+def collect_kernel_timing():
+    """-> {name: {ms (sum of event-pair durations), calls, units (sum of B / N / M of the calls)}}; synchronises"""
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1, units in _timing["events"]:
+        d = out.setdefault(name, {"ms": 0.0, "calls": 0, "units": 0})
+        d["ms"] += e0.elapsed_time(e1); d["calls"] += 1; d["units"] += units
+    _timing["events"] = []
+    return out
+
+
+def _wrap_timed(name, fn):
+    ui = _UNITS.get(name)
+
+    def timed(*a, **k):
+        if not _timing["on"] or (_timing["only"] is not None and name not in _timing["only"]):
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        _timing["events"].append((name, e0, e1, int(a[ui]) if ui is not None else 0))
+        return r
+    timed.__name__ = name
+    return timed
+
+
+for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):
+    for _k, _v in list(vars(_cls).items()):
+        if isinstance(_v, staticmethod) and not _k.startswith("_"):
+            setattr(_cls, _k, staticmethod(_wrap_timed(_k, _v.__func__)))
+
 raymarching_backend = _RayMarching
 gridencoder_backend = _GridEncoder
 shencoder_backend = _SHEncoder

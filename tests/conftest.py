@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def O():
+    """the CPU oracle (test infrastructure)"""
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    from laenerf_amd import build, _lib
+    build.build()
+    return _lib.load()

@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the reference's Python (unmodified) in THIS container.
+
+Run from the repo root:   python tests/golden/make_golden.py
+Needs /root/reference (never available on the GPU box; only the emitted vectors travel).
+
+What is executed from the reference: gridencoder/grid.py (GridEncoder sizing), ffmlp/ffmlp.py (FFMLP
+parameter layout/init, padding), nerf/network.py (the nn.Linear chain + trunc_exp + sigmoid that ffmlp
+replaces), nerf/network_ff.py and nerf/renderer.py (run / run_cuda / run_cuda_distill orchestration),
+raymarching/raymarching.py, shencoder/sphere_harmonics.py, activation.py, encoding.py.
+What is NOT from the reference: the four native extensions.  The reference's CUDA kernels cannot be
+built here, so `_raymarching/_gridencoder/_shencoder/_ffmlp` are the repo's CPU oracle
+(tests/golden/oracle_backends.py).  The vectors therefore pin (a) everything the reference computes in
+Python and (b) the behaviour of this repo's operators UNDER the reference's own callers.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("LAE_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+sys.path.insert(0, HERE)
+import oracle_backends  # noqa: E402
+
+oracle_backends.install()
+
+# ---- stubs for modules the reference imports but the hot path never uses
+sys.modules["trimesh"] = types.ModuleType("trimesh")
+sys.modules["turtle"] = types.ModuleType("turtle")
+sys.modules["turtle"].backward = sys.modules["turtle"].forward = None
+sys.path.insert(0, REF)
+nerf_pkg = types.ModuleType("nerf")
+nerf_pkg.__path__ = [os.path.join(REF, "nerf")]
+sys.modules["nerf"] = nerf_pkg
+nerf_utils = types.ModuleType("nerf.utils")
+nerf_utils.custom_meshgrid = lambda *a: torch.meshgrid(*a, indexing="ij")     # nerf/utils.py:43-48
+sys.modules["nerf.utils"] = nerf_utils
+torch.Tensor.cuda = lambda self, *a, **k: self          # wrappers call .cuda() unconditionally
+
+# the fused-MLP oracle speaks fp16; without a GPU autocast cannot cast for us, so adapt fp32 tensors that
+# carry fp16-representable values (the reference would hand over half tensors under `-O`)
+_ff = sys.modules["_ffmlp"]
+_fwd, _inf, _bwd = _ff.ffmlp_forward, _ff.ffmlp_inference, _ff.ffmlp_backward
+
+
+def _h(t):
+    return t.to(torch.float16).contiguous()
+
+
+def _ff_forward(inputs, weights, B, i, o, h, n, a, oa, forward_buffer, outputs):
+    fb, out = torch.empty(forward_buffer.shape, dtype=torch.float16), torch.empty(outputs.shape, dtype=torch.float16)
+    _fwd(_h(inputs), _h(weights), B, i, o, h, n, a, oa, fb, out)
+    forward_buffer.copy_(fb); outputs.copy_(out)
+
+
+def _ff_inference(inputs, weights, B, i, o, h, n, a, oa, inference_buffer, outputs):
+    out = torch.empty(outputs.shape, dtype=torch.float16)
+    _inf(_h(inputs), _h(weights), B, i, o, h, n, a, oa, None, out)
+    outputs.copy_(out)
+
+
+def _ff_backward(grad, inputs, weights, forward_buffer, B, i, o, h, n, a, oa, calc_gi, backward_buffer, grad_inputs, grad_weights):
+    bb = torch.empty(backward_buffer.shape, dtype=torch.float16)
+    gw = torch.empty(grad_weights.shape, dtype=torch.float16)
+    gi = torch.empty(inputs.shape, dtype=torch.float16) if calc_gi else None
+    _bwd(_h(grad), _h(inputs), _h(weights), _h(forward_buffer), B, i, o, h, n, a, oa, calc_gi, bb, gi, gw)
+    backward_buffer.copy_(bb); grad_weights.copy_(gw)
+    if calc_gi:
+        grad_inputs.copy_(gi)
+
+
+_ff.ffmlp_forward, _ff.ffmlp_inference, _ff.ffmlp_backward = _ff_forward, _ff_inference, _ff_backward
+
+from gridencoder import GridEncoder  # noqa: E402  (reference)
+from ffmlp import FFMLP  # noqa: E402  (reference)
+import raymarching  # noqa: E402  (reference wrappers)
+from nerf.network import NeRFNetwork as LinearNet  # noqa: E402
+from nerf.network_ff import NeRFNetwork as FFNet  # noqa: E402
+from nerf.renderer import NeRFRenderer  # noqa: E402
+
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from laenerf_amd import synthetic as S  # noqa: E402  (numpy-only generators)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def f16r(t):
+    """round to fp16-representable fp32"""
+    return t.to(torch.float16).to(torch.float32)
+
+
+# ---------------------------------------------------------------- A. GridEncoder level sizing (grid.py:98-134)
+def gen_grid_offsets():
+    cfgs = [dict(), dict(desired_resolution=2048), dict(desired_resolution=4096), dict(num_levels=4, desired_resolution=2048),
+            dict(input_dim=2, num_levels=4, log2_hashmap_size=19, desired_resolution=2048),
+            dict(desired_resolution=2048, align_corners=True), dict(desired_resolution=1024, gridtype="tiled", log2_hashmap_size=15),
+            dict(num_levels=8, level_dim=4, base_resolution=8, per_level_scale=1.5, log2_hashmap_size=14)]
+    out = {}
+    for i, kw in enumerate(cfgs):
+        e = GridEncoder(**kw)
+        out[f"cfg{i}_offsets"] = e.offsets.numpy()
+        out[f"cfg{i}_pls"] = np.float64(e.per_level_scale)
+        out[f"cfg{i}_kw"] = np.array(repr(sorted(kw.items())))
+    save("grid_offsets", **out)
+
+
+# ---------------------------------------------------------------- B. FFMLP layout / init (ffmlp.py:99-165)
+def gen_ffmlp_init():
+    out = {}
+    for name, args in (("sigma", (32, 16, 64, 2)), ("color", (32, 3, 64, 3)), ("wide", (48, 3, 128, 2))):
+        m = FFMLP(*args)
+        w = m.weights.detach().numpy()
+        out[name + "_n"] = np.int64(m.num_parameters)
+        out[name + "_head"] = w[:256].copy()
+        out[name + "_sum"] = np.float64(w.astype(np.float64).sum())
+        out[name + "_padded_out"] = np.int64(m.padded_output_dim)
+    # padding rule of FFMLP.forward (ffmlp.py:157-165), observed through the output shape of the unpad
+    m = FFMLP(32, 3, 64, 2).eval()
+    seen = []
+
+    def spy(inputs, weights, B, *a):
+        seen.append(B)
+        a[-1].zero_()
+    _ff.ffmlp_inference, keep = spy, _ff.ffmlp_inference
+    import ffmlp.ffmlp as ffmod
+    for B in (1, 127, 128, 129, 256):
+        y = m(torch.zeros(B, 32))
+        assert y.shape == (B, 3)
+    _ff.ffmlp_inference = keep
+    out["pad_B_in"] = np.array([1, 127, 128, 129, 256])
+    out["pad_B_backend"] = np.array(seen)
+    save("ffmlp_init", **out)
+
+
+def small_encoder(num_levels=16, log2_hashmap_size=10, desired_resolution=2048, seed=1, scale=0.5):
+    e = GridEncoder(num_levels=num_levels, log2_hashmap_size=log2_hashmap_size, desired_resolution=desired_resolution)
+    g = torch.Generator().manual_seed(seed)
+    e.embeddings.data = f16r((torch.rand(e.embeddings.shape, generator=g) * 2 - 1) * scale)
+    return e
+
+
+# ---------------------------------------------------------------- C. nn.Linear chain (network.py:95-124) = oracle for ffmlp
+def gen_mlp_chain():
+    torch.manual_seed(7)
+    net = LinearNet(num_layers=3, hidden_dim=64, geo_feat_dim=15, num_layers_color=4, hidden_dim_color=64, bound=1,
+                    cuda_ray=False)
+    net.encoder = small_encoder()
+    for p in list(net.sigma_net.parameters()) + list(net.color_net.parameters()):
+        p.data = f16r(p.data)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(512, 3, generator=g) * 2 - 1) * 0.9
+    d = torch.randn(512, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        sigma, color = net(x, d)
+        enc = net.encoder(x, bound=1)
+        h = enc
+        hs = []
+        for l in range(3):
+            h = net.sigma_net[l](h)
+            if l != 2:
+                h = torch.relu(h)
+            hs.append(h.clone())
+    save("mlp_chain", x=x.numpy(), d=d.numpy(), table=net.encoder.embeddings.detach().numpy(),
+         offsets=net.encoder.offsets.numpy(), pls=np.float64(net.encoder.per_level_scale), enc=enc.numpy(),
+         sigma_w=[p.detach().numpy() for p in net.sigma_net.parameters()][0], sigma_w1=net.sigma_net[1].weight.detach().numpy(),
+         sigma_w2=net.sigma_net[2].weight.detach().numpy(),
+         color_w0=net.color_net[0].weight.detach().numpy(), color_w1=net.color_net[1].weight.detach().numpy(),
+         color_w2=net.color_net[2].weight.detach().numpy(), color_w3=net.color_net[3].weight.detach().numpy(),
+         sigma_h=hs[2].numpy(), sigma=sigma.numpy(), color=color.numpy())
+
+
+# ---------------------------------------------------------------- D. NeRFRenderer.run cumprod compositing (renderer.py:128-256)
+class AnalyticField(NeRFRenderer):
+    """analytic density/colour so the compositing of `run` can be checked on known samples"""
+
+    def density(self, x):
+        r2 = (x * x).sum(-1)
+        return {"sigma": 40.0 * torch.exp(-6.0 * r2)}
+
+    def color(self, x, d, mask=None, **kw):
+        rgb = torch.sigmoid(torch.stack([3 * x[:, 0] + d[:, 1], 2 * x[:, 1] - d[:, 2], x[:, 2] * 4 + d[:, 0]], -1))
+        if mask is not None:
+            rgb = rgb * mask[:, None]
+        return rgb
+
+
+def gen_run_path():
+    o, d = S.lego_like_rays(192, seed=5)
+    r = AnalyticField(bound=1, cuda_ray=False, min_near=0.2).eval()
+    with torch.no_grad():
+        res = r.run(torch.from_numpy(o)[None], torch.from_numpy(d)[None], num_steps=96, upsample_steps=0, bg_color=1, perturb=False)
+    save("run_path", rays_o=o, rays_d=d, image=res["image"][0].numpy(), depth=res["depth"][0].numpy(),
+         weights_sum=res["weights_sum"].numpy(), num_steps=np.int64(96))
+
+
+# ---------------------------------------------------------------- E. run_cuda / run_cuda_distill orchestration
+def make_ff_net(bound, seed):
+    torch.manual_seed(seed)
+    net = FFNet(bound=bound, cuda_ray=True, min_near=0.2, density_thresh=10)
+    net.encoder = small_encoder(desired_resolution=2048 * bound, seed=seed)
+    net.sigma_net.weights.data = f16r(net.sigma_net.weights.data)
+    net.color_net.weights.data = f16r(net.color_net.weights.data)
+    return net
+
+
+def gen_e2e(tag, bound):
+    C = 1 + int(np.ceil(np.log2(bound)))
+    net = make_ff_net(bound, seed=11)
+    grid = S.sphere_density_grid(cascade=C, bound=float(bound), radius=0.55)
+    bitfield = torch.from_numpy(S.pack_bits_np(grid, 10.0))
+    net.density_bitfield = bitfield.clone()
+    o, d = S.lego_like_rays(256, seed=9, radius=3.2 if bound == 1 else 2.5)
+    ro, rd = torch.from_numpy(o)[None], torch.from_numpy(d)[None]
+    gen = torch.Generator().manual_seed(21)
+    target = torch.rand(256, 3, generator=gen)
+    out = dict(rays_o=o, rays_d=d, bitfield=bitfield.numpy(), table=net.encoder.embeddings.detach().numpy(),
+               offsets=net.encoder.offsets.numpy(), pls=np.float64(net.encoder.per_level_scale),
+               sigma_w=net.sigma_net.weights.detach().numpy(), color_w=net.color_net.weights.detach().numpy(),
+               target=target.numpy(), bound=np.float64(bound))
+    # --- training render, first-steps mode (mean_count = 0 -> M = N*max_steps, trimmed)
+    net.train()
+    res = net.render(ro, rd, staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=256)
+    loss = ((res["image"][0] - target) ** 2).mean()
+    loss.backward()
+    out.update(train_image=res["image"][0].detach().numpy(), train_depth=res["depth"][0].detach().numpy(),
+               train_ws=res["weights_sum"].detach().numpy(), train_counter=net.step_counter[0].numpy().copy(),
+               train_loss=np.float64(loss.item()),
+               g_sigma_w=net.sigma_net.weights.grad.numpy().copy(), g_color_w=net.color_net.weights.grad.numpy().copy(),
+               g_table_norm=np.float64(net.encoder.embeddings.grad.norm().item()),
+               g_table_sample=net.encoder.embeddings.grad.numpy()[::997].copy())
+    # --- steady-state mode: mean_count > 0 (M = mean_count rounded up, may drop rays that overflow)
+    net.zero_grad()
+    net.mean_count = int(net.step_counter[0, 0].item() * 0.6)        # deliberately too small: exercises the overflow drop
+    res2 = net.render(ro, rd, staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=256)
+    out.update(train2_mean_count=np.int64(net.mean_count), train2_image=res2["image"][0].detach().numpy(),
+               train2_ws=res2["weights_sum"].detach().numpy())
+    # --- eval render (renderer.py:335-387)
+    net.eval()
+    with torch.no_grad():
+        ev = net.render(ro, rd, staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=256, scale_depth=True)
+    out.update(eval_image=ev["image"][0].numpy(), eval_depth=ev["depth"][0].numpy())
+    # --- distill render (renderer.py:394-480) with an edit bitfield = one octant of the density bitfield
+    edit_grid = grid.copy()
+    cx, cy, cz = S._morton_inverse_table(128)
+    edit_grid[:, ~((cx >= 64) & (cy >= 48))] = 0
+    edit_bits = torch.from_numpy(S.pack_bits_np(edit_grid, 10.0))
+    with torch.no_grad():
+        ds = net.run_cuda_distill(ro, rd, edit_bits, dt_gamma=0, perturb=False, max_steps=256)
+    out.update(edit_bitfield=edit_bits.numpy(), dist_image=ds["image"][0].numpy(), dist_depth=ds["depth"][0].numpy(),
+               dist_depth_edit=ds["depth_edit"].numpy(), dist_weights_edit=ds["weights_edit"].numpy(),
+               dist_weights=ds["weights"].numpy(), dist_x_term=ds["x_term"].numpy())
+    save("e2e_" + tag, **out)
+
+
+# ---------------------------------------------------------------- F. operator-level vectors under the reference's wrappers
+def gen_ops():
+    """small vectors produced THROUGH the reference's Python wrappers (shape/padding/alignment rules of
+    raymarching.py:161-235, 297-348 are reference code; the arithmetic is the oracle's)."""
+    o, d = S.lego_like_rays(128, seed=13)
+    ro, rd = torch.from_numpy(o), torch.from_numpy(d)
+    grid = S.sphere_density_grid()
+    bits = torch.from_numpy(S.pack_bits_np(grid, 10.0))
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0])
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32)
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, counter, -1, False, 128,
+                                                            False, 0, 128)
+    out = dict(rays_o=o, rays_d=d, bitfield=bits.numpy(), nears=nears.numpy(), fars=fars.numpy(), counter=counter.numpy(),
+               xyzs=xyzs.numpy(), deltas=deltas.numpy(), rays=rays.numpy(), M_trimmed=np.int64(xyzs.shape[0]))
+    # mean_count path: M = mean_count rounded up by `+= align - m % align`
+    for mc in (1000, 1024, 5000):
+        c2 = torch.zeros(2, dtype=torch.int32)
+        x2, _, _, r2 = raymarching.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, c2, mc, False, 128, False, 0, 128)
+        out[f"mc{mc}_M"] = np.int64(x2.shape[0])
+        out[f"mc{mc}_rays"] = r2.numpy()
+    # inference march output sizing (align 128)
+    alive = torch.arange(100, dtype=torch.int32)
+    t = nears.clone()
+    x3, _, dl3 = raymarching.march_rays(100, 3, alive, t, ro, rd, 1.0, bits, 1, 128, nears, fars, 128, False, 0, 128)
+    out["infer_M"] = np.int64(x3.shape[0])
+    out["infer_xyzs"] = x3.numpy()
+    out["infer_deltas"] = dl3.numpy()
+    save("ops_wrappers", **out)
+
+
+if __name__ == "__main__":
+    gen_grid_offsets()
+    gen_ffmlp_init()
+    gen_mlp_chain()
+    gen_run_path()
+    gen_ops()
+    gen_e2e("b1", 1)
+    gen_e2e("b2", 2)

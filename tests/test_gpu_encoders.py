@@ -1,0 +1,141 @@
+"""-m gpu: gridencoder / shencoder HIP kernels vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, N, T, bits_from_half, half_from_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def grid_case(O, D=3, C=2, L=16, T_log2=19, desired=2048, base=16, B=3000, seed=0, gridtype=0, align=False, scale=1e-4):
+    rng = np.random.default_rng(seed)
+    offsets, pls = O.grid_offsets(input_dim=D, num_levels=L, level_dim=C, base_resolution=base, log2_hashmap_size=T_log2,
+                                  desired_resolution=desired, align_corners=align)
+    table = rng.uniform(-scale, scale, (int(offsets[-1]), C)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0] = 0; x[1] = 1; x[2, 0] = 1.0000001; x[3, 1] = -1e-7; x[4] = 0.5          # edges, OOB, cell boundary
+    return offsets, pls, table, x
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(L=4), dict(desired=4096), dict(D=2, L=4), dict(C=1, L=8, T_log2=14),
+                                dict(C=4, L=8, T_log2=14, desired=512), dict(C=8, L=8, T_log2=12, desired=256),
+                                dict(gridtype=1, T_log2=15, desired=1024), dict(align=True), dict(D=4, L=8, T_log2=14, desired=128),
+                                dict(D=5, L=8, T_log2=14, desired=64, B=500)])
+def test_grid_forward_fp32_bit_exact(O, kw):
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, **kw)
+    D, C, L = x.shape[1], table.shape[1], offsets.shape[0] - 1
+    gt, al = kw.get("gridtype", 0), kw.get("align", False)
+    for interp in (0, 1):
+        ref, ref_dd = O.grid_encode_forward(x, table, offsets, pls, kw.get("base", 16), calc_dy_dx=True, gridtype=gt,
+                                            align_corners=al, interp=interp)
+        out = torch.empty(L, x.shape[0], C, device=DEV); dd = torch.empty(x.shape[0], L * D * C, device=DEV)
+        G.grid_encode_forward(T(x), T(table), T(offsets), out, x.shape[0], D, C, L, np.log2(pls), kw.get("base", 16), dd, gt, al, interp)
+        assert np.array_equal(N(out), ref)
+        assert np.allclose(N(dd), ref_dd, rtol=1e-5, atol=1e-7)
+        out2 = torch.empty(x.shape[0], L * C, device=DEV)
+        G.grid_encode_forward(T(x), T(table), T(offsets), out2, x.shape[0], D, C, L, np.log2(pls), kw.get("base", 16), None, gt, al, interp, blc=True)
+        assert np.array_equal(N(out2).reshape(-1, L, C).transpose(1, 0, 2), ref)
+
+
+@pytest.mark.parametrize("kw", [dict(scale=0.5), dict(L=8, T_log2=14, C=4, scale=0.5), dict(D=2, L=4, scale=0.5)])
+def test_grid_forward_fp16_bit_exact(O, kw):
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, **kw)
+    D, C, L = x.shape[1], table.shape[1], offsets.shape[0] - 1
+    th = O.to_f16_bits(table)
+    ref, ref_dd = O.grid_encode_forward(x, th, offsets, pls, 16, calc_dy_dx=True, f16=True)
+    out = torch.empty(L, x.shape[0], C, device=DEV, dtype=torch.half)
+    dd = torch.empty(x.shape[0], L * D * C, device=DEV, dtype=torch.half)
+    G.grid_encode_forward(T(x), half_from_bits(th), T(offsets), out, x.shape[0], D, C, L, np.log2(pls), 16, dd, 0, False, 0)
+    assert np.array_equal(bits_from_half(out), ref)
+    assert np.allclose(N(dd), O.from_f16_bits(ref_dd), rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("kw", [dict(B=20000), dict(L=4, B=5000), dict(D=2, L=4), dict(C=4, L=8, T_log2=14, desired=512),
+                                dict(C=1, L=8, T_log2=14), dict(gridtype=1, T_log2=15, desired=1024)])
+def test_grid_backward_fp32(O, kw):
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, **kw)
+    D, C, L, B = x.shape[1], table.shape[1], offsets.shape[0] - 1, x.shape[0]
+    gt = kw.get("gridtype", 0)
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal((L, B, C)).astype(np.float32)
+    _, dd = O.grid_encode_forward(x, table, offsets, pls, 16, calc_dy_dx=True, gridtype=gt)
+    ref, ref_gi = O.grid_encode_backward(g, x, table.shape, offsets, pls, 16, dy_dx=dd, gridtype=gt)
+    ge = torch.zeros(table.shape, device=DEV); gi = torch.zeros(B, D, device=DEV)
+    G.grid_encode_backward(T(g), T(x), T(table), T(offsets), ge, B, D, C, L, np.log2(pls), 16, T(dd), gi, gt, False, 0)
+    # float atomics: order differs from the sequential oracle -> rounding-level tolerance
+    assert np.allclose(N(ge), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    assert np.allclose(N(gi), ref_gi, rtol=1e-4, atol=1e-5 * (1 + np.abs(ref_gi).max()))
+    ge2 = torch.zeros(table.shape, device=DEV)
+    gb = np.ascontiguousarray(g.transpose(1, 0, 2).reshape(B, L * C))
+    G.grid_encode_backward(T(gb), T(x), T(table), T(offsets), ge2, B, D, C, L, np.log2(pls), 16, None, None, gt, False, 0, blc=True)
+    assert np.allclose(N(ge2), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_grid_backward_fp16(O):
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, B=4000, L=8, T_log2=14, desired=512)
+    B, L, C = 4000, 8, 2
+    g = (np.random.default_rng(2).standard_normal((L, B, C)) * 1e-2).astype(np.float32)
+    gh = O.to_f16_bits(g)
+    ref32, _ = O.grid_encode_backward(O.from_f16_bits(gh), x, table.shape, offsets, pls, 16)
+    ge = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    G.grid_encode_backward(half_from_bits(gh), T(x), T(table).half(), T(offsets), ge, B, 3, C, L, np.log2(pls), 16, None, None, 0, False, 0)
+    # fp16 atomics round every partial sum: compare with the fp32 sum at fp16 resolution of the largest bins
+    assert np.abs(N(ge) - ref32).max() < 2e-2 * np.abs(ref32).max()
+
+
+def test_grid_autograd_module(O):
+    """GridEncoder module: forward [B, L*C], backward -> embeddings.grad; fp32 and autocast(fp16)"""
+    from laenerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=8, log2_hashmap_size=14, desired_resolution=512).to(DEV)
+    rng = np.random.default_rng(3)
+    enc.embeddings.data = T(rng.uniform(-0.5, 0.5, enc.embeddings.shape).astype(np.float32))
+    x = rng.uniform(-1, 1, (1000, 3)).astype(np.float32)
+    y = enc(T(x), bound=1)
+    ref, _ = O.grid_encode_forward((x + 1) / 2, N(enc.embeddings), N(enc.offsets), enc.per_level_scale, 16, out_blc=True)
+    assert y.shape == (1000, 16) and np.allclose(N(y), ref, atol=1e-6)
+    g = rng.standard_normal((1000, 16)).astype(np.float32)
+    y.backward(T(g))
+    refg, _ = O.grid_encode_backward(g, (x + 1) / 2, tuple(enc.embeddings.shape), N(enc.offsets), enc.per_level_scale, 16, grad_blc=True)
+    assert np.allclose(N(enc.embeddings.grad), refg, rtol=1e-4, atol=1e-4 * np.abs(refg).max())
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = enc(T(x), bound=1)
+    assert y16.dtype == torch.float16 and np.abs(N(y16) - ref).max() < 3e-3
+    # input gradients (calc_grad_inputs) through the module
+    xi = T(x).requires_grad_()
+    enc(xi, bound=1).backward(T(g))
+    _, dd = O.grid_encode_forward((x + 1) / 2, N(enc.embeddings), N(enc.offsets), enc.per_level_scale, 16, calc_dy_dx=True, out_blc=True)
+    _, gi = O.grid_encode_backward(g, (x + 1) / 2, tuple(enc.embeddings.shape), N(enc.offsets), enc.per_level_scale, 16, dy_dx=dd, grad_blc=True)
+    assert np.allclose(N(xi.grad), gi / 2, rtol=1e-3, atol=1e-3 * np.abs(gi).max())
+
+
+def test_grid_total_variation(O):
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, L=8, T_log2=14, desired=512, B=2000, scale=0.5)
+    grad = np.zeros_like(table)
+    O.grad_total_variation(x, table, grad, offsets, 1e-3, pls, 16)
+    g = torch.zeros(table.shape, device=DEV)
+    G.grad_total_variation(T(x), T(table), g, T(offsets), 1e-3, 2000, 3, 2, 8, np.log2(pls), 16, 0, False)
+    assert np.allclose(N(g), grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("degree", range(1, 9))
+def test_sh_all_degrees(O, degree):
+    from laenerf_amd.shencoder import sh_encode
+    rng = np.random.default_rng(degree)
+    for B in (1, 255, 1000):
+        d = rng.standard_normal((B, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[0] = [0, 0, 1]
+        ref, ref_dd = O.sh_encode_forward(d, degree, True)
+        out = sh_encode(T(d), degree, False)
+        assert out.shape == (B, degree * degree)
+        assert np.allclose(N(out), ref, rtol=2e-5, atol=2e-6)
+        di = T(d).requires_grad_()
+        y = sh_encode(di, degree, True)
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        y.backward(T(g))
+        assert np.allclose(N(di.grad), O.sh_encode_backward(g, ref_dd, degree), rtol=1e-4, atol=1e-4 * (1 + np.abs(ref_dd).max()))

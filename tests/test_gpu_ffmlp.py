@@ -1,0 +1,87 @@
+"""-m gpu: MFMA MLP vs the oracle (fp16 storage, fp32 accumulate).  Tolerances: outputs differ from the oracle only
+by the MFMA's internal summation order before the fp16 rounding of each stored activation (<= 1 fp16 ulp per layer)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, N, T, bits_from_half, half_from_bits
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(32, 64, 2), (32, 64, 3), (48, 64, 2), (64, 64, 2), (16, 16, 2), (32, 32, 4), (32, 128, 2), (48, 128, 3), (32, 256, 2)]
+
+
+def close_f16(a, b, rel=4e-3, floor=2e-3):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.abs(a - b).max() <= rel * np.abs(b).max() + floor
+
+
+@pytest.mark.parametrize("IN,H,NL", CASES)
+@pytest.mark.parametrize("B", [128, 1152])
+def test_ffmlp_forward_backward(O, IN, H, NL, B):
+    from laenerf_amd.backend import ffmlp_backend as F
+    rng = np.random.default_rng(IN + H + NL)
+    nW = O.ffmlp_num_params(IN, H, NL)
+    W = rng.uniform(-np.sqrt(3 / H), np.sqrt(3 / H), nW).astype(np.float32)
+    X = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    Wh, Xh = O.to_f16_bits(W), O.to_f16_bits(X)
+    ref_out, ref_fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL)
+    out = torch.empty(B, 16, device=DEV, dtype=torch.half); fb = torch.empty(NL, B, H, device=DEV, dtype=torch.half)
+    F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, fb, out)
+    assert close_f16(N(fb), O.from_f16_bits(ref_fb)) and close_f16(N(out), O.from_f16_bits(ref_out))
+    out_i = torch.empty(B, 16, device=DEV, dtype=torch.half)
+    F.ffmlp_inference(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, None, out_i)
+    assert torch.equal(out_i, out)
+    # backward: feed the ORACLE's forward buffer so both sides see identical ReLU masks
+    G = (rng.standard_normal((B, 16)) * 0.05).astype(np.float32); Gh = O.to_f16_bits(G)
+    ref_gw, ref_gi, ref_bb = O.ffmlp_backward(Gh, Xh, Wh, ref_fb, IN, 16, H, NL, calc_grad_inputs=True)
+    bb = torch.empty(NL, B, H, device=DEV, dtype=torch.half); gi = torch.empty(B, IN, device=DEV, dtype=torch.half)
+    gw = torch.empty(nW, device=DEV, dtype=torch.half)
+    F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), half_from_bits(ref_fb), B, IN, 16, H, NL, 0, 6, True, bb, gi, gw)
+    assert close_f16(N(bb), O.from_f16_bits(ref_bb), floor=5e-4)
+    assert close_f16(N(gi), O.from_f16_bits(ref_gi), floor=5e-4)
+    assert close_f16(N(gw), O.from_f16_bits(ref_gw), rel=1e-2, floor=2e-3)
+    # determinism of the slab reduction
+    gw2 = torch.empty_like(gw)
+    F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), half_from_bits(ref_fb), B, IN, 16, H, NL, 0, 6, False, bb, gi, gw2)
+    assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize("act", [0, 3, 6])
+def test_ffmlp_activations(O, act):
+    from laenerf_amd.backend import ffmlp_backend as F
+    rng = np.random.default_rng(act)
+    IN, H, NL, B = 32, 64, 2, 256
+    nW = O.ffmlp_num_params(IN, H, NL)
+    Wh = O.to_f16_bits(rng.uniform(-0.2, 0.2, nW).astype(np.float32)); Xh = O.to_f16_bits(rng.uniform(-1, 1, (B, IN)).astype(np.float32))
+    ref_out, ref_fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL, activation=act)
+    out = torch.empty(B, 16, device=DEV, dtype=torch.half); fb = torch.empty(NL, B, H, device=DEV, dtype=torch.half)
+    F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, act, 6, fb, out)
+    assert close_f16(N(out), O.from_f16_bits(ref_out)) and close_f16(N(fb), O.from_f16_bits(ref_fb))
+
+
+def test_ffmlp_module_matches_linear_chain(O):
+    """FFMLP module under autocast == the nn.Linear chain of the reference (golden vectors from nerf/network.py)"""
+    from conftest import golden
+    from test_oracle_golden_cpu import ff_weights_from_linear
+    from laenerf_amd.ffmlp import FFMLP
+    g = golden("mlp_chain")
+    m = FFMLP(32, 16, 64, 2).to(DEV)
+    m.weights.data = T(ff_weights_from_linear([g["sigma_w"], g["sigma_w1"], g["sigma_w2"]], 32))
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m(T(g["enc"]))
+    assert y.shape == (512, 16) and np.abs(N(y) - g["sigma_h"]).max() < 2e-3
+    # training mode + backward through the autograd.Function
+    x = T(g["enc"]).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = m.train()(x)
+    y.float().square().sum().backward()
+    lin = [torch.nn.Linear(32, 64, bias=False), torch.nn.Linear(64, 64, bias=False), torch.nn.Linear(64, 16, bias=False)]
+    for l, w in zip(lin, (g["sigma_w"], g["sigma_w1"], g["sigma_w2"])):
+        l.weight.data = T(w)
+    xr = T(g["enc"]).requires_grad_()
+    h = torch.relu(lin[0].to(DEV)(xr)); h = torch.relu(lin[1].to(DEV)(h)); yr = lin[2].to(DEV)(h)
+    yr.square().sum().backward()
+    gw_ref = torch.cat([l.weight.grad.reshape(-1) for l in lin])
+    assert np.abs(N(m.weights.grad) - N(gw_ref)).max() < 2e-2 * N(gw_ref).max()
+    assert np.abs(N(x.grad) - N(xr.grad)).max() < 2e-2 * np.abs(N(xr.grad)).max() + 1e-3

@@ -1,0 +1,257 @@
+"""The oracle against independent published definitions (the parts of the path the reference only has in CUDA)."""
+import numpy as np
+import pytest
+
+
+def test_sh_matches_scipy_and_is_orthonormal(O):
+    from scipy.special import sph_harm_y
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((2048, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out, _ = O.sh_encode_forward(d, 8)
+    theta, phi = np.arccos(np.clip(d[:, 2], -1, 1)), np.arctan2(d[:, 1], d[:, 0])
+    for l in range(8):
+        for m in range(-l, l + 1):
+            Y = sph_harm_y(l, abs(m), theta, phi)           # includes the Condon-Shortley phase
+            v = Y.real if m == 0 else np.sqrt(2) * (Y.real if m > 0 else Y.imag)
+            assert np.abs(out[:, l * l + l + m] - v).max() < 2e-6, (l, m)
+    # reference constants spot checks (shencoder.cu:50-56)
+    o1, _ = O.sh_encode_forward(np.array([[0.3, -0.5, 0.81]]), 2)
+    assert np.allclose(o1[0], [0.28209479, -0.48860251 * -0.5, 0.48860251 * 0.81, -0.48860251 * 0.3], atol=1e-7)
+    # orthonormality by Monte-Carlo quadrature on the sphere
+    G = out.T @ out * (4 * np.pi / d.shape[0])
+    assert np.abs(G - np.eye(64)).max() < 0.35          # MC noise ~ sqrt(64/2048)
+
+
+def test_sh_gradients_by_finite_differences(O):
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal((64, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32).astype(np.float64)
+    _, dy = O.sh_encode_forward(d, 6, True)
+    dy = dy.reshape(64, 3, 36)
+    eps = 1e-3
+    for ax in range(3):
+        dp, dm = d.copy(), d.copy(); dp[:, ax] += eps; dm[:, ax] -= eps
+        fd = (O.sh_encode_forward(dp, 6)[0].astype(np.float64) - O.sh_encode_forward(dm, 6)[0]) / (2 * eps)
+        assert np.abs(fd - dy[:, ax]).max() < 5e-3
+    g = rng.standard_normal((64, 36)).astype(np.float32)
+    gi = O.sh_encode_backward(g, dy.reshape(64, -1), 6)
+    assert np.allclose(gi, np.einsum("bc,bdc->bd", g, dy), atol=1e-4)
+
+
+def test_morton_is_bit_interleave_and_roundtrips(O):
+    rng = np.random.default_rng(2)
+    c = rng.integers(0, 128, (4096, 3)).astype(np.int32)
+    naive = np.zeros(4096, np.int64)
+    for b in range(7):
+        for a in range(3):
+            naive |= ((c[:, a] >> b) & 1).astype(np.int64) << (3 * b + a)
+    m = O.morton3D(c)
+    assert np.array_equal(m, naive)
+    assert np.array_equal(O.morton3D_invert(m), c)
+    allc = np.stack(np.meshgrid(*[np.arange(128)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    idx = O.morton3D(allc)
+    assert np.array_equal(np.sort(idx), np.arange(128 ** 3))
+
+
+def test_packbits(O):
+    rng = np.random.default_rng(3)
+    g = rng.uniform(-1, 3, 4096).astype(np.float32)
+    g[::7] = 1.5; g[::11] = -1            # exactly-at-threshold and the untrained marker (renderer.py:552)
+    bits = O.packbits(g, 1.5)
+    assert np.array_equal(np.unpackbits(bits, bitorder="little").astype(bool), g > 1.5)
+
+
+def trilinear_dense(x, table, res_p1, scale):
+    """independent dense trilinear interpolation with align_corners=False (pos = x*scale + 0.5)"""
+    pos = x.astype(np.float64) * scale + 0.5
+    p0 = np.floor(pos).astype(np.int64); f = pos - p0
+    out = np.zeros((x.shape[0], table.shape[1]))
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                idx = (p0[:, 0] + dx) + (p0[:, 1] + dy) * res_p1 + (p0[:, 2] + dz) * res_p1 ** 2
+                out += w[:, None] * table[idx]
+    return out
+
+
+def test_grid_dense_levels_are_trilinear_and_hash_uses_ngp_primes(O):
+    rng = np.random.default_rng(4)
+    offsets, pls = O.grid_offsets(num_levels=16, desired_resolution=2048)
+    table = rng.uniform(-1, 1, (int(offsets[-1]), 2)).astype(np.float32)
+    x = rng.uniform(0, 1, (512, 3)).astype(np.float32)
+    x[0] = 0; x[1] = 1; x[2] = [0, 1, 0.5]
+    out, _ = O.grid_encode_forward(x, table, offsets, pls, 16)
+    S = np.float32(np.log2(pls))
+    for level in (0, 1, 2, 3, 4):               # dense levels
+        scale = float(np.float32(np.exp2(np.float32(level) * S)) * np.float32(16) - np.float32(1))
+        res = int(np.ceil(scale)) + 1
+        ref = trilinear_dense(x, table[offsets[level]:offsets[level + 1]].astype(np.float64), res + 1, scale)
+        assert np.abs(out[level] - ref).max() < 1e-5, level
+    # hashed level: index = (x ^ y*2654435761 ^ z*805459861) mod 2^19
+    level = 10
+    scale = float(np.float32(np.exp2(np.float32(level) * S)) * np.float32(16) - np.float32(1))
+    pos = x.astype(np.float64) * scale + 0.5
+    p0 = np.floor(pos).astype(np.uint64); f = pos - p0
+    ref = np.zeros((512, 2))
+    T = int(offsets[level + 1] - offsets[level])
+    assert T == 2 ** 19
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                h = ((p0[:, 0] + dx) & 0xffffffff) ^ (((p0[:, 1] + dy) * 2654435761) & 0xffffffff) ^ (((p0[:, 2] + dz) * 805459861) & 0xffffffff)
+                ref += w[:, None] * table[offsets[level] + (h % T).astype(np.int64)]
+    assert np.abs(out[level] - ref).max() < 1e-4        # fp32 coordinate rounding at scale ~400 (gridencoder.cu:141)
+    # out-of-range inputs give zeros (gridencoder.cu:110-135)
+    xo = np.array([[1.0001, 0.5, 0.5], [0.5, -1e-6, 0.5]], np.float32)
+    oo, dd = O.grid_encode_forward(xo, table, offsets, pls, 16, calc_dy_dx=True)
+    assert np.all(oo == 0) and np.all(dd == 0)
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+def test_grid_backward_is_the_adjoint_and_dydx_is_the_derivative(O, interp):
+    rng = np.random.default_rng(5)
+    offsets, pls = O.grid_offsets(num_levels=6, log2_hashmap_size=12, desired_resolution=256)
+    table = rng.uniform(-1, 1, (int(offsets[-1]), 2)).astype(np.float32)
+    x = rng.uniform(0.05, 0.95, (64, 3)).astype(np.float32)
+    out, dy = O.grid_encode_forward(x, table, offsets, pls, 16, calc_dy_dx=True, interp=interp)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    gt, gi = O.grid_encode_backward(g, x, table.shape, offsets, pls, 16, dy_dx=dy, interp=interp)
+    # <g, J dW> == <J^T g, dW> for a random table perturbation (encoding is linear in the table)
+    dW = rng.standard_normal(table.shape).astype(np.float32)
+    out2, _ = O.grid_encode_forward(x, table + dW, offsets, pls, 16, interp=interp)
+    assert np.sum(g * (out2 - out).astype(np.float64)) == pytest.approx(np.sum(gt.astype(np.float64) * dW), rel=2e-3)
+    # input gradient vs central differences
+    eps = 1e-4
+    for ax in range(3):
+        xp, xm = x.copy(), x.copy(); xp[:, ax] += eps; xm[:, ax] -= eps
+        fp, _ = O.grid_encode_forward(xp, table, offsets, pls, 16, interp=interp)
+        fm, _ = O.grid_encode_forward(xm, table, offsets, pls, 16, interp=interp)
+        fd = np.sum(g * ((fp - fm) / (xp[:, ax] - xm[:, ax])[None, :, None]), axis=(0, 2))
+        ok = np.abs(fd - gi[:, ax]) < 2e-2 * (1 + np.abs(fd))
+        assert ok.mean() > 0.75      # samples whose +-eps stencil crosses a cell face (kink of the linear interpolant) are excluded
+
+
+def test_grid_fp16_mode_tracks_fp32(O):
+    rng = np.random.default_rng(6)
+    offsets, pls = O.grid_offsets(num_levels=8, log2_hashmap_size=12, desired_resolution=512)
+    table = rng.uniform(-0.5, 0.5, (int(offsets[-1]), 2)).astype(np.float32)
+    th = O.to_f16_bits(table)
+    x = rng.uniform(0, 1, (256, 3)).astype(np.float32)
+    o32, _ = O.grid_encode_forward(x, O.from_f16_bits(th), offsets, pls, 16, out_blc=True)
+    o16, _ = O.grid_encode_forward(x, th, offsets, pls, 16, f16=True, out_blc=True)
+    assert np.abs(O.from_f16_bits(o16) - o32).max() < 2e-3          # 8 fp16 accumulations of O(0.5) values
+
+
+def test_march_invariants(O):
+    from laenerf_amd import synthetic as S
+    for C, bound, dtg in ((1, 1.0, 0.0), (2, 2.0, 0.0), (2, 2.0, 1 / 128), (1, 1.0, 1 / 64)):
+        grid = S.sphere_density_grid(cascade=C, bound=bound)
+        bits = S.pack_bits_np(grid, 10.0)
+        o, d = S.lego_like_rays(256, seed=C, radius=2.6)
+        d[0] = [0, 0, -1]; o[0] = [0.1, 0.2, 3.0]                 # axis-parallel ray: 1/0 = inf slabs
+        nears, fars = O.near_far_from_aabb(o, d, [-bound] * 3 + [bound] * 3, 0.05)
+        noises = np.random.default_rng(1).random(256).astype(np.float32)
+        xyzs, dirs, deltas, rays, counter = O.march_rays_train(o, d, bound, bits, C, 128, nears, fars, noises, dt_gamma=dtg)
+        total = int(counter[0])
+        assert counter[1] == 256 and rays[:, 2].sum() == total
+        assert np.array_equal(rays[:, 1], np.concatenate([[0], np.cumsum(rays[:-1, 2])]))
+        dt_min, dt_max = 2 * np.sqrt(3) / 1024, 2 * np.sqrt(3) * 2 ** (C - 1) / 128
+        dl = deltas[:total]
+        assert dl[:, 0].min() >= np.float32(dt_min) * (1 - 1e-6) and dl[:, 0].max() <= np.float32(dt_max) * (1 + 1e-6)
+        assert np.all(dl[:, 1] >= dl[:, 0] * (1 - 1e-3))              # depth delta includes skipped space
+        assert np.all(np.abs(xyzs[:total]) <= bound)
+        assert np.all(rays[nears > 1e30, 2] == 0)                     # missed rays: near = far = FLT_MAX
+        # every emitted sample sits in an occupied voxel of its cascade
+        p = xyzs[:total].astype(np.float64)
+        lvl = np.clip(np.frexp(np.abs(p).max(1))[1], 0, C - 1)
+        lvl = np.maximum(lvl, np.clip(np.frexp(dl[:, 0].astype(np.float64) * 128 * 0.5)[1], 0, C - 1))
+        mb = np.minimum(2.0 ** lvl, bound)[:, None]
+        n = np.clip((0.5 * (p / mb + 1) * 128), 0, 127).astype(np.int64)
+        idx = lvl * 128 ** 3 + O.morton3D(n.astype(np.int32)).astype(np.int64)
+        assert np.all((bits[idx >> 3] >> (idx & 7)) & 1)
+
+
+def test_composite_backward_is_the_gradient_of_forward(O):
+    rng = np.random.default_rng(7)
+    N, K = 16, 12
+    rays = np.stack([rng.permutation(N), np.arange(N) * K, rng.integers(0, K + 1, N)], 1).astype(np.int32)
+    M = N * K
+    sig = rng.uniform(0, 30, M).astype(np.float32)
+    rgb = rng.uniform(0, 1, (M, 3)).astype(np.float32)
+    dl = np.stack([rng.uniform(0.003, 0.02, M), rng.uniform(0.003, 0.05, M)], 1).astype(np.float32)
+    ws, depth, img = O.composite_rays_train_forward(sig, rgb, dl, rays, T_thresh=0.0)
+    gws, gimg = rng.standard_normal(N).astype(np.float32), rng.standard_normal((N, 3)).astype(np.float32)
+    gs, gc = O.composite_rays_train_backward(gws, gimg, sig, rgb, dl, rays, ws, img, T_thresh=0.0)
+    L = lambda s, c: (lambda r: np.sum(gws * r[0].astype(np.float64)) + np.sum(gimg * r[2].astype(np.float64)))(O.composite_rays_train_forward(s, c, dl, rays, T_thresh=0.0))
+    for i in rng.choice(M, 24, replace=False):
+        e = 1e-2
+        sp, sm = sig.copy(), sig.copy(); sp[i] += e; sm[i] -= e
+        fd = (L(sp, rgb) - L(sm, rgb)) / (sp[i] - sm[i])
+        assert fd == pytest.approx(gs[i], rel=5e-2, abs=2e-4)
+    i = int(rays[rays[:, 2] > 0][0, 1])
+    cp, cm = rgb.copy(), rgb.copy(); cp[i, 1] += 1e-2; cm[i, 1] -= 1e-2
+    assert (L(sig, cp) - L(sig, cm)) / 2e-2 == pytest.approx(gc[i, 1], rel=2e-2, abs=1e-5)
+
+
+def test_inference_loop_equals_training_composite(O):
+    """K9+K11 iterated with the reference's n_step schedule == K6+K7 on the same scene (T_thresh small)"""
+    from laenerf_amd import synthetic as S
+    bits = S.pack_bits_np(S.sphere_density_grid(), 10.0)
+    o, d = S.lego_like_rays(200, seed=4)
+    N = 200
+    nears, fars = O.near_far_from_aabb(o, d, [-1, -1, -1, 1, 1, 1], 0.2)
+    xyzs, dirs, deltas, rays, counter = O.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, np.zeros(N), max_steps=256)
+    field = lambda p: (25 * np.exp(-4 * (p ** 2).sum(-1)).astype(np.float32), (0.5 + 0.5 * np.sin(3 * p)).astype(np.float32))
+    s, c = field(xyzs)
+    ws_t, dep_t, img_t = O.composite_rays_train_forward(s, c, deltas, rays, T_thresh=1e-4)
+    ws, dep, img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive, rays_t, step = np.arange(N, dtype=np.int32), nears.copy(), 0
+    while step < 256 and alive.size:
+        n_alive = alive.size
+        n_step = max(min(N // n_alive, 8), 1)
+        x, dd, dl = O.march_rays(n_alive, n_step, alive, rays_t, o, d, 1.0, bits, 1, 128, nears, fars, np.zeros(n_alive),
+                                 align=128, max_steps=256)
+        s, c = field(x)
+        O.composite_rays(n_alive, n_step, alive, rays_t, s, c, dl, ws, dep, img, T_thresh=1e-4)
+        alive = np.ascontiguousarray(alive[alive >= 0])
+        step += n_step
+    # the two early-stop rules differ by at most one sample of weight < T_thresh
+    assert np.abs(ws - ws_t).max() < 2e-4 and np.abs(img - img_t).max() < 2e-4
+    # inference accumulates absolute t (rays_t starts at near), training t relative to the first sample
+    assert np.abs((dep - ws * nears) - dep_t).max() < 2e-3
+
+
+def test_ffmlp_backward_is_the_gradient(O):
+    rng = np.random.default_rng(8)
+    B, IN, H, NL = 128, 32, 64, 3
+    nW = O.ffmlp_num_params(IN, H, NL)
+    W = rng.uniform(-0.2, 0.2, nW).astype(np.float32)
+    X = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    Wh, Xh = O.to_f16_bits(W), O.to_f16_bits(X)
+    out, fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL)
+    G = rng.standard_normal((B, 16)).astype(np.float32) * 0.1
+    gw, gi, bb = O.ffmlp_backward(O.to_f16_bits(G), Xh, Wh, fb, IN, 16, H, NL, calc_grad_inputs=True)
+    gw, gi = O.from_f16_bits(gw), O.from_f16_bits(gi)
+    # float64 reference of the same network
+    Wf = O.from_f16_bits(Wh).astype(np.float64); Xf = O.from_f16_bits(Xh).astype(np.float64)
+    Gf = O.from_f16_bits(O.to_f16_bits(G)).astype(np.float64)
+    mats, off, K = [], 0, IN
+    for l in range(NL):
+        mats.append(Wf[off:off + H * K].reshape(H, K)); off += H * K; K = H
+    mats.append(Wf[off:off + 16 * H].reshape(16, H))
+    acts = [Xf]
+    for m in mats[:-1]:
+        acts.append(np.maximum(acts[-1] @ m.T, 0))
+    y = acts[-1] @ mats[-1].T
+    assert np.abs(O.from_f16_bits(out) - y).max() < 5e-3
+    g = Gf; grads = []
+    for l in range(NL, -1, -1):
+        grads.append(g.T @ acts[l])
+        g = g @ mats[l]
+        if l > 0:
+            g = g * (acts[l] > 0)
+    gw_ref = np.concatenate([x.reshape(-1) for x in grads[::-1]])
+    assert np.abs(gw - gw_ref).max() < 2e-2 * (1 + np.abs(gw_ref).max())
+    assert np.abs(gi - g).max() < 1e-2
