@@ -83,7 +83,7 @@ def test_march_rays_train_wrapper_modes(O, rm):
     # empty / ragged: zero rays, and rays that all miss
     e = torch.zeros(0, 3, device=DEV)
     xe, _, _, re_ = rm.march_rays_train(e, e, 1.0, bits, 1, 128, torch.zeros(0, device=DEV), torch.zeros(0, device=DEV), None, -1, False, 128, False, 0, 64)
-    assert re_.shape == (0, 3) and xe.shape[0] == 128
+    assert re_.shape == (0, 3) and xe.shape[0] == 0          # zeros(0,3)[:128] is empty, as in the reference
     far_o = T(np.full((64, 3), 9.0, np.float32)); up = T(np.tile(np.array([[0, 1, 0]], np.float32), (64, 1)))
     nn_, ff_ = rm.near_far_from_aabb(far_o, up, T(np.array([-1, -1, -1, 1, 1, 1], np.float32)), 0.2)
     c = torch.zeros(2, dtype=torch.int32, device=DEV)
