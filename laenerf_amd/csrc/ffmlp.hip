@@ -14,7 +14,6 @@
 // is bit-for-bit the B fragment of K-step t of the next layer, so activations
 // chain through all layers in registers: no LDS, no shuffles.  Accumulation is
 // fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
-#include <mutex>
 #include "lae_common.h"
 
 namespace {
@@ -336,33 +335,7 @@ __global__ void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, 
 }
 
 // ---------------------------------------------------------------- host side
-// Process-global split-K workspace, the counterpart of the reference's static stream/event
-// vectors + per-stream CUTLASS workspace (ffmlp.cu:711-740, cutlass_matmul.h:335-352).
-std::mutex g_ws_mutex;
-float* g_ws = nullptr;
-size_t g_ws_bytes = 0;
-constexpr size_t WS_DEFAULT_BYTES = 48ull << 20;
-
-int ensure_workspace(size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_ws_mutex);
-    if (g_ws_bytes >= bytes) return LAE_OK;
-    if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
-    const size_t want = bytes > WS_DEFAULT_BYTES ? bytes : WS_DEFAULT_BYTES;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_ws), want);
-    if (e != hipSuccess) { lae::set_last_error("ffmlp workspace hipMalloc", e); return LAE_ELAUNCH; }
-    g_ws_bytes = want;
-    return LAE_OK;
-}
-
-int n_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+int n_cus() { return lae::num_cus(); }
 
 bool shape_ok(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t hidden, uint32_t num_layers) {
     // ffmlp.py:112-115,157: hidden in {16..256}, in % 16 == 0, out <= 16 (always padded to 16), layers >= 2, B % 128 == 0
@@ -423,8 +396,8 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
     const uint32_t n_jobs = MB * NB0 + MB * MB * n_hidden + MB;
     // slices: aim for ~4 workgroups per CU in total, at least 64 rows per slice, bounded by the workspace
     uint32_t n_slices = max(1u, min(B / 64, (uint32_t)(n_cus() * 4) / n_jobs));
-    int rc = ensure_workspace((size_t)n_slices * nW * sizeof(float));
-    if (rc) return rc;
+    float* g_ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)n_slices * nW * sizeof(float)));
+    if (!g_ws) return LAE_ELAUNCH;
     uint32_t rows_per_slice = lae::cdiv(B, n_slices);
     rows_per_slice = (rows_per_slice + 63) / 64 * 64;
     n_slices = lae::cdiv(B, rows_per_slice);
@@ -487,8 +460,7 @@ int lae_allocate_splitk(uint64_t size) {
 }
 
 int lae_free_splitk(void) {
-    std::lock_guard<std::mutex> lk(g_ws_mutex);
-    if (g_ws) { (void)hipFree(g_ws); g_ws = nullptr; g_ws_bytes = 0; }
+    lae::free_workspaces();
     return LAE_OK;
 }
 

@@ -10,6 +10,14 @@ namespace lae {
 
 void set_last_error(const char* what, hipError_t e);
 
+// Library-owned, grow-only device workspaces (the counterpart of the reference's process-global split-K
+// streams + CUTLASS workspace, ffmlp.cu:711-740, cutlass_matmul.h:335-352).  Returns nullptr on failure
+// (error string set).  Growing synchronises the device once; steady state is allocation free.
+enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_SLOTS = 2 };
+void* workspace(WsSlot slot, size_t bytes);
+void free_workspaces();
+int num_cus();
+
 // every launch is followed by this: the reference never checked its launches
 // (SURVEY 8b "Errors"); we do, and surface the error through the return code.
 static inline int check_launch(const char* what) {
