@@ -185,96 +185,149 @@ static MarchCfg make_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32
 }
 
 // ---------------------------------------------------------------- K6 (training march)
-// raymarching.cu:311-480, split into count -> scan -> emit.
-constexpr int MARCH_BLOCK = 128;   // 2 waves; N = 4096 rays -> 32 blocks spread over CUs
+// raymarching.cu:311-480.  MI355X form: ONE WAVEFRONT PER RAY.
+//
+// The reference walks a ray with one thread: probe the bitfield (a dependent 1-byte load), then either emit a
+// sample and advance by dt, or skip to the voxel exit with `do t += dt while (t < tt)`.  Either way t only ever
+// moves along the fixed sequence T_{k+1} = T_k + clamp(T_k * dt_gamma, dt_min, dt_max): occupancy decides
+// which T_k are VISITED, never their values.  So a wave evaluates 64 consecutive candidates at once
+//   1. lanes build T_k..T_k+63 with the exact serial fp32 recurrence (pure VALU, no memory),
+//   2. every lane probes its candidate (64 bitfield loads in flight instead of 1),
+//   3. the visited chain is resolved on the scalar unit from two ballots: runs of occupied candidates are
+//      taken whole, an empty candidate jumps to the first T_j >= tt (ballot + ctz),
+//   4. emitted samples are ranked with popcounts of the emit mask -> consecutive lanes write consecutive rows.
+// Counts, offsets and every emitted float are bit-identical to the serial walk (same probe_at / same sums).
+constexpr int MARCH_WAVES = 4;                 // rays per 256-thread block
+constexpr int MARCH_BLOCK = 64 * MARCH_WAVES;
 
-// pass 1: per-ray sample count + block-local exclusive prefix
-__global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_count(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
-    MarchCfg cfg, uint32_t max_steps, uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
-    const float* __restrict__ noises, uint32_t* __restrict__ counts, uint32_t* __restrict__ local_prefix,
-    uint32_t* __restrict__ block_totals) {
-    __shared__ uint32_t lds[MARCH_BLOCK / 64 + 1];
-    const uint32_t n = blockIdx.x * MARCH_BLOCK + threadIdx.x;
-    uint32_t num = 0;
-    if (n < N) {
-        const Ray r = load_ray(rays_o, rays_d, n);
-        const float far = fars[n];
-        float t = nears[n];
-        t = fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t);   // :351
-        while (t < far && num < max_steps) {
-            const Probe p = probe_at(r, cfg, grid, t);
-            if (p.occ) { num++; t += p.dt; }
-            else t = skip_to(cfg, t, p.tt);
+__device__ __forceinline__ float step_of(const MarchCfg& c, float t) { return clampf(t * c.dt_gamma, c.dt_min, c.dt_max); }
+
+// EMIT == false: count the samples of ray n.  EMIT == true: write them at `offset` (num_steps known).
+template <bool EMIT>
+__global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchCfg cfg,
+    uint32_t max_steps, uint32_t N, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
+    const float* __restrict__ noises, uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays) {
+    const uint32_t n = blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6);
+    if (n >= N) return;                                   // whole wave
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    uint32_t limit = max_steps, offset = 0;
+    if (EMIT) {
+        limit = counts[n];
+        offset = prefix[N] + prefix[n];                   // prefix[N] = counter value before this call (:405)
+        if (lane == 0) {
+            const uint32_t row = prefix[N + 1] + n;       // :406 (ray-id order)
+            rays[3 * (size_t)row + 0] = (int32_t)n;
+            rays[3 * (size_t)row + 1] = (int32_t)offset;
+            rays[3 * (size_t)row + 2] = (int32_t)limit;
         }
-        counts[n] = num;
+        if (limit == 0 || offset + limit > M) return;     // :415-416 (overflowing rays write nothing)
     }
-    uint32_t total;
-    const uint32_t ex = lae::block_excl_scan<MARCH_BLOCK / 64>(num, &total, lds);
-    if (n < N) local_prefix[n] = ex;
-    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t_base = nears[n];
+    t_base = fmaf(step_of(cfg, t_base), noises[n], t_base);                   // :351
+    float last_t = t_base;                                // post-step t of the previous emitted sample
+    uint32_t emitted = 0;
+    bool pending = false;                                 // walker is skipping towards pending_tt
+    float pending_tt = 0.f;
+
+    while (t_base < far && emitted < limit) {
+        // 1. candidates: lane i gets T_{base+i} by i serial steps (identical rounding to the serial walk)
+        float t = t_base;
+#pragma unroll 8
+        for (int j = 0; j < 63; j++) {
+            const float tn = t + step_of(cfg, t);
+            t = (lane > j) ? tn : t;
+        }
+        const float dt = step_of(cfg, t);
+        const float t_next = t + dt;                      // == T_{base+i+1}
+        const bool valid = t < far;
+        // 2. probe
+        Probe p;
+        p.occ = false; p.tt = t; p.x = p.y = p.z = 0.f; p.dt = dt; p.index = 0;
+        if (valid) p = probe_at(r, cfg, grid, t);
+        const unsigned long long valid_mask = __ballot(valid);
+        const unsigned long long occ_mask = __ballot(valid && p.occ);
+        // 3. visited chain (all scalar)
+        unsigned long long emit = 0ull;
+        int k = 0;
+        if (pending) {
+            const unsigned long long m = __ballot(valid && t >= pending_tt);
+            if (m) { k = __builtin_ctzll(m); pending = false; } else k = 64;
+        }
+        while (k < 64 && ((valid_mask >> k) & 1ull)) {
+            if ((occ_mask >> k) & 1ull) {
+                const unsigned long long inv = (~occ_mask) >> k;
+                const int run = inv ? __builtin_ctzll(inv) : 64 - k;          // bits beyond `valid` are 0 in occ_mask
+                emit |= ((run >= 64) ? ~0ull : ((1ull << run) - 1ull)) << k;
+                k += run;
+            } else {
+                const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.tt), k));
+                unsigned long long m = __ballot(valid && t >= tt);
+                m &= (k >= 63) ? 0ull : ~((2ull << k) - 1ull);                // at least one step (:396-398)
+                if (m) k = __builtin_ctzll(m);
+                else { pending = true; pending_tt = tt; k = 64; }
+            }
+        }
+        // cap at `limit` samples (:359 / :427)
+        uint32_t cnt = (uint32_t)__builtin_popcountll(emit);
+        bool done = false;
+        if (emitted + cnt > limit) {
+            const uint32_t keep = limit - emitted;
+            const bool mine = ((emit >> lane) & 1ull) && (uint32_t)__builtin_popcountll(emit & below) < keep;
+            emit = __ballot(mine);
+            cnt = keep;
+            done = true;
+        }
+        // 4. emit
+        if (EMIT && emit) {
+            const unsigned long long pm = emit & below;
+            const int prev_lane = pm ? 63 - __builtin_clzll(pm) : 0;
+            const float prev_next = __shfl(t_next, prev_lane, 64);
+            if ((emit >> lane) & 1ull) {
+                const size_t row = (size_t)offset + emitted + (uint32_t)__builtin_popcountll(pm);
+                float* px = xyzs + 3 * row; float* pd = dirs + 3 * row; float* pl = deltas + 2 * row;
+                px[0] = p.x; px[1] = p.y; px[2] = p.z;
+                pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+                pl[0] = dt;
+                pl[1] = t_next - (pm ? prev_next : last_t);                   // :461
+            }
+            const int top = 63 - __builtin_clzll(emit);
+            last_t = __shfl(t_next, top, 64);
+        }
+        emitted += cnt;
+        if (done || valid_mask != ~0ull) break;           // cap reached, or the ray left [near, far) in this chunk
+        t_base = __shfl(t_next, 63, 64);
+    }
+    if (!EMIT && lane == 0) counts[n] = emitted;
 }
 
-// single-block exclusive scan of the block totals (in place) + counter update (:405-406)
-__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t* __restrict__ totals, uint32_t nblk,
-                                                       int32_t* __restrict__ counter, uint32_t N) {
+// exclusive scan of the per-ray counts (single block) + counter update (:405-406).
+// prefix[0..N) = exclusive prefix, prefix[N] / prefix[N+1] = counter values before this call.
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ counts, uint32_t N,
+                                                       uint32_t* __restrict__ prefix, int32_t* __restrict__ counter) {
     __shared__ uint32_t lds[17];
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblk; base += 1024) {
+    for (uint32_t base = 0; base < N; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < nblk ? totals[i] : 0;
+        const uint32_t v = i < N ? counts[i] : 0;
         uint32_t total;
         const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
-        if (i < nblk) totals[i] = carry + ex;
+        if (i < N) prefix[i] = carry + ex;
         carry += total;
     }
-    // reservation bases = counter values before this call (what the reference's atomicAdd returns)
     if (threadIdx.x == 0) {
         int32_t b0 = 0, b1 = 0;
         if (counter) {
             b0 = atomicAdd(counter, (int32_t)carry);
             b1 = atomicAdd(counter + 1, (int32_t)N);
         }
-        totals[nblk] = (uint32_t)b0;
-        totals[nblk + 1] = (uint32_t)b1;
-    }
-}
-
-// pass 2: re-march and emit samples at offset = block prefix + local prefix
-__global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_emit(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
-    MarchCfg cfg, uint32_t N, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
-    const float* __restrict__ noises, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ local_prefix,
-    const uint32_t* __restrict__ block_prefix, uint32_t nblk,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays) {
-    const uint32_t n = blockIdx.x * MARCH_BLOCK + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t num_steps = counts[n];
-    const uint32_t point_index = block_prefix[nblk] + block_prefix[blockIdx.x] + local_prefix[n];
-    const uint32_t row = block_prefix[nblk + 1] + n;
-    rays[3 * (size_t)row + 0] = (int32_t)n;
-    rays[3 * (size_t)row + 1] = (int32_t)point_index;
-    rays[3 * (size_t)row + 2] = (int32_t)num_steps;
-    if (num_steps == 0 || point_index + num_steps > M) return;     // :415-416
-
-    const Ray r = load_ray(rays_o, rays_d, n);
-    const float far = fars[n];
-    float t = nears[n];
-    t = fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t);
-    float last_t = t;
-    float* px = xyzs + 3 * (size_t)point_index;
-    float* pd = dirs + 3 * (size_t)point_index;
-    float* pl = deltas + 2 * (size_t)point_index;
-    uint32_t step = 0;
-    while (t < far && step < num_steps) {
-        const Probe p = probe_at(r, cfg, grid, t);
-        if (p.occ) {
-            px[0] = p.x; px[1] = p.y; px[2] = p.z;
-            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-            t += p.dt;
-            pl[0] = p.dt; pl[1] = t - last_t; last_t = t;
-            px += 3; pd += 3; pl += 2; step++;
-        } else t = skip_to(cfg, t, p.tt);
+        prefix[N] = (uint32_t)b0;
+        prefix[N + 1] = (uint32_t)b1;
     }
 }
 
@@ -506,8 +559,7 @@ int lae_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
 }
 
 uint64_t lae_march_rays_train_scratch_bytes(uint32_t N) {
-    const uint64_t nblk = lae::cdiv(N, MARCH_BLOCK);
-    return 4ull * (2ull * N + nblk + 2) + 64;
+    return 4ull * (2ull * N + 2) + 64;        // counts[N] | prefix[N + 2]
 }
 
 int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -519,16 +571,15 @@ int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
         return LAE_ENULL;
     if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0) return LAE_EINVAL;
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
-    const uint32_t nblk = lae::cdiv(N, MARCH_BLOCK);
+    const uint32_t nblk = lae::cdiv(N, MARCH_WAVES);
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
-    uint32_t* local_prefix = counts + N;
-    uint32_t* totals = local_prefix + N;
+    uint32_t* prefix = counts + N;
     hipStream_t s = STREAM(stream);
-    k_march_train_count<<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, nears, fars, noises,
-                                                     counts, local_prefix, totals);
-    k_scan_totals<<<1, 1024, 0, s>>>(totals, nblk, counter, N);
-    k_march_train_emit<<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, N, M, nears, fars, noises, counts,
-                                                    local_prefix, totals, nblk, xyzs, dirs, deltas, rays);
+    k_march_train_wave<false><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
+                                                           counts, nullptr, nullptr, nullptr, nullptr, nullptr);
+    k_scan_counts<<<1, 1024, 0, s>>>(counts, N, prefix, counter);
+    k_march_train_wave<true><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
+                                                          counts, prefix, xyzs, dirs, deltas, rays);
     return lae::check_launch("march_rays_train");
 }
 
