@@ -125,7 +125,7 @@ def main():
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
     r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
     r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)      # main_nerf.py:223
+    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)      # main_nerf.py:223
     scaler = torch.amp.GradScaler("cuda")
     n_batches = 16
     batches = []

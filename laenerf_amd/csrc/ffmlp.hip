@@ -326,12 +326,27 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
     }
 }
 
-__global__ void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW, half_t* __restrict__ gw) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nW) return;
-    float s = 0;
-    for (uint32_t k = 0; k < n_slices; k++) s += slabs[(size_t)k * nW + i];
-    gw[i] = (half_t)s;
+// sum the per-slice slabs in a fixed order (deterministic) and round once to fp16.
+// 256 threads = 64 weights x 4 slice groups; unrolled by 4 so several slab loads are in flight per lane.
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
+                                                    half_t* __restrict__ gw) {
+    __shared__ float part[4][64];
+    const uint32_t e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64 + e;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (i < nW) {
+        uint32_t k = sg;
+        for (; k + 12 < n_slices; k += 16) {
+            s0 += slabs[(size_t)k * nW + i];
+            s1 += slabs[(size_t)(k + 4) * nW + i];
+            s2 += slabs[(size_t)(k + 8) * nW + i];
+            s3 += slabs[(size_t)(k + 12) * nW + i];
+        }
+        for (; k < n_slices; k += 4) s0 += slabs[(size_t)k * nW + i];
+    }
+    part[sg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0 && i < nW) gw[i] = (half_t)((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
 }
 
 // ---------------------------------------------------------------- host side
@@ -395,7 +410,7 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
     const uint32_t NB0 = (in_dim / 16 + 3) / 4;
     const uint32_t n_jobs = MB * NB0 + MB * MB * n_hidden + MB;
     // slices: aim for ~4 workgroups per CU in total, at least 64 rows per slice, bounded by the workspace
-    uint32_t n_slices = max(1u, min(B / 64, (uint32_t)(n_cus() * 4) / n_jobs));
+    uint32_t n_slices = max(1u, min(B / 64, (uint32_t)(n_cus() * 2) / n_jobs));
     float* g_ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)n_slices * nW * sizeof(float)));
     if (!g_ws) return LAE_ELAUNCH;
     uint32_t rows_per_slice = lae::cdiv(B, n_slices);
@@ -403,7 +418,7 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
     n_slices = lae::cdiv(B, rows_per_slice);
     k_mlp_dw<WIDTH><<<dim3(n_slices, n_jobs), MLP_BLOCK, 0, s>>>(grad, in, fwd_buf, bwd_buf, B, in_dim, n_hidden, g_ws, nW,
                                                                  rows_per_slice);
-    k_dw_reduce<<<lae::cdiv(nW, 256), 256, 0, s>>>(g_ws, n_slices, nW, gw);
+    k_dw_reduce<<<lae::cdiv(nW, 64), 256, 0, s>>>(g_ws, n_slices, nW, gw);
     return LAE_OK;
 }
 

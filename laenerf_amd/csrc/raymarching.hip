@@ -332,67 +332,119 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------- K7 / K8 (training composite)
-// raymarching.cu:500-577
-__global__ void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                      const float* __restrict__ deltas, const int32_t* __restrict__ rays,
-                                      uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
-                                      float* __restrict__ depth, float* __restrict__ image) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
-    const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
-    float r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0, T = 1.0f;
-    if (!(num_steps == 0 || offset + num_steps > M)) {
-        const float* s = sigmas + offset;
-        const float* c = rgbs + 3 * (size_t)offset;
-        const float* dl = deltas + 2 * (size_t)offset;
-        for (uint32_t k = 0; k < num_steps; k++) {
-            const float alpha = 1.0f - __expf(-s[k] * dl[2 * k]);
-            const float w = alpha * T;
-            r = fmaf(w, c[3 * k], r); g = fmaf(w, c[3 * k + 1], g); b = fmaf(w, c[3 * k + 2], b);
-            t += dl[2 * k + 1];
-            d = fmaf(w, t, d);
-            ws += w;
-            T *= 1.0f - alpha;
-            if (T < T_thresh) break;
-        }
-    }
-    weights_sum[index] = ws; depth[index] = d;
-    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+// raymarching.cu:500-577 / :601-682.  MI355X form: one wavefront per ray, 64 samples per pass.
+// Transmittance T_k = prod_{j<k} (1 - alpha_j) is a wave-level multiplicative scan, the running colour /
+// depth sums are additive scans, the early stop `T < T_thresh` is a ballot + ctz.  Sample reads and gradient
+// writes are lane-consecutive (coalesced); the reference's one-thread-per-ray loop strides by ray.
+// Scan association differs from the serial loop -> results agree to fp32 rounding (tests: 2e-6).
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= d) v *= o; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
 }
 
-// raymarching.cu:601-682
-__global__ void k_composite_train_bwd(const float* __restrict__ grad_ws, const float* __restrict__ grad_image,
-                                      const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                      const float* __restrict__ deltas, const int32_t* __restrict__ rays,
-                                      const float* __restrict__ weights_sum, const float* __restrict__ image,
-                                      uint32_t M, uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
-                                      float* __restrict__ grad_rgbs) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int COMP_WAVES = 4;
+constexpr int COMP_BLOCK = 64 * COMP_WAVES;
+
+__global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+    const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
+    float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
+    const int lane = threadIdx.x & 63;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
-    if (num_steps == 0 || offset + num_steps > M) return;
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (!(num_steps == 0 || offset + num_steps > M)) {                      // :521
+        float T = 1.0f, t = 0.0f;
+        for (uint32_t base = 0; base < num_steps; base += 64) {
+            const uint32_t k = base + lane;
+            bool valid = k < num_steps;
+            float alpha = 0.f, d1 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (valid) {
+                const size_t i = (size_t)offset + k;
+                alpha = 1.0f - __expf(-sigmas[i] * deltas[2 * i]);
+                d1 = deltas[2 * i + 1];
+                c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+            }
+            const float incl = wave_scan_mul(1.0f - alpha, lane);           // prod_{j<=k} within the pass
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T_post = T * incl;
+            const unsigned long long stop = __ballot(valid && T_post < T_thresh);   // :557 (sample included)
+            bool done = false;
+            if (stop) { const int last = __builtin_ctzll(stop); valid = valid && lane <= last; done = true; }
+            const float w = valid ? alpha * (T * excl) : 0.0f;
+            const float tk = t + wave_scan_add(d1, lane);
+            r += wave_sum(w * c0); g += wave_sum(w * c1); b += wave_sum(w * c2);
+            d += wave_sum(w * tk); ws += wave_sum(w);
+            if (done) break;
+            T *= __shfl(incl, 63, 64);
+            t = __shfl(tk, 63, 64);
+        }
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    }
+}
+
+__global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
+    const float* __restrict__ grad_ws, const float* __restrict__ grad_image, const float* __restrict__ sigmas,
+    const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+    const float* __restrict__ weights_sum, const float* __restrict__ image, uint32_t M, uint32_t N, float T_thresh,
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
+    const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;                   // :624
     const float gws = grad_ws[index];
     const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
     const float rf = image[3 * (size_t)index], gf = image[3 * (size_t)index + 1], bf = image[3 * (size_t)index + 2];
-    const float wsf = weights_sum[index];
-    const float* s = sigmas + offset;
-    const float* c = rgbs + 3 * (size_t)offset;
-    const float* dl = deltas + 2 * (size_t)offset;
-    float* gs = grad_sigmas + offset;
-    float* gc = grad_rgbs + 3 * (size_t)offset;
+    const float tail = gws * (1 - weights_sum[index]);
     float T = 1.0f, r = 0, g = 0, b = 0;
-    for (uint32_t k = 0; k < num_steps; k++) {
-        const float alpha = 1.0f - __expf(-s[k] * dl[2 * k]);
-        const float w = alpha * T;
-        const float c0 = c[3 * k], c1 = c[3 * k + 1], c2 = c[3 * k + 2];
-        r = fmaf(w, c0, r); g = fmaf(w, c1, g); b = fmaf(w, c2, b);
-        T *= 1.0f - alpha;
-        gc[3 * k] = g0 * w; gc[3 * k + 1] = g1 * w; gc[3 * k + 2] = g2 * w;
-        gs[k] = dl[2 * k] * (g0 * (T * c0 - (rf - r)) + g1 * (T * c1 - (gf - g)) + g2 * (T * c2 - (bf - b)) +
-                             gws * (1 - wsf));
-        if (T < T_thresh) break;
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t k = base + lane;
+        bool valid = k < num_steps;
+        const size_t i = (size_t)offset + k;
+        float alpha = 0.f, d0 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (valid) {
+            d0 = deltas[2 * i];
+            alpha = 1.0f - __expf(-sigmas[i] * d0);
+            c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+        }
+        const float incl = wave_scan_mul(1.0f - alpha, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T_post = T * incl;
+        const unsigned long long stop = __ballot(valid && T_post < T_thresh);
+        bool done = false;
+        if (stop) { const int last = __builtin_ctzll(stop); valid = valid && lane <= last; done = true; }
+        const float w = valid ? alpha * (T * excl) : 0.0f;
+        const float rk = r + wave_scan_add(w * c0, lane);                   // running sums INCLUDING this sample
+        const float gk = g + wave_scan_add(w * c1, lane);
+        const float bk = b + wave_scan_add(w * c2, lane);
+        if (valid) {
+            grad_rgbs[3 * i] = g0 * w; grad_rgbs[3 * i + 1] = g1 * w; grad_rgbs[3 * i + 2] = g2 * w;      // :657-659
+            grad_sigmas[i] = d0 * (g0 * (T_post * c0 - (rf - rk)) + g1 * (T_post * c1 - (gf - gk)) +
+                                   g2 * (T_post * c2 - (bf - bk)) + tail);                                // :662-667
+        }
+        if (done) break;
+        T *= __shfl(incl, 63, 64);
+        r = __shfl(rk, 63, 64); g = __shfl(gk, 63, 64); b = __shfl(bk, 63, 64);
     }
 }
 
@@ -589,8 +641,8 @@ int lae_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
     if (N == 0) return LAE_OK;
     if (!rays || !weights_sum || !depth || !image) return LAE_ENULL;
     if (M > 0 && (!sigmas || !rgbs || !deltas)) return LAE_ENULL;
-    k_composite_train_fwd<<<lae::cdiv(N, 64), 64, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh,
-                                                                        weights_sum, depth, image);
+    k_composite_train_fwd<<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N,
+                                                                                        T_thresh, weights_sum, depth, image);
     return lae::check_launch("composite_rays_train_forward");
 }
 
@@ -602,9 +654,9 @@ int lae_composite_rays_train_backward(const float* grad_weights_sum, const float
     if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image ||
         !grad_sigmas || !grad_rgbs)
         return LAE_ENULL;
-    k_composite_train_bwd<<<lae::cdiv(N, 64), 64, 0, STREAM(stream)>>>(grad_weights_sum, grad_image, sigmas, rgbs,
-                                                                        deltas, rays, weights_sum, image, M, N,
-                                                                        T_thresh, grad_sigmas, grad_rgbs);
+    k_composite_train_bwd<<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
+        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
+        grad_rgbs);
     return lae::check_launch("composite_rays_train_backward");
 }
 
