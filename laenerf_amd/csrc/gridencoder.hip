@@ -35,6 +35,7 @@ struct LevelInfo {
     uint32_t stride[D];      // dense strides of the dims that fit (gridencoder.cu:72-75)
     uint32_t ndense;         // how many dims the dense loop consumed
     bool use_hash, pow2;
+    bool nowrap;             // dense index provably < hashmap_size (all dims indexed and (res+1)^D <= size): no modulo needed
 };
 
 template <int D>
@@ -57,6 +58,7 @@ __device__ __forceinline__ LevelInfo<D> level_info(const LevelScales& sc, const 
         }
     }
     li.use_hash = (gridtype == 0) && (stride > li.hashmap_size);
+    li.nowrap = (li.ndense == (uint32_t)D) && (stride <= li.hashmap_size);
     li.pow2 = (li.hashmap_size & (li.hashmap_size - 1)) == 0;
     return li;
 }
@@ -223,13 +225,19 @@ template <typename T, int D, int C>
 __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     const T* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
     T* __restrict__ grad_grid, uint32_t B, uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners,
-    uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t gs_b, uint64_t gs_l) {
+    uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t gs_b, uint64_t gs_l, bool only_unbinned) {
     uint32_t level, chunk;
     block_to_level_chunk(nb, xcd_mode, level, chunk);
     if (level >= L) return;
     const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
     if (b >= B) return;
     const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
+    if (only_unbinned) {      // companion of the binned fast path: only hashed levels with more partitions than the bucket tables hold
+        constexpr uint32_t SH = sizeof(T) == 2 ? 13 : 14;
+        const uint32_t P_ = (li.hashmap_size + (1u << SH) - 1) >> SH;
+        const uint32_t SUB_ = P_ >= 16u ? 1u : (16u + P_ - 1) / P_;
+        if (P_ * SUB_ <= 256u) return;
+    }
     T* __restrict__ tab = grad_grid + (size_t)li.table_off * C;
 
     float frac[D];
@@ -290,7 +298,6 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
 //                  are combined with contiguous (full-rate) global atomics.
 // grads come in [L][B][2] (the reference's layout); the [B, L*2] variant is transposed into a workspace first.
 constexpr int LB_THREADS = 1024;
-constexpr uint32_t LB_DENSE_WGS = 16;     // target workgroups per dense level
 
 template <typename T>
 __device__ __forceinline__ void lds_acc_add(uint32_t* acc, uint32_t e, float v0, float v1) {
@@ -304,160 +311,343 @@ __device__ __forceinline__ void lds_acc_add(uint32_t* acc, uint32_t e, float v0,
     }
 }
 
+// per-sample cell data shared by both modes
+struct CellF { float frac[3]; uint32_t pg[3]; float g0, g1; bool ok; };
+
 template <typename T>
-__global__ __launch_bounds__(LB_THREADS) void k_grid_bwd_lds(
-    const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
-    T* __restrict__ grad_grid, uint32_t B, uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners,
-    uint32_t interp) {
-    constexpr bool HALF = sizeof(T) == 2;
-    constexpr uint32_t SHIFT = HALF ? 15 : 14, PART = 1u << SHIFT;
-    __shared__ uint32_t acc[32768];                     // 128 KiB: half2[32768] or float2[16384]
-    const uint32_t tid = threadIdx.x;
-
-    // work list: item = (level, partition p, slice s); enumerated round-major so that with L % 8 == 0
-    // item id mod 8 == level mod 8 (one XCD per level residue -> its L2 serves that level's samples)
-    uint32_t total = 0, maxcnt = 0;
-    for (uint32_t l = 0; l < L; l++) {
-        const uint32_t hs = (uint32_t)offsets[l + 1] - (uint32_t)offsets[l];
-        const uint32_t P = (hs + PART - 1) >> SHIFT;
-        const LevelInfo<3> li = level_info<3>(sc, offsets, l, gridtype, align_corners);
-        const uint32_t cnt = li.use_hash ? P : P * max(1u, LB_DENSE_WGS / P);
-        total += cnt; maxcnt = max(maxcnt, cnt);
+__device__ __forceinline__ CellF load_cell(const float* __restrict__ inputs, const T* __restrict__ g_lvl, uint32_t b, uint32_t B,
+                                           float scale, bool align_corners, uint32_t interp) {
+    CellF c;
+    c.ok = b < B;
+    const uint32_t bb = c.ok ? b : 0;
+    float xv[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) xv[d] = inputs[(size_t)bb * 3 + d];
+    if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[bb]; c.g0 = (float)gv[0]; c.g1 = (float)gv[1]; }
+    else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[bb]; c.g0 = gv.x; c.g1 = gv.y; }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        c.ok = c.ok && !(xv[d] < 0.0f) && !(xv[d] > 1.0f);
+        float pp = fmaf(xv[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pp);
+        c.pg[d] = (uint32_t)fl;
+        pp -= (float)c.pg[d];
+        if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
+        c.frac[d] = pp;
     }
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
-        // decode item -> (level, q)
-        uint32_t level = 0, q = 0, id = 0;
-        bool found = false;
-        for (uint32_t j = 0; j < maxcnt && !found; j++)
-            for (uint32_t l = 0; l < L; l++) {
-                const uint32_t hs = (uint32_t)offsets[l + 1] - (uint32_t)offsets[l];
-                const uint32_t P = (hs + PART - 1) >> SHIFT;
-                const LevelInfo<3> lj = level_info<3>(sc, offsets, l, gridtype, align_corners);
-                const uint32_t cnt = lj.use_hash ? P : P * max(1u, LB_DENSE_WGS / P);
-                if (j < cnt) {
-                    if (id == item) { level = l; q = j; found = true; break; }
-                    id++;
-                }
-            }
-        const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
-        const uint32_t P = (li.hashmap_size + PART - 1) >> SHIFT;
-        const uint32_t S = li.use_hash ? 1u : max(1u, LB_DENSE_WGS / P);
-        const uint32_t p = q % P, sl = q / P;
-        const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
+    return c;
+}
 
-        for (uint32_t i = tid; i < 32768; i += LB_THREADS) acc[i] = 0;
-        __syncthreads();
+// MI355X grid backward, work-efficient form (D = 3, C = 2).
+//   k_bin<COUNT> : every lane walks BIN_SPT CONSECUTIVE samples of one level (samples of a ray stay in a cell for
+//                  many steps at coarse/mid levels) and sums the 8 corner contributions in registers while the cell is
+//                  unchanged; each finished cell emits ITEMS = {entry offsets e0|e1<<16, value0, value1}:
+//                    hashed level : 4 items, one per (y',z') corner pair (both x corners share a partition because
+//                                   x' < 2^SHIFT, and bucket = hash >> SHIFT depends on (y',z') only)
+//                    dense level  : 8 single-corner items (e1 = NONE)
+//                  COUNT pass: per-bucket item counts (LDS histogram -> one global add per bucket per block).
+//   k_bin_scan   : exclusive scan of the bucket counts -> queue offsets / cursors.
+//   k_bin<FILL>  : same walk, items appended to their bucket's queue (block-local rank from the LDS histogram,
+//                  one global cursor add per bucket per block -> contiguous runs).
+//   k_bin_acc    : one workgroup per bucket: queue -> LDS accumulators -> grad_grid.
+// bucket = (level, partition p of 2^SHIFT entries, sub-bucket): levels with few partitions are split into SUB
+// sub-buckets by block id so that ~16 workgroups share every level.
+// fp16 grads accumulate EXACTLY as 2^-24 fixed point in int64 LDS words (ds_add_u64 ~0.8 cycles / lane-op vs ~3.2 for
+// ds_add_f32 / ds_pk_add_f16 on gfx950, tools/ubench/lds_atomic.hip; every fp16 value is a multiple of 2^-24), so the
+// result is the correctly rounded sum of the fp16 contributions, independent of order.  fp32 grads use ds_add_f32.
+constexpr uint32_t BK_MAX = 256;              // buckets per level in the tables
+constexpr uint32_t BK_TARGET = 16;            // target workgroups per level
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_SPT = 8;                    // consecutive samples per lane
+constexpr uint32_t E_NONE = 0xffffu;
 
+template <typename T> struct HShift { static constexpr uint32_t value = sizeof(T) == 2 ? 13 : 14; };
+template <typename T> struct HItem;
+template <> struct HItem<half_t> { uint32_t e; half2_t v0, v1; uint32_t pad; };            // 16 B
+template <> struct HItem<float> { uint32_t e; float v0x, v0y, v1x, v1y; uint32_t pad; };    // 24 B
+
+struct LevelBins { uint32_t P, SUB; };
+template <typename T>
+__device__ __forceinline__ LevelBins level_bins(const LevelInfo<3>& li) {
+    constexpr uint32_t SHIFT = HShift<T>::value;
+    LevelBins lb;
+    lb.P = (li.hashmap_size + (1u << SHIFT) - 1) >> SHIFT;
+    lb.SUB = lb.P >= BK_TARGET ? 1u : (BK_TARGET + lb.P - 1) / lb.P;
+    return lb;
+}
+
+template <typename T, bool FILL>
+__global__ __launch_bounds__(BIN_THREADS) void k_bin(
+    const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
+    uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t nb,
+    uint32_t* __restrict__ block_counts, const uint32_t* __restrict__ offs, HItem<T>* __restrict__ queue) {
+    constexpr uint32_t SHIFT = HShift<T>::value, PART = 1u << SHIFT;
+    const uint32_t level = blockIdx.x / nb, chunk = blockIdx.x % nb;
+    const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
+    const LevelBins lb = level_bins<T>(li);
+    const uint32_t nbk = lb.P * lb.SUB;
+    if (nbk > BK_MAX) return;                           // handled by the generic atomic kernel
+    __shared__ uint32_t hist[BK_MAX];
+    __shared__ uint32_t base[BK_MAX];
+    const uint32_t tid = threadIdx.x;
+    uint32_t* __restrict__ my_counts = block_counts + ((size_t)level * nb + chunk) * BK_MAX;
+    hist[tid] = 0;                                      // BIN_THREADS == BK_MAX
+    // FILL: queue position of this block's first item per bucket = bucket offset + exclusive count of earlier blocks
+    if (FILL) base[tid] = tid < nbk ? offs[level * BK_MAX + tid] + my_counts[tid] : 0u;
+    __syncthreads();
+    const uint32_t sub = chunk % lb.SUB;
+    const uint32_t pmask = lb.P - 1, emask = min(li.hashmap_size, PART) - 1;
+    const bool nowrap = li.nowrap;
+    const uint32_t b0 = (chunk * BIN_THREADS + tid) * BIN_SPT;
+
+    // ---- pass A: walk the samples, build the merged cells in registers (at most BIN_SPT cells)
+    // per cell: key coords + 16 accumulated values.  Processed twice (rank, then emit) to keep registers small.
+    float xs[BIN_SPT][3]; float g0[BIN_SPT], g1[BIN_SPT];
+    if (b0 + BIN_SPT <= B) {
+        const float4* src = reinterpret_cast<const float4*>(inputs + (size_t)b0 * 3);      // 96 B per lane, 16 B aligned
+        float4 v[BIN_SPT * 3 / 4];
+#pragma unroll
+        for (int i = 0; i < BIN_SPT * 3 / 4; i++) v[i] = src[i];
+        const float* vf = reinterpret_cast<const float*>(v);
+#pragma unroll
+        for (int s_ = 0; s_ < BIN_SPT; s_++) { xs[s_][0] = vf[3 * s_]; xs[s_][1] = vf[3 * s_ + 1]; xs[s_][2] = vf[3 * s_ + 2]; }
+    } else {
+#pragma unroll
+        for (int s_ = 0; s_ < BIN_SPT; s_++) {
+            const uint32_t b = min(b0 + s_, B - 1);
+            xs[s_][0] = inputs[(size_t)b * 3]; xs[s_][1] = inputs[(size_t)b * 3 + 1]; xs[s_][2] = inputs[(size_t)b * 3 + 2];
+        }
+    }
+    const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
+#pragma unroll
+    for (int s_ = 0; s_ < BIN_SPT; s_++) {
+        const uint32_t b = min(b0 + s_, B - 1);
+        if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
+        else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
+    }
+
+    // emit one finished cell: `mode` 0 = count/rank (returns ranks through rk[]), 1 = write items
+    uint32_t cpg[3] = {0, 0, 0};
+    float a0[8], a1[8];
+    auto cell_items = [&](auto&& visit) {
+        // visit(bucket, e, v0a, v0b, v1a, v1b) for every item of the current cell
         if (li.use_hash) {
-            // ---- hashed level: lane per sample, all samples
-            const uint32_t pmask = P - 1;               // hashed levels have power-of-two sizes
-            const uint32_t emask = min(li.hashmap_size, PART) - 1;   // offset inside the partition (levels < 1 partition wrap at T)
-            for (uint32_t b = tid; b < B; b += LB_THREADS) {
-                float frac[3]; uint32_t pg[3]; bool oob = false;
+            const uint32_t hy0 = cpg[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = cpg[2] * 805459861u, hz1 = hz0 + 805459861u;
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const float xv = inputs[(size_t)b * 3 + d];
-                    oob |= (xv < 0.0f) | (xv > 1.0f);
-                    float pp = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
-                    const float fl = floorf(pp);
-                    pg[d] = (uint32_t)fl;
-                    pp -= (float)pg[d];
-                    if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
-                    frac[d] = pp;
-                }
-                if (oob) continue;
-                float g0, g1;
-                if constexpr (HALF) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0 = (float)gv[0]; g1 = (float)gv[1]; }
-                else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0 = gv.x; g1 = gv.y; }
-                const uint32_t hy0 = pg[1] * 2654435761u, hy1 = hy0 + 2654435761u;
-                const uint32_t hz0 = pg[2] * 805459861u, hz1 = hz0 + 805459861u;
-                const float wx0 = 1 - frac[0], wx1 = frac[0];
-#pragma unroll
-                for (int yz = 0; yz < 4; yz++) {
-                    const uint32_t h = ((yz & 1) ? hy1 : hy0) ^ ((yz & 2) ? hz1 : hz0);
-                    if (((h >> SHIFT) & pmask) != p) continue;
-                    const float wy = (yz & 1) ? frac[1] : 1 - frac[1];
-                    const float wz = (yz & 2) ? frac[2] : 1 - frac[2];
-                    const float w0 = (wx0 * wy) * wz, w1 = (wx1 * wy) * wz;
-                    lds_acc_add<T>(acc, (pg[0] ^ h) & emask, w0 * g0, w0 * g1);
-                    lds_acc_add<T>(acc, ((pg[0] + 1) ^ h) & emask, w1 * g0, w1 * g1);
-                }
+            for (int yz = 0; yz < 4; yz++) {
+                const uint32_t h = ((yz & 1) ? hy1 : hy0) ^ ((yz & 2) ? hz1 : hz0);
+                const uint32_t bk = ((h >> SHIFT) & pmask) * lb.SUB + sub;
+                const uint32_t e = ((cpg[0] ^ h) & emask) | ((((cpg[0] + 1) ^ h) & emask) << 16);
+                visit(yz, bk, e, a0[2 * yz], a1[2 * yz], a0[2 * yz + 1], a1[2 * yz + 1]);
             }
         } else {
-            // ---- dense / tiled level: lane-serial runs over this slice
-            const uint32_t slice = (B + S - 1) / S;
-            const uint32_t b_begin = min(B, sl * slice), b_end = min(B, b_begin + slice);
-            const uint32_t K = (b_end - b_begin + LB_THREADS - 1) / LB_THREADS;
-            const uint32_t b0 = min(b_end, b_begin + tid * K), b1 = min(b_end, b0 + K);
-            uint32_t off[8];
+            const uint32_t key = cpg[0] * li.stride[0] + cpg[1] * li.stride[1] + cpg[2] * li.stride[2];
 #pragma unroll
-            for (int c = 0; c < 8; c++)
-                off[c] = ((c & 1) ? li.stride[0] : 0u) + ((c & 2) ? li.stride[1] : 0u) + ((c & 4) ? li.stride[2] : 0u);
-            float a0[8], a1[8];
+            for (int c = 0; c < 8; c++) {
+                uint32_t idx = key + ((c & 1) ? li.stride[0] : 0u) + ((c & 2) ? li.stride[1] : 0u) + ((c & 4) ? li.stride[2] : 0u);
+                if (!nowrap) idx = li.pow2 ? (idx & (li.hashmap_size - 1)) : (idx % li.hashmap_size);
+                const uint32_t bk = (idx >> SHIFT) * lb.SUB + sub;
+                // corner order c = x + 2y + 4z; accumulators are stored pair-major: slot = 2*(c>>1) + (c&1)
+                visit(c, bk, (idx & (PART - 1)) | (E_NONE << 16), a0[c], a1[c], 0.0f, 0.0f);
+            }
+        }
+    };
+
+    // one sweep over the lane's samples.  COUNT: histogram only.  FILL: slot = LDS fill counter (any unique slot in
+    // the block's reserved range is fine; the accumulation is order independent for fp16, see k_bin_acc).
+    {
+        bool have = false;
+#pragma unroll
+        for (int c = 0; c < 8; c++) { a0[c] = 0; a1[c] = 0; }
+        auto finish = [&]() {
+            if (!FILL) {
+                cell_items([&](int, uint32_t bk, uint32_t, float, float, float, float) { atomicAdd(&hist[bk], 1u); });
+            } else {
+                cell_items([&](int, uint32_t bk, uint32_t e, float va, float vb, float vc, float vd) {
+                    HItem<T> it;
+                    it.e = e; it.pad = 0;
+                    if constexpr (sizeof(T) == 2) { it.v0 = half2_t{(half_t)va, (half_t)vb}; it.v1 = half2_t{(half_t)vc, (half_t)vd}; }
+                    else { it.v0x = va; it.v0y = vb; it.v1x = vc; it.v1y = vd; }
+                    queue[(size_t)base[bk] + atomicAdd(&hist[bk], 1u)] = it;
+                });
+            }
 #pragma unroll
             for (int c = 0; c < 8; c++) { a0[c] = 0; a1[c] = 0; }
-            uint32_t cur = 0; bool have = false;
-            auto flush = [&]() {
+        };
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    uint32_t idx = cur + off[c];
-                    idx = li.pow2 ? (idx & (li.hashmap_size - 1)) : (idx % li.hashmap_size);
-                    if ((idx >> SHIFT) == p) lds_acc_add<T>(acc, idx & (PART - 1), a0[c], a1[c]);
-                    a0[c] = 0; a1[c] = 0;
-                }
-            };
-            for (uint32_t b = b0; b < b1; b++) {
-                float frac[3]; uint32_t pg[3]; bool oob = false;
+        for (int s_ = 0; s_ < BIN_SPT; s_++) {
+            if (b0 + s_ >= B) break;
+            float frac[3]; uint32_t pg[3]; bool ok = true;
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const float xv = inputs[(size_t)b * 3 + d];
-                    oob |= (xv < 0.0f) | (xv > 1.0f);
-                    float pp = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
-                    const float fl = floorf(pp);
-                    pg[d] = (uint32_t)fl;
-                    pp -= (float)pg[d];
-                    if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
-                    frac[d] = pp;
-                }
-                if (oob) continue;
-                float g0, g1;
-                if constexpr (HALF) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0 = (float)gv[0]; g1 = (float)gv[1]; }
-                else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0 = gv.x; g1 = gv.y; }
-                const uint32_t key = pg[0] * li.stride[0] + pg[1] * li.stride[1] + pg[2] * li.stride[2];
-                if (!have || key != cur) { if (have) flush(); cur = key; have = true; }
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float w = (((c & 1) ? frac[0] : 1 - frac[0]) * ((c & 2) ? frac[1] : 1 - frac[1])) * ((c & 4) ? frac[2] : 1 - frac[2]);
-                    a0[c] = fmaf(w, g0, a0[c]); a1[c] = fmaf(w, g1, a1[c]);
-                }
+            for (int d = 0; d < 3; d++) {
+                const float xv = xs[s_][d];
+                ok = ok && !(xv < 0.0f) && !(xv > 1.0f);
+                float pp = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
+                const float fl = floorf(pp);
+                pg[d] = (uint32_t)fl;
+                pp -= (float)pg[d];
+                if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
+                frac[d] = pp;
             }
-            if (have) flush();
+            if (!ok) continue;
+            if (!have || pg[0] != cpg[0] || pg[1] != cpg[1] || pg[2] != cpg[2]) {
+                if (have) finish();
+                cpg[0] = pg[0]; cpg[1] = pg[1]; cpg[2] = pg[2]; have = true;
+            }
+            // slot c = x + 2y + 4z = x + 2*yz: the same numbering serves the pair items (hashed) and corner items (dense)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float w = (((c & 1) ? frac[0] : 1 - frac[0]) * ((c & 2) ? frac[1] : 1 - frac[1])) * ((c & 4) ? frac[2] : 1 - frac[2]);
+                a0[c] = fmaf(w, g0[s_], a0[c]); a1[c] = fmaf(w, g1[s_], a1[c]);
+            }
         }
+        if (have) finish();
+    }
+    if (!FILL) {
         __syncthreads();
+        my_counts[tid] = hist[tid];                     // coalesced; zeros included (the scan reads every slot)
+    }
+}
 
-        // ---- add the partition to grad_grid
+// per bucket: exclusive scan over the blocks' counts (in place) and bucket total.  One wavefront per (level, bucket).
+__global__ __launch_bounds__(256) void k_bin_scan_blocks(uint32_t* __restrict__ block_counts, uint32_t* __restrict__ counts,
+                                                          uint32_t L, uint32_t nb) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= L * BK_MAX) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t level = t / BK_MAX, bk = t % BK_MAX;
+    uint32_t* p = block_counts + (size_t)level * nb * BK_MAX + bk;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < nb ? p[(size_t)c * BK_MAX] : 0u;
+        const uint32_t inc = lae::wave_incl_scan(v);
+        if (c < nb) p[(size_t)c * BK_MAX] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) counts[t] = carry;
+}
+
+// bucket totals -> exclusive offsets (global item index).  One small block.
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t n) {
+    __shared__ uint32_t lds[17];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? counts[i] : 0;
+        uint32_t total;
+        const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
+        if (i < n) offs[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// fp16 bits -> value * 2^24 as a signed integer (exact: fp16 values are multiples of 2^-24, |v| * 2^24 < 2^40)
+__device__ __forceinline__ long long half_to_fix24(half_t v) {
+    const uint32_t u = (uint32_t)__builtin_bit_cast(uint16_t, v);
+    const uint32_t e = (u >> 10) & 31u, m = u & 1023u;
+    const unsigned long long mag = e ? ((unsigned long long)(m | 1024u) << (e - 1)) : (unsigned long long)m;
+    return (u & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+
+template <typename T>
+__global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
+    const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
+    bool align_corners, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
+    const HItem<T>* __restrict__ queue) {
+    constexpr bool HALF = sizeof(T) == 2;
+    constexpr uint32_t SHIFT = HShift<T>::value, PART = 1u << SHIFT;
+    __shared__ unsigned long long acc64[16384];         // 128 KiB: int64[8192][2] (fp16 grads) or float2[16384]
+    const uint32_t tid = threadIdx.x;
+    // bucket list, level-major; per-level bucket counts computed ONCE into LDS (decoding must not walk offsets[]
+    // with dependent global loads: that serial walk cost ~300 us in an earlier version)
+    __shared__ uint32_t s_cnt[MAX_LEVELS], s_sub[MAX_LEVELS];
+    if (tid < L) {
+        const LevelBins lb = level_bins<T>(level_info<3>(sc, offsets, tid, gridtype, align_corners));
+        const uint32_t nbk = lb.P * lb.SUB;
+        s_cnt[tid] = nbk <= BK_MAX ? nbk : 0u;
+        s_sub[tid] = lb.SUB;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t l = 0; l < L; l++) total += s_cnt[l];
+    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+        uint32_t level = 0, bk = item;
+        while (bk >= s_cnt[level]) { bk -= s_cnt[level]; level++; }
+        const uint32_t SUB = s_sub[level], p = bk / SUB;
+        const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
+        const uint32_t n = counts[level * BK_MAX + bk];
+        if (n == 0) continue;                               // uniform per block
+        for (uint32_t i = tid; i < 16384; i += LB_THREADS) acc64[i] = 0ull;
+        __syncthreads();
+        const HItem<T>* __restrict__ q = queue + offs[level * BK_MAX + bk];
+        auto apply = [&](const HItem<T>& it) {
+            const uint32_t e0 = it.e & 0xffffu, e1 = it.e >> 16;
+            if constexpr (HALF) {
+                atomicAdd(&acc64[2 * e0], (unsigned long long)half_to_fix24(it.v0[0]));
+                atomicAdd(&acc64[2 * e0 + 1], (unsigned long long)half_to_fix24(it.v0[1]));
+                if (e1 != E_NONE) {
+                    atomicAdd(&acc64[2 * e1], (unsigned long long)half_to_fix24(it.v1[0]));
+                    atomicAdd(&acc64[2 * e1 + 1], (unsigned long long)half_to_fix24(it.v1[1]));
+                }
+            } else {
+                float* af = reinterpret_cast<float*>(acc64);
+                atomicAdd(af + 2 * e0, it.v0x); atomicAdd(af + 2 * e0 + 1, it.v0y);
+                if (e1 != E_NONE) { atomicAdd(af + 2 * e1, it.v1x); atomicAdd(af + 2 * e1 + 1, it.v1y); }
+            }
+        };
+        // four queue loads in flight per lane before the first LDS atomic (the loop is latency bound otherwise)
+        uint32_t i = tid;
+        for (; i + 3 * LB_THREADS < n; i += 4 * LB_THREADS) {
+            const HItem<T> i0 = q[i], i1 = q[i + LB_THREADS], i2 = q[i + 2 * LB_THREADS], i3 = q[i + 3 * LB_THREADS];
+            apply(i0); apply(i1); apply(i2); apply(i3);
+        }
+        for (; i < n; i += LB_THREADS) apply(q[i]);
+        __syncthreads();
         const uint32_t part_lo = p << SHIFT;
         const uint32_t n_ent = min(PART, li.hashmap_size - part_lo);
         T* __restrict__ dst = grad_grid + ((size_t)li.table_off + part_lo) * 2;
         if constexpr (HALF) {
             half2_t* d2 = reinterpret_cast<half2_t*>(dst);
-            const half2_t* a2 = reinterpret_cast<const half2_t*>(acc);
             for (uint32_t e = tid; e < n_ent; e += LB_THREADS) {
-                const half2_t v = a2[e];
-                if (S == 1) { const half2_t o = d2[e]; d2[e] = half2_t{(half_t)((float)o[0] + (float)v[0]), (half_t)((float)o[1] + (float)v[1])}; }
-                else if ((float)v[0] != 0.0f || (float)v[1] != 0.0f)
-                    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(d2 + e), v);
+                const long long i0 = (long long)acc64[2 * e], i1 = (long long)acc64[2 * e + 1];
+                const float s0 = (float)i0 * 5.9604644775390625e-08f, s1 = (float)i1 * 5.9604644775390625e-08f;   // * 2^-24
+                if (SUB == 1) {      // only writer of this table slice: plain coalesced read-modify-write
+                    const half2_t o = d2[e];
+                    d2[e] = half2_t{(half_t)((float)o[0] + s0), (half_t)((float)o[1] + s1)};
+                } else if (i0 != 0 || i1 != 0) {
+                    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(d2 + e), half2_t{(half_t)s0, (half_t)s1});
+                }
             }
         } else {
-            const float* af = reinterpret_cast<const float*>(acc);
+            const float* af = reinterpret_cast<const float*>(acc64);
             for (uint32_t e = tid; e < 2 * n_ent; e += LB_THREADS) {
                 const float v = af[e];
-                if (S == 1) dst[e] += v;
-                else if (v != 0.0f) atomicAdd(dst + e, v);
+                if (SUB == 1) dst[e] += v; else if (v != 0.0f) atomicAdd(dst + e, v);
             }
         }
         __syncthreads();
     }
+}
+
+// [L][B][2] -> [B][L][2] through an LDS tile: the gather kernel writes level-major (each level's block stores 256
+// consecutive pairs = full lines); storing 4 B per lane at a 64 B stride straight into [B, L*2] measured 123 MB of
+// HBM writes for 16 MB of output (profiles/r1_pmc_fetch_write_per_kernel.csv).
+template <typename T>
+__global__ __launch_bounds__(256) void k_out_transpose(const T* __restrict__ in, T* __restrict__ out, uint32_t B, uint32_t L) {
+    using V = typename std::conditional<sizeof(T) == 2, uint32_t, uint2>::type;
+    __shared__ V tile[256 * 33];
+    const uint32_t b0 = blockIdx.x * 256;
+    const uint32_t nb = min(256u, B - b0);
+    const V* src = reinterpret_cast<const V*>(in);
+    for (uint32_t e = threadIdx.x; e < nb * L; e += 256) {
+        const uint32_t l = e / nb, b = e % nb;
+        tile[b * (L + 1) + l] = src[(size_t)l * B + b0 + b];
+    }
+    __syncthreads();
+    V* dstv = reinterpret_cast<V*>(out) + (size_t)b0 * L;
+    for (uint32_t e = threadIdx.x; e < nb * L; e += 256) dstv[e] = tile[(e / L) * (L + 1) + (e % L)];
 }
 
 // [B][L][2] -> [L][B][2] through an LDS tile (256 samples x L levels), coalesced on both sides
@@ -597,7 +787,7 @@ static void launch_bwd(const BwdArgs& a) {
     const bool xcd = (a.L % 8) == 0;
     k_grid_bwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.grad ? (const T*)a.grad : nullptr, a.inputs, a.offsets,
                                                                 (T*)a.gemb, a.B, a.L, a.sc, a.gridtype, a.align,
-                                                                a.interp, nb, xcd, a.gs_b, a.gs_l);
+                                                                a.interp, nb, xcd, a.gs_b, a.gs_l, false);
 }
 template <typename T, int D>
 static int dispatch_bwd_c(const BwdArgs& a, uint32_t C) {
@@ -640,14 +830,60 @@ static int grid_forward(const float* inputs, const void* embeddings, const int32
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
     a.dy_dx = dy_dx; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
-    a.os_b = blc ? (uint64_t)L * C : C;
-    a.os_l = blc ? C : (uint64_t)B * C;
     a.stream = reinterpret_cast<hipStream_t>(stream);
+    if (dtype != LAE_F32 && dtype != LAE_F16) return LAE_EINVAL;
+    // [B, L*C] output with C == 2: gather level-major into the workspace, then one tiled transpose
+    const bool staged = blc && C == 2 && L <= 32;
+    void* lbc = nullptr;
+    if (staged) {
+        lbc = lae::workspace(lae::WS_GRID_OUT_T, (size_t)B * L * C * (dtype == LAE_F16 ? 2 : 4));
+        if (!lbc) return LAE_ELAUNCH;
+        a.out = lbc;
+    }
+    const bool level_major = !blc || staged;
+    a.os_b = level_major ? C : (uint64_t)L * C;
+    a.os_l = level_major ? (uint64_t)B * C : C;
     if (dtype == LAE_F32) rc = dispatch_fwd_d<float>(a, D, C);
-    else if (dtype == LAE_F16) rc = dispatch_fwd_d<half_t>(a, D, C);
-    else rc = LAE_EINVAL;
+    else rc = dispatch_fwd_d<half_t>(a, D, C);
     if (rc) return rc;
+    if (staged) {
+        if (dtype == LAE_F16) k_out_transpose<half_t><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const half_t*)lbc, (half_t*)outputs, B, L);
+        else k_out_transpose<float><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const float*)lbc, (float*)outputs, B, L);
+    }
     return lae::check_launch("grid_encode_forward");
+}
+
+template <typename T>
+static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L,
+                           const BwdArgs& a) {
+    const T* g = (const T*)gT;
+    T* ge = (T*)gemb;
+    // count -> scans -> fill -> accumulate.  Worst case 8 items per (sample, level).
+    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
+    const size_t n_tab = (size_t)L * BK_MAX;
+    const size_t tab_bytes = ((2 * n_tab * 4 + 255) / 256) * 256;
+    const size_t blk_bytes = (((size_t)nb * n_tab * 4 + 255) / 256) * 256;
+    const size_t q_bytes = (size_t)B * 8 * L * sizeof(HItem<T>);
+    uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, tab_bytes + blk_bytes + q_bytes));
+    if (!ws) return LAE_ELAUNCH;
+    uint32_t* counts = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* offs = counts + n_tab;
+    uint32_t* block_counts = reinterpret_cast<uint32_t*>(ws + tab_bytes);
+    HItem<T>* queue = reinterpret_cast<HItem<T>*>(ws + tab_bytes + blk_bytes);
+    k_bin<T, false><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
+                                                        block_counts, offs, queue);
+    k_bin_scan_blocks<<<lae::cdiv(n_tab, 4), 256, 0, a.stream>>>(block_counts, counts, L, nb);
+    k_bin_scan<<<1, 1024, 0, a.stream>>>(counts, offs, (uint32_t)n_tab);
+    k_bin<T, true><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
+                                                       block_counts, offs, queue);
+    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, counts, offs, queue);
+    // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel, exits at once otherwise
+    {
+        const uint32_t nbg = lae::cdiv(B, GRID_BLOCK);
+        k_grid_bwd<T, 3, 2><<<nbg * L, GRID_BLOCK, 0, a.stream>>>(g, inputs, offsets, ge, B, L, a.sc, a.gridtype, a.align, a.interp, nbg,
+                                                                  (L % 8) == 0, 2, (uint64_t)B * 2, true);
+    }
+    return LAE_OK;
 }
 
 // test hook: force the generic global-atomic kernel (env LAE_GRID_BWD_ATOMIC=1)
@@ -681,13 +917,9 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
             else k_grad_transpose<float><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const float*)grad, (float*)ws, B, L);
             gT = ws;
         }
-        const uint32_t nwg = (uint32_t)lae::num_cus();
-        if (dtype == LAE_F16)
-            k_grid_bwd_lds<half_t><<<nwg, LB_THREADS, 0, a.stream>>>((const half_t*)gT, inputs, offsets, (half_t*)grad_embeddings, B, L,
-                                                                     a.sc, gridtype, a.align, interp);
-        else
-            k_grid_bwd_lds<float><<<nwg, LB_THREADS, 0, a.stream>>>((const float*)gT, inputs, offsets, (float*)grad_embeddings, B, L,
-                                                                   a.sc, gridtype, a.align, interp);
+        rc = (dtype == LAE_F16) ? launch_bwd_fast<half_t>(gT, inputs, offsets, grad_embeddings, B, L, a)
+                                : launch_bwd_fast<float>(gT, inputs, offsets, grad_embeddings, B, L, a);
+        if (rc) return rc;
         rc = LAE_OK;
     } else if (dtype == LAE_F32) rc = dispatch_bwd_d<float>(a, D, C);
     else rc = dispatch_bwd_d<half_t>(a, D, C);

@@ -10,8 +10,8 @@ void set_last_error(const char* what, hipError_t e) {
 }
 
 static std::mutex g_ws_mutex;
-static void* g_ws[WS_SLOTS] = {nullptr, nullptr};
-static size_t g_ws_bytes[WS_SLOTS] = {0, 0};
+static void* g_ws[WS_SLOTS] = {};
+static size_t g_ws_bytes[WS_SLOTS] = {};
 
 void* workspace(WsSlot slot, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mutex);

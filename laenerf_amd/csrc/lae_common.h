@@ -13,7 +13,7 @@ void set_last_error(const char* what, hipError_t e);
 // Library-owned, grow-only device workspaces (the counterpart of the reference's process-global split-K
 // streams + CUTLASS workspace, ffmlp.cu:711-740, cutlass_matmul.h:335-352).  Returns nullptr on failure
 // (error string set).  Growing synchronises the device once; steady state is allocation free.
-enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_SLOTS = 2 };
+enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_GRID_OUT_T = 2, WS_GRID_BINS = 3, WS_SLOTS = 4 };
 void* workspace(WsSlot slot, size_t bytes);
 void free_workspaces();
 int num_cus();
