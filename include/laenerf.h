@@ -238,6 +238,11 @@ LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void*
                        void* backward_buffer, void* grad_inputs, void* grad_weights,
                        void* stream);
 
+/* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
+ * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the
+ * three-kernel path that fills both buffers exactly like the reference. */
+LAE_API int lae_ffmlp_set_mode(int mode);
+
 /* ffmlp.cu:721-740: the reference keeps process-global side streams for its
  * split-K CUTLASS GEMMs.  The MFMA backward reduces dW inside one stream, so
  * these are accepted and ignored (kept so FFMLP.__init__ runs unmodified). */

@@ -230,7 +230,7 @@ class _FFMLP:
     def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                       forward_buffer, outputs):
         need_cuda(inputs, weights, forward_buffer, outputs); need_contig(inputs, weights, forward_buffer, outputs)
-        _FFMLP._half(inputs, weights, forward_buffer, outputs)
+        _FFMLP._half(inputs, weights, forward_buffer, outputs)      # forward_buffer may be None: activations not saved
         check(_lib.load().lae_ffmlp_forward(ptr(inputs), ptr(weights), B, input_dim, output_dim, hidden_dim, num_layers,
                                             activation, output_activation, ptr(forward_buffer), ptr(outputs), stream()),
               "ffmlp_forward")
@@ -253,6 +253,15 @@ class _FFMLP:
                                              output_dim, hidden_dim, num_layers, activation, output_activation,
                                              int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
                                              ptr(grad_weights), stream()), "ffmlp_backward")
+
+    @staticmethod
+    def ffmlp_set_mode(mode):
+        """0 = fused backward (default), 1 = buffer-faithful three-kernel backward (fills forward/backward buffers)"""
+        check(_lib.load().lae_ffmlp_set_mode(int(mode)), "ffmlp_set_mode")
+
+    @staticmethod
+    def fused_backward_available(input_dim, hidden_dim, num_layers, activation):
+        return hidden_dim == 64 and activation == 0 and num_layers in (2, 3) and input_dim in (32, 48, 64)
 
     @staticmethod
     def allocate_splitk(size):

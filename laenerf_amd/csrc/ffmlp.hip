@@ -14,6 +14,7 @@
 // is bit-for-bit the B fragment of K-step t of the next layer, so activations
 // chain through all layers in registers: no LDS, no shuffles.  Accumulation is
 // fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
+#include <algorithm>
 #include "lae_common.h"
 
 namespace {
@@ -349,6 +350,290 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ sla
     if (sg == 0 && i < nW) gw[i] = (half_t)((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
 }
 
+// ---------------------------------------------------------------- fused backward (WIDTH = 64, ReLU)
+// One kernel for everything the reference does in kernel_mlp_fused_backward + (num_layers+1) split-K CUTLASS
+// GEMMs (ffmlp.cu:410-518, 800-877), WITHOUT the forward/backward buffers: the hidden activations are
+// recomputed from the 64-byte input row (cheap on the matrix cores; the buffers cost ~3.5 KB/sample of HBM
+// traffic), dL/dH is chained through the layers in registers exactly like k_mlp_bwd, and every wave accumulates
+// its own dW = dY^T A for all weight tiles over its 16-row tiles:
+//   * the dY / A tiles are written row-major into a WAVE-PRIVATE LDS region with ds_write_b64 straight from the
+//     MFMA C/D layout and read back transposed with ds_read_b64_tr_b16 -- that IS the A / B operand layout for a
+//     product that sums over the batch (lane) index; no barrier, waves never share tiles;
+//   * weights live row-major in LDS (padded rows): forward fragments are plain ds_read_b64, the transposed
+//     fragments of the backward chain are ds_read_b64_tr_b16 of the same image;
+//   * the 4 waves' dW accumulators are summed through LDS once at the end (fixed order) and stored as one fp32
+//     slab per workgroup; k_dw_reduce adds the slabs in order -> deterministic gradients.
+typedef __fp16 hraw4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h4 lds_tr_read(const half_t* p) {
+    const hraw4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hraw4*)(p));
+    return __builtin_bit_cast(h4, r);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int IN, int NH>
+struct FusedCfg {
+    static constexpr int KT0 = IN / 16;                    // k-steps of the input layer
+    static constexpr int LDX = IN + 8;                     // padded LDS row strides (halves); multiples of 4 -> 8-byte rows
+    static constexpr int LDH = 72;
+    static constexpr int LDG = 24;
+    // weight image (halves)
+    static constexpr int W0_OFF = 0;
+    static constexpr int WH_OFF = 64 * LDX;
+    static constexpr int WO_OFF = WH_OFF + NH * 64 * LDH;
+    static constexpr int W_HALVES = WO_OFF + 16 * LDH;
+    // per-wave tile region: X | H[0..NH] | D (one tile, reused per layer) | G
+    static constexpr int X_OFF = 0;
+    static constexpr int H_OFF = 16 * LDX;
+    static constexpr int D_OFF = H_OFF + (NH + 1) * 16 * LDH;
+    static constexpr int G_OFF = D_OFF + 16 * LDH;
+    static constexpr int WAVE_HALVES = G_OFF + 16 * LDG;
+    static constexpr int N_TILES = 4 * KT0 + NH * 16 + 4; // 16x16 dW tiles: W0 | hidden | Wout
+    static constexpr int LDS_HALVES = W_HALVES + 4 * WAVE_HALVES;
+};
+
+template <int IN, int NH>
+__global__ __launch_bounds__(256) void k_mlp_bwd_fused(
+    const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
+    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW) {
+    using C = FusedCfg<IN, NH>;
+    constexpr int KT0 = C::KT0;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* Wl = lds;                                          // weight image
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    half_t* T = lds + C::W_HALVES + w * C::WAVE_HALVES;        // this wave's tiles
+    // transposed-read lane address inside a [16 x ld] tile: group g reads rows 4g..4g+3, lane i=4q+p supplies row q, cols 4p..
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+
+    // ---- stage the weights row-major (padded) once per workgroup
+    for (uint32_t e = threadIdx.x; e < 64u * IN / 4; e += 256) {
+        const uint32_t r = (e * 4) / IN, k = (e * 4) % IN;
+        *reinterpret_cast<h4*>(Wl + C::W0_OFF + r * C::LDX + k) = *reinterpret_cast<const h4*>(W + (size_t)r * IN + k);
+    }
+    for (uint32_t e = threadIdx.x; e < (uint32_t)NH * 64 * 64 / 4; e += 256) {
+        const uint32_t m = (e * 4) / 4096, r = ((e * 4) % 4096) / 64, k = (e * 4) % 64;
+        *reinterpret_cast<h4*>(Wl + C::WH_OFF + (m * 64 + r) * C::LDH + k) =
+            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)m * 4096 + r * 64 + k);
+    }
+    for (uint32_t e = threadIdx.x; e < 16u * 64 / 4; e += 256) {
+        const uint32_t r = (e * 4) / 64, k = (e * 4) % 64;
+        *reinterpret_cast<h4*>(Wl + C::WO_OFF + r * C::LDH + k) =
+            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)NH * 4096 + r * 64 + k);
+    }
+    __syncthreads();
+
+    f4 dW0[4][KT0], dWh[NH][4][4], dWo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < KT0; j++) dW0[i][j] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NH; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) dWh[m][i][j] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) dWo[j] = f4{0, 0, 0, 0};
+
+    const uint32_t wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+    for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
+        const size_t row = (size_t)tile * 16 + c;
+        // ---- inputs: B fragments + X tile
+        h4 xf[KT0];
+#pragma unroll
+        for (int kt = 0; kt < KT0; kt++) {
+            xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+            *reinterpret_cast<h4*>(T + C::X_OFF + c * C::LDX + kt * 16 + 4 * g) = xf[kt];
+        }
+        const h4 gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
+        *reinterpret_cast<h4*>(T + C::G_OFF + c * C::LDG + 4 * g) = gf;
+        // ---- recompute the hidden activations (post-ReLU), keep them in registers and in the H tiles
+        h4 h[NH + 1][4];
+        {
+            f4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < KT0; kt++) {
+                    const h4 a = *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g);
+                    acc[mt] = mfma16(a, xf[kt], acc[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[0][mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
+                *reinterpret_cast<h4*>(T + C::H_OFF + c * C::LDH + mt * 16 + 4 * g) = h[0][mt];
+            }
+#pragma unroll
+            for (int l = 0; l < NH; l++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++) {
+                        const h4 a = *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g);
+                        acc[mt] = mfma16(a, h[l][kt], acc[mt]);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[l + 1][mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
+                    *reinterpret_cast<h4*>(T + C::H_OFF + (l + 1) * 16 * C::LDH + c * C::LDH + mt * 16 + 4 * g) = h[l + 1][mt];
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- output layer: dWout += G^T H_NH ;  dH_NH = (Wout^T G) * relu'
+        {
+            const h4 a = lds_tr_read(T + C::G_OFF + (4 * g + tq) * C::LDG + 4 * tp);                         // A[o][b]
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const h4 b = lds_tr_read(T + C::H_OFF + NH * 16 * C::LDH + (4 * g + tq) * C::LDH + nt * 16 + 4 * tp);   // B[b][i]
+                dWo[nt] = mfma16(a, b, dWo[nt]);
+            }
+        }
+        h4 d[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const h4 a = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);             // A[f][o] = Wout[o][f]
+            const f4 acc = mfma16(a, gf, f4{0, 0, 0, 0});
+#pragma unroll
+            for (int r = 0; r < 4; r++) d[mt][r] = ((float)h[NH][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
+        }
+        // ---- hidden layers, last to first: dW_l += D_l^T H_{l-1} ; dH_{l-1} = (W_l^T dH_l) * relu'
+#pragma unroll
+        for (int l = NH; l >= 1; l--) {
+            wave_lds_fence();                               // previous readers of the D tile are done
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(T + C::D_OFF + c * C::LDH + mt * 16 + 4 * g) = d[mt];
+            wave_lds_fence();
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const h4 a = lds_tr_read(T + C::D_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const h4 b = lds_tr_read(T + C::H_OFF + (l - 1) * 16 * C::LDH + (4 * g + tq) * C::LDH + nt * 16 + 4 * tp);
+                    dWh[l - 1][mt][nt] = mfma16(a, b, dWh[l - 1][mt][nt]);
+                }
+            }
+            h4 dn[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                f4 acc = f4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) {
+                    const h4 a = lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp);   // W_l^T
+                    acc = mfma16(a, d[kt], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) dn[mt][r] = ((float)h[l - 1][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) d[mt] = dn[mt];
+        }
+        // ---- input layer: dW0 += D_0^T X ; dX = W0^T dH_0
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(T + C::D_OFF + c * C::LDH + mt * 16 + 4 * g) = d[mt];
+        wave_lds_fence();
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const h4 a = lds_tr_read(T + C::D_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);
+#pragma unroll
+            for (int nt = 0; nt < KT0; nt++) {
+                const h4 b = lds_tr_read(T + C::X_OFF + (4 * g + tq) * C::LDX + nt * 16 + 4 * tp);
+                dW0[mt][nt] = mfma16(a, b, dW0[mt][nt]);
+            }
+        }
+        if (grad_in) {
+#pragma unroll
+            for (int it = 0; it < KT0; it++) {
+                f4 acc = f4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) {
+                    const h4 a = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp);    // W0^T
+                    acc = mfma16(a, d[kt], acc);
+                }
+                h4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];
+                *reinterpret_cast<h4*>(grad_in + row * IN + it * 16 + 4 * g) = v;
+            }
+        }
+        wave_lds_fence();                                   // tiles are rewritten by the next iteration
+    }
+
+    // ---- sum the 4 waves' dW tiles through LDS in wave order (deterministic), store one slab per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);             // N_TILES * 256 floats (<= 45 KiB), reuses the LDS
+    auto put = [&](int t, const f4& v, bool first) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float* p = red + t * 256 + (4 * g + r) * 16 + c;
+            *p = first ? v[r] : (*p + v[r]);
+        }
+    };
+    for (int ww = 0; ww < 4; ww++) {
+        if (w == ww) {
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < KT0; j++) put(t++, dW0[i][j], ww == 0);
+#pragma unroll
+            for (int m = 0; m < NH; m++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) put(t++, dWh[m][i][j], ww == 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) put(t++, dWo[j], ww == 0);
+        }
+        __syncthreads();
+    }
+    float* slab = slabs + (size_t)blockIdx.x * nW;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)C::N_TILES * 256; e += 256) {
+        const uint32_t t = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
+        size_t idx;
+        if (t < 4u * KT0) idx = (size_t)((t / KT0) * 16 + rr) * IN + (t % KT0) * 16 + cc;
+        else if (t < 4u * KT0 + NH * 16u) {
+            const uint32_t u = t - 4 * KT0, m = u / 16, i = (u % 16) / 4, j = u % 4;
+            idx = (size_t)64 * IN + (size_t)m * 4096 + (i * 16 + rr) * 64 + j * 16 + cc;
+        } else idx = (size_t)64 * IN + (size_t)NH * 4096 + rr * 64 + (t - 4 * KT0 - NH * 16) * 16 + cc;
+        slab[idx] = red[e];
+    }
+}
+
+template <int IN, int NH>
+int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s) {
+    using C = FusedCfg<IN, NH>;
+    const uint32_t nW = 64 * (IN + 64 * NH + 16);
+    const uint32_t n_tiles = B / 16;
+    const size_t lds_bytes = std::max((size_t)C::LDS_HALVES * 2, (size_t)C::N_TILES * 1024);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+        attr_set = true;
+    }
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+    if (!ws) return LAE_ELAUNCH;
+    k_mlp_bwd_fused<IN, NH><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW);
+    k_dw_reduce<<<lae::cdiv(nW, 64), 256, 0, s>>>(ws, blocks, nW, gw);
+    return LAE_OK;
+}
+
+// 0 = fused backward where available (default), 1 = always the buffer-faithful three-kernel path
+int g_ffmlp_mode = 0;
+
 // ---------------------------------------------------------------- host side
 int n_cus() { return lae::num_cus(); }
 
@@ -429,7 +714,7 @@ extern "C" {
 int lae_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                       void* forward_buffer, void* outputs, void* stream) {
-    if (B > 0 && !forward_buffer) return LAE_ENULL;
+    // forward_buffer == NULL is accepted: activations are then not saved (the fused backward recomputes them)
     return forward_any(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                        forward_buffer, outputs, stream);
 }
@@ -448,7 +733,7 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
                        void* grad_inputs, void* grad_weights, void* stream) {
     (void)output_activation;   // the reference ignores it too (ffmlp.cu:781)
     if (B == 0) return LAE_OK;
-    if (!grad || !inputs || !weights || !forward_buffer || !backward_buffer || !grad_weights) return LAE_ENULL;
+    if (!grad || !inputs || !weights || !grad_weights) return LAE_ENULL;
     if (calc_grad_inputs && !grad_inputs) return LAE_ENULL;
     if (!shape_ok(B, input_dim, output_dim, hidden_dim, num_layers) || activation > 6) return LAE_EINVAL;
     const half_t* g = (const half_t*)grad; const half_t* in = (const half_t*)inputs; const half_t* W = (const half_t*)weights;
@@ -457,6 +742,21 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const uint32_t nh = num_layers - 1;
     int rc;
+    // fused path: recomputes the activations, never touches forward_buffer / backward_buffer (both are scratch
+    // that the reference's Python allocates and never reads, ffmlp.py:31-35,71)
+    if (g_ffmlp_mode == 0 && hidden_dim == 64 && activation == LAE_ACT_RELU && (nh == 1 || nh == 2) &&
+        (input_dim == 32 || input_dim == 48 || input_dim == 64)) {
+        rc = LAE_EINVAL;
+        if (nh == 1 && input_dim == 32) rc = launch_bwd_fused<32, 1>(g, in, W, B, gi, gw, s);
+        else if (nh == 2 && input_dim == 32) rc = launch_bwd_fused<32, 2>(g, in, W, B, gi, gw, s);
+        else if (nh == 1 && input_dim == 48) rc = launch_bwd_fused<48, 1>(g, in, W, B, gi, gw, s);
+        else if (nh == 2 && input_dim == 48) rc = launch_bwd_fused<48, 2>(g, in, W, B, gi, gw, s);
+        else if (nh == 1 && input_dim == 64) rc = launch_bwd_fused<64, 1>(g, in, W, B, gi, gw, s);
+        else if (nh == 2 && input_dim == 64) rc = launch_bwd_fused<64, 2>(g, in, W, B, gi, gw, s);
+        if (rc) return rc;
+        return lae::check_launch("ffmlp_backward(fused)");
+    }
+    if (!forward_buffer || !backward_buffer) return LAE_ENULL;
     switch (hidden_dim) {
         case 16: rc = backward_w<16>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
         case 32: rc = backward_w<32>(g, in, W, fb, B, input_dim, nh, activation, bb, gi, gw, s); break;
@@ -467,6 +767,12 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
     }
     if (rc) return rc;
     return lae::check_launch("ffmlp_backward");
+}
+
+int lae_ffmlp_set_mode(int mode) {
+    if (mode != 0 && mode != 1) return LAE_EINVAL;
+    g_ffmlp_mode = mode;
+    return LAE_OK;
 }
 
 int lae_allocate_splitk(uint64_t size) {

@@ -20,10 +20,14 @@ class _ffmlp_forward(Function):
         inputs, weights = inputs.contiguous(), weights.contiguous()
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if not inference:
-            forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            # the fused MI355X backward recomputes the hidden activations from `inputs` (64 B/row) instead of
+            # reading a [num_layers, B, hidden] buffer back from HBM, so no forward_buffer is written or kept
+            fused = _backend.fused_backward_available(input_dim, hidden_dim, num_layers, activation)
+            forward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                    output_activation, forward_buffer, outputs)
-            ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
+            ctx.fused = fused
+            ctx.save_for_backward(*((inputs, weights, outputs) if fused else (inputs, weights, outputs, forward_buffer)))
             ctx.dims = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
         else:
             _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
@@ -35,11 +39,14 @@ class _ffmlp_forward(Function):
     def backward(ctx, grad):
         B = grad.shape[0]
         grad = grad.contiguous()
-        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
+        if ctx.fused:
+            (inputs, weights, outputs), forward_buffer = ctx.saved_tensors, None
+        else:
+            inputs, weights, outputs, forward_buffer = ctx.saved_tensors
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
         grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
         grad_weights = torch.empty_like(weights)
-        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        backward_buffer = None if ctx.fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                                 activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
         return (grad_inputs if calc_grad_inputs else None), grad_weights, None, None, None, None, None, None, None, None

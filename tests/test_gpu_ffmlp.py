@@ -37,14 +37,26 @@ def test_ffmlp_forward_backward(O, IN, H, NL, B):
     ref_gw, ref_gi, ref_bb = O.ffmlp_backward(Gh, Xh, Wh, ref_fb, IN, 16, H, NL, calc_grad_inputs=True)
     bb = torch.empty(NL, B, H, device=DEV, dtype=torch.half); gi = torch.empty(B, IN, device=DEV, dtype=torch.half)
     gw = torch.empty(nW, device=DEV, dtype=torch.half)
-    F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), half_from_bits(ref_fb), B, IN, 16, H, NL, 0, 6, True, bb, gi, gw)
-    assert close_f16(N(bb), O.from_f16_bits(ref_bb), floor=5e-4)
-    assert close_f16(N(gi), O.from_f16_bits(ref_gi), floor=5e-4)
-    assert close_f16(N(gw), O.from_f16_bits(ref_gw), rel=1e-2, floor=2e-3)
-    # determinism of the slab reduction
-    gw2 = torch.empty_like(gw)
-    F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), half_from_bits(ref_fb), B, IN, 16, H, NL, 0, 6, False, bb, gi, gw2)
-    assert torch.equal(gw, gw2)
+    # mode 1: the buffer-faithful path (fills backward_buffer like the reference); mode 0: fused path where available
+    # (recomputes the activations, needs neither buffer)
+    try:
+        for mode in (1, 0):
+            F.ffmlp_set_mode(mode)
+            fused = mode == 0 and F.fused_backward_available(IN, H, NL, 0)
+            gi.zero_(); gw.zero_()
+            F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), None if fused else half_from_bits(ref_fb),
+                             B, IN, 16, H, NL, 0, 6, True, None if fused else bb, gi, gw)
+            if not fused:
+                assert close_f16(N(bb), O.from_f16_bits(ref_bb), floor=5e-4)
+            assert close_f16(N(gi), O.from_f16_bits(ref_gi), floor=5e-4), mode
+            assert close_f16(N(gw), O.from_f16_bits(ref_gw), rel=1e-2, floor=2e-3), mode
+            # determinism of the slab reduction
+            gw2 = torch.empty_like(gw)
+            F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), None if fused else half_from_bits(ref_fb),
+                             B, IN, 16, H, NL, 0, 6, False, None if fused else bb, gi, gw2)
+            assert torch.equal(gw, gw2)
+    finally:
+        F.ffmlp_set_mode(0)
 
 
 @pytest.mark.parametrize("act", [0, 3, 6])
