@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
     return p.parse_args()
 
 
@@ -125,7 +126,8 @@ def main():
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
     r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
     r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)      # main_nerf.py:223
+    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True,
+                           capturable=not args.no_graph)                                   # main_nerf.py:223
     scaler = torch.amp.GradScaler("cuda")
     n_batches = 16
     batches = []
@@ -135,19 +137,20 @@ def main():
                         torch.rand(args.rays, 3, device=dev)))
     net.train()
 
-    def step(i):
-        o, d, gt = batches[i % n_batches]
+    def step_body(o, d, gt):
         with torch.autocast("cuda", dtype=torch.float16):
             res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
             loss = torch.nn.functional.mse_loss(res["image"], gt)
-        opt.zero_grad(set_to_none=True)
-        if args.no_optimizer:
-            scaler.scale(loss).backward()
-        else:
-            scaler.scale(loss).backward()
+        scaler.scale(loss).backward()
+        if not args.no_optimizer:
             scaler.step(opt)
             scaler.update()
         return res["n_samples"]
+
+    def step(i):
+        o, d, gt = batches[i % n_batches]
+        opt.zero_grad(set_to_none=True)
+        return step_body(o, d, gt)
 
     # warm-up: the first 16 steps run in the reference's "mean_count <= 0" mode (sized by a D2H read), then the
     # running mean is refreshed every 16 steps exactly like update_extra_state does (renderer.py:644-647)
@@ -158,7 +161,36 @@ def main():
             r.update_mean_count()
     r.update_mean_count() if r.local_step > 0 else None
     samples = []
-    backend.enable_kernel_timing(True)
+
+    # Steady state has static shapes (sample buffers are sized by mean_count, renderer.py:644-646), no host sync,
+    # a fused capturable Adam and device-side GradScaler, so the ~100 launches of one step are captured once into a
+    # HIP graph and replayed: the eager step is bound by host launch overhead (~15 us per launch), not by the GPU.
+    graph = None
+    if not args.no_graph:
+        so, sd, sgt = (torch.empty_like(t) for t in batches[0])
+        for t, b in zip((so, sd, sgt), batches[0]):
+            t.copy_(b)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations, workspaces)
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                step_body(so, sd, sgt)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            n_graph_samples = step_body(so, sd, sgt)
+
+        def step(i):                                        # noqa: F811  (replaces the eager step)
+            o, d, gt = batches[i % n_batches]
+            so.copy_(o); sd.copy_(d); sgt.copy_(gt)
+            graph.replay()
+            return n_graph_samples
+        for i in range(5):
+            step(i)
+    backend.enable_kernel_timing(not graph)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -172,14 +204,20 @@ def main():
         samples.append(step(n_warm + i))
     sync_all()
     dt = time.perf_counter() - t0
-    timing_grid = backend.collect_kernel_timing()
-    # diagnostic (outside the timed region): per-operator device time of 20 more steps
+    timing_grid = backend.collect_kernel_timing() if not graph else {}
+    # diagnostic (outside the timed region): per-operator device time of 20 eager steps (HIP events around each
+    # operator on the launch stream); with graph replay this is also where the roofline kernel is timed, because
+    # events cannot be read back from inside a replayed graph
     backend.enable_kernel_timing(True, only=None)
     n_diag = 20
     for i in range(n_diag):
-        step(n_warm + args.steps + i)
+        o, d, gt = batches[i % n_batches]
+        opt.zero_grad(set_to_none=True)
+        step_body(o, d, gt)
     timing_all = backend.collect_kernel_timing()
     backend.enable_kernel_timing(False)
+    if graph:
+        timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -209,6 +247,7 @@ def main():
                                    "steady-state train step incl. backward + Adam",
                        "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
                        "optimizer_in_timed_region": not args.no_optimizer,
+                       "hip_graph_replay": bool(graph),
                        "parallelism": f"{world} independent ray-batch replicas (no data-path collective)"},
             "roofline": {"kernel": "k_grid_fwd (hash-grid encode forward, fp16 table)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -315,7 +315,8 @@ def _wrap_timed(name, fn):
 
 for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):
     for _k, _v in list(vars(_cls).items()):
-        if isinstance(_v, staticmethod) and not _k.startswith("_"):
+        if isinstance(_v, staticmethod) and not _k.startswith("_") and _k not in ("fused_backward_available", "ffmlp_set_mode",
+                                                                                   "allocate_splitk", "free_splitk"):
             setattr(_cls, _k, staticmethod(_wrap_timed(_k, _v.__func__)))
 
 raymarching_backend = _RayMarching

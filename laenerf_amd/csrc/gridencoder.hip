@@ -148,6 +148,43 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
     T res[C];
 #pragma unroll
     for (int ch = 0; ch < C; ch++) res[ch] = (T)0.0f;
+    if constexpr (D == 3 && C == 2) {
+        // Corner pairs (x, x+1): the two entries are adjacent and pair-aligned whenever idx(x+1) == idx(x) ^ 1 -- on
+        // hashed levels for every even x ((x ^ h) and ((x|1) ^ h) differ in bit 0 only), on dense levels for even
+        // idx -- and are then fetched with ONE 8/16-byte load.  The kernel is bound by the number of cache lines the
+        // texture path touches (~1 line / cycle / CU, profiles/r1_grid_fwd_pmc.txt); this removes ~25 % of them.
+        // Accumulation order is unchanged (idx = x + 2y + 4z), so results stay bit-identical.
+        using V2 = typename std::conditional<sizeof(T) == 2, half2_t, float2>::type;
+        const V2* __restrict__ tab2 = reinterpret_cast<const V2*>(tab);
+        T cv[8][2];
+#pragma unroll
+        for (int yz = 0; yz < 4; yz++) {
+            uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+            const uint32_t i0 = cell_index<D>(li, pl);
+            pl[0] = pg[0] + 1;
+            const uint32_t i1 = cell_index<D>(li, pl);
+            V2 a, b;
+            if (i1 == (i0 ^ 1u)) {
+                if constexpr (sizeof(T) == 2) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(tab2 + (i0 & ~1u));
+                    const half2_t lo = __builtin_bit_cast(half2_t, w.x), hi = __builtin_bit_cast(half2_t, w.y);
+                    a = (i0 & 1u) ? hi : lo; b = (i0 & 1u) ? lo : hi;
+                } else {
+                    const float4 w = *reinterpret_cast<const float4*>(tab2 + (i0 & ~1u));
+                    a = (i0 & 1u) ? make_float2(w.z, w.w) : make_float2(w.x, w.y);
+                    b = (i0 & 1u) ? make_float2(w.x, w.y) : make_float2(w.z, w.w);
+                }
+            } else { a = tab2[i0]; b = tab2[i1]; }
+            if constexpr (sizeof(T) == 2) { cv[2 * yz][0] = a[0]; cv[2 * yz][1] = a[1]; cv[2 * yz + 1][0] = b[0]; cv[2 * yz + 1][1] = b[1]; }
+            else { cv[2 * yz][0] = a.x; cv[2 * yz][1] = a.y; cv[2 * yz + 1][0] = b.x; cv[2 * yz + 1][1] = b.y; }
+        }
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const float w = (((idx & 1) ? frac[0] : 1 - frac[0]) * ((idx & 2) ? frac[1] : 1 - frac[1])) * ((idx & 4) ? frac[2] : 1 - frac[2]);
+            accum(res[0], w, cv[idx][0]);
+            accum(res[1], w, cv[idx][1]);
+        }
+    } else {
 #pragma unroll
     for (int idx = 0; idx < (1 << D); idx++) {             // :166-191
         float w = 1.0f;
@@ -159,18 +196,11 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
         }
         const uint32_t gi = cell_index<D>(li, pgl) * C;
         T v[C];
-        if constexpr (C == 2 && sizeof(T) == 2) {
-            const half2_t h = *reinterpret_cast<const half2_t*>(tab + gi);
-            v[0] = h[0]; v[1] = h[1];
-        } else if constexpr (C == 2 && sizeof(T) == 4) {
-            const float2 h = *reinterpret_cast<const float2*>(tab + gi);
-            v[0] = h.x; v[1] = h.y;
-        } else {
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) v[ch] = tab[gi + ch];
-        }
+        for (int ch = 0; ch < C; ch++) v[ch] = tab[gi + ch];
 #pragma unroll
         for (int ch = 0; ch < C; ch++) accum(res[ch], w, v[ch]);
+    }
     }
     if constexpr (C == 2 && sizeof(T) == 2) {
         half2_t h = {res[0], res[1]};
