@@ -84,21 +84,29 @@ def cpu_baseline(n_rays_hint, n_threads):
 
     o, d = S.lego_like_rays(4096, seed=0)
     noises = np.random.default_rng(1).random(4096).astype(np.float32)
-    # calibrate on 64 rays, then size the sample for ~15 s of work on n_threads threads
+    # calibrate on 64 rays, then size the sample for ~15 s of wall time on n_threads threads: whole 4096-ray steps
+    # (different ray batches) when one step is too short for the box
     t0 = time.perf_counter(); one_chunk(o[:64], d[:64], noises[:64]); t_cal = time.perf_counter() - t0
     if n_rays_hint <= 0:
-        n_rays = int(min(4096, max(256, 15.0 / (t_cal / 64) * n_threads)))
-        n_rays -= n_rays % n_threads
+        # threads do not scale linearly (every chunk zero-fills its own 24 MB gradient table): assume 1/4 efficiency
+        n_rays = int(max(256, 15.0 / (t_cal / 64) * n_threads / 4))
+        n_rays = min(n_rays, 16 * 4096)
     else:
         n_rays = n_rays_hint
-    chunks = np.array_split(np.arange(n_rays), n_threads)
+    n_steps = max(1, (n_rays + 4095) // 4096)
+    work = []
+    for k in range(n_steps):
+        ok_, dk_ = (o, d) if k == 0 else S.lego_like_rays(4096, seed=k)
+        n_k = min(4096, n_rays - 4096 * k)
+        for c in np.array_split(np.arange(n_k), max(1, min(n_threads, n_k // 16))):
+            work.append((ok_[c], dk_[c], noises[c]))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(n_threads) as ex:
-        tot = sum(ex.map(lambda c: one_chunk(o[c], d[c], noises[c]), chunks))
+        tot = sum(ex.map(lambda a: one_chunk(*a), work))
     dt = time.perf_counter() - t0
     return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": n_threads, "kind": "port",
-            "sample": f"{n_rays} of 4096 rays of the same step ({tot} samples), forward+backward without optimizer, "
-                      f"oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
+            "sample": f"{n_rays} rays = {n_steps} step(s) of the same 4096-ray workload ({tot} samples), forward+backward "
+                      f"without optimizer, oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
 
 
 def main():

@@ -193,6 +193,10 @@ LAE_API int lae_grid_encode_backward_blc(const void* grad, const float* inputs, 
                                  const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                  int align_corners, uint32_t interp, int dtype, void* stream);
 
+/* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
+ * 1 = always the generic kernel (one global atomic per corner, what the reference does). */
+LAE_API int lae_grid_set_backward_mode(int mode);
+
 /* gridencoder.cu:639-645  grad_total_variation(inputs[B,D], embeddings, grad, offsets,
  * weight, B, D, C, L, S, H, gridtype, align_corners); inputs has the table dtype. */
 LAE_API int lae_grad_total_variation(const void* inputs, const void* embeddings, void* grad,

@@ -193,6 +193,11 @@ class _GridEncoder:
               "grid_encode_backward")
 
     @staticmethod
+    def set_backward_mode(mode):
+        """0 = binned LDS pipeline (default), 1 = generic global-atomic kernel"""
+        check(_lib.load().lae_grid_set_backward_mode(int(mode)), "grid_set_backward_mode")
+
+    @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):
         need_cuda(inputs, embeddings, grad, offsets); need_contig(inputs, embeddings, grad, offsets)
         check(_lib.load().lae_grad_total_variation(ptr(inputs), ptr(embeddings), ptr(grad), ptr(offsets), float(weight), B, D,
@@ -315,7 +320,7 @@ def _wrap_timed(name, fn):
 
 for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):
     for _k, _v in list(vars(_cls).items()):
-        if isinstance(_v, staticmethod) and not _k.startswith("_") and _k not in ("fused_backward_available", "ffmlp_set_mode",
+        if isinstance(_v, staticmethod) and not _k.startswith("_") and _k not in ("fused_backward_available", "ffmlp_set_mode", "set_backward_mode",
                                                                                    "allocate_splitk", "free_splitk"):
             setattr(_cls, _k, staticmethod(_wrap_timed(_k, _v.__func__)))
 

@@ -916,8 +916,8 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     return LAE_OK;
 }
 
-// test hook: force the generic global-atomic kernel (env LAE_GRID_BWD_ATOMIC=1)
-static const bool g_force_atomic_bwd = [] { const char* e = getenv("LAE_GRID_BWD_ATOMIC"); return e && e[0] == '1'; }();
+// 0 = binned LDS pipeline where available (default), 1 = always the generic global-atomic kernel
+static int g_force_atomic_bwd = 0;
 
 static int grid_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
@@ -1009,6 +1009,12 @@ int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const vo
                                  int align_corners, uint32_t interp, int dtype, void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, dtype, true, stream);
+}
+
+int lae_grid_set_backward_mode(int mode) {
+    if (mode != 0 && mode != 1) return LAE_EINVAL;
+    g_force_atomic_bwd = mode;
+    return LAE_OK;
 }
 
 int lae_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
