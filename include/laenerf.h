@@ -242,6 +242,21 @@ LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void*
                        void* backward_buffer, void* grad_inputs, void* grad_weights,
                        void* stream);
 
+/* MI355X-native fusion of NeRFNetwork.forward after the encoder (nerf/network_ff.py:57-79): sigma FFMLP(32,64,2 layers)
+ * -> sigma = density_scale * exp(h[0]); colour input = [SH degree 4 of dirs | h[1..15] | 0] -> colour FFMLP(32,64,3 layers)
+ * -> rgb = sigmoid(out[0..2]).  enc [M,32] fp16, dirs [M,3] fp32, weights in the FFMLP flat fp16 layout, M % 16 == 0.
+ * Outputs: h_out [M,16] fp16 (sigma-net output, saved for the backward), sigmas [M] fp32, rgbs [M,3] fp32. */
+LAE_API int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, void* stream);
+
+/* Backward of lae_nerf_head_forward: grad_sigmas [M], grad_rgbs [M,3] fp32 (as produced by
+ * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).
+ * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused. */
+LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
+                           const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
+                           float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
+                           void* grad_color_weights, void* stream);
+
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the
  * three-kernel path that fills both buffers exactly like the reference. */

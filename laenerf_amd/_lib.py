@@ -45,6 +45,8 @@ SIGNATURES = {
     "lae_ffmlp_forward": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],
+    "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, vp],
+    "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, vp],
     "lae_ffmlp_set_mode": [i32],
     "lae_allocate_splitk": [u64],
     "lae_free_splitk": [],

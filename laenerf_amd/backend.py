@@ -260,6 +260,27 @@ class _FFMLP:
                                              ptr(grad_weights), stream()), "ffmlp_backward")
 
     @staticmethod
+    def nerf_head_forward(enc, dirs, sigma_weights, color_weights, M, density_scale, h_out, sigmas, rgbs):
+        """MI355X-native: network_ff.py:57-79 after the grid encoder, in one kernel (include/laenerf.h)"""
+        ts = (enc, dirs, sigma_weights, color_weights, h_out, sigmas, rgbs)
+        need_cuda(*ts); need_contig(*ts); _FFMLP._half(enc, sigma_weights, color_weights, h_out)
+        check(_lib.load().lae_nerf_head_forward(ptr(enc), ptr(dirs), ptr(sigma_weights), ptr(color_weights), M,
+                                                float(density_scale), ptr(h_out), ptr(sigmas), ptr(rgbs), stream()),
+              "nerf_head_forward")
+
+    @staticmethod
+    def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,
+                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights):
+        ts = (grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, grad_h, grad_enc,
+              grad_sigma_weights, grad_color_weights)
+        need_cuda(*ts); need_contig(*ts)
+        _FFMLP._half(enc, h, sigma_weights, color_weights, grad_h, grad_enc, grad_sigma_weights, grad_color_weights)
+        check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
+                                                 ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
+                                                 ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
+                                                 ptr(grad_color_weights), stream()), "nerf_head_backward")
+
+    @staticmethod
     def ffmlp_set_mode(mode):
         """0 = fused backward (default), 1 = buffer-faithful three-kernel backward (fills forward/backward buffers)"""
         check(_lib.load().lae_ffmlp_set_mode(int(mode)), "ffmlp_set_mode")
@@ -282,7 +303,7 @@ class _FFMLP:
 # backend calls; used by bench.py for the roofline figure.  Off by default: zero overhead in the product path.
 _timing = {"on": False, "only": None, "events": []}
 _UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "ffmlp_forward": 2, "ffmlp_inference": 2,
-          "ffmlp_backward": 4, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
+          "ffmlp_backward": 4, "nerf_head_forward": 4, "nerf_head_backward": 8, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
           "composite_rays_train_backward": 9}
 
 

@@ -350,6 +350,77 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ sla
     if (sg == 0 && i < nW) gw[i] = (half_t)((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
 }
 
+// ---------------------------------------------------------------- fused NeRF head (network_ff.py:51-81 in one kernel)
+// sigma net (32 -> 64 -> 64 -> 16) -> sigma = density_scale * exp(h[0]) ; colour-net input = [SH_4(dir) | h[1..15] | 0]
+// -> colour net (32 -> 64 -> 64 -> 64 -> 16) -> rgb = sigmoid(out[0..2]).  One wave owns a 16-row tile and chains
+// every activation through registers in the MFMA C/D layout (lane = row, 4 regs = 4 consecutive features):
+//   * h[1 + m] -> colour feature 16 + m is a shift by one feature: three in-lane register moves and one
+//     16-lane shuffle;
+//   * the 16 SH values of a row are evaluated per lane and the lane keeps components 4g..4g+3 (its K-slice);
+//   * weights of both nets sit row-major in LDS (ds_read_b64 fragments).
+// Saved for the backward: h [M,16] fp16 (32 B/row) and rgb; nothing else touches HBM.
+#include "sh_table.inc"
+
+struct HeadCfg {
+    static constexpr int LDX = 40, LDH = 72;
+    // sigma net image
+    static constexpr int S0 = 0, S1 = S0 + 64 * LDX, SO = S1 + 64 * LDH, S_END = SO + 16 * LDH;
+    // colour net image
+    static constexpr int C0 = S_END, C1 = C0 + 64 * LDX, C2 = C1 + 64 * LDH, CO = C2 + 64 * LDH, C_END = CO + 16 * LDH;
+    static constexpr int LDS_HALVES = C_END;
+};
+
+__device__ __forceinline__ void stage_rows(half_t* dst, int ld, const half_t* __restrict__ src, int rows, int cols) {
+    for (uint32_t e = threadIdx.x; e < (uint32_t)rows * cols / 4; e += blockDim.x) {
+        const uint32_t r = (e * 4) / cols, k = (e * 4) % cols;
+        *reinterpret_cast<h4*>(dst + r * ld + k) = *reinterpret_cast<const h4*>(src + (size_t)r * cols + k);
+    }
+}
+
+// one 64-wide layer on a 16-row tile: acc[mt] = sum_kt W[mt*16+c][kt*16+4g..] * in[kt]
+template <int KT>
+__device__ __forceinline__ void layer64(const half_t* Wl, int ld, const h4 (&in)[KT], int c, int g, f4 (&acc)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            const h4 a = *reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g);
+            acc[mt] = mfma16(a, in[kt], acc[mt]);
+        }
+    }
+}
+__device__ __forceinline__ void relu4(const f4 (&acc)[4], h4 (&out)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
+}
+__device__ __forceinline__ f4 out16(const half_t* Wl, int ld, const h4 (&in)[4], int c, int g) {
+    f4 o = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++) {
+        const h4 a = *reinterpret_cast<const h4*>(Wl + c * ld + kt * 16 + 4 * g);
+        o = mfma16(a, in[kt], o);
+    }
+    return o;
+}
+
+// colour-net input fragments of a tile: k-step 0 = SH components 4g..4g+3 of the row's direction,
+// k-step 1 = features 16 + 4g + j = h[1 + 4g + j] (h = fp16 sigma-net output in C/D layout), feature 31 = 0
+__device__ __forceinline__ void color_inputs(const float* __restrict__ dirs, size_t row, const h4& hq, int g, h4 (&cin)[2]) {
+    float o[16], gx[1], gy[1], gz[1];
+    sh_eval<4, false>(dirs[3 * row], dirs[3 * row + 1], dirs[3 * row + 2], o, gx, gy, gz);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float v = g == 0 ? o[j] : g == 1 ? o[4 + j] : g == 2 ? o[8 + j] : o[12 + j];
+        cin[0][j] = (half_t)v;
+    }
+    const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[0]), 16, 64));
+    cin[1][0] = hq[1]; cin[1][1] = hq[2]; cin[1][2] = hq[3];
+    cin[1][3] = g == 3 ? (half_t)0.0f : nxt;
+}
+
 // ---------------------------------------------------------------- fused backward (WIDTH = 64, ReLU)
 // One kernel for everything the reference does in kernel_mlp_fused_backward + (num_layers+1) split-K CUTLASS
 // GEMMs (ffmlp.cu:410-518, 800-877), WITHOUT the forward/backward buffers: the hidden activations are
@@ -395,10 +466,18 @@ struct FusedCfg {
     static constexpr int LDS_HALVES = W_HALVES + 4 * WAVE_HALVES;
 };
 
-template <int IN, int NH>
+// MODE 1 = colour net of the fused NeRF head: the input rows are built on the fly from (h, dirs) exactly like
+// k_nerf_head_fwd, dL/dout comes from (grad_rgb, rgb) through the sigmoid, and instead of dL/dX the kernel writes
+// dL/dh [M,16] = [ grad_sigma * density_scale * exp(clamp(h0, -15, 15)) | dX[16..30] ] (trunc_exp backward,
+// activation.py:14-17, and the inverse of the one-feature shift) -- the sigma net's backward reads that directly.
+struct HeadBwdArgs {
+    const float* dirs; const float* rgbs; const float* grad_rgbs; const float* grad_sigmas; float density_scale;
+};
+
+template <int IN, int NH, int MODE>
 __global__ __launch_bounds__(256) void k_mlp_bwd_fused(
     const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
-    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW) {
+    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW, HeadBwdArgs ha) {
     using C = FusedCfg<IN, NH>;
     constexpr int KT0 = C::KT0;
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
@@ -444,12 +523,26 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(
         const size_t row = (size_t)tile * 16 + c;
         // ---- inputs: B fragments + X tile
         h4 xf[KT0];
+        h4 gf, hq;
+        if constexpr (MODE == 1) {
+            static_assert(MODE == 0 || KT0 == 2, "head colour net has a 32-wide input");
+            hq = *reinterpret_cast<const h4*>(x + row * 16 + 4 * g);
+            color_inputs(ha.dirs, row, hq, g, xf);
+            gf = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+            if (g == 0) {
 #pragma unroll
-        for (int kt = 0; kt < KT0; kt++) {
-            xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
-            *reinterpret_cast<h4*>(T + C::X_OFF + c * C::LDX + kt * 16 + 4 * g) = xf[kt];
+                for (int r = 0; r < 3; r++) {
+                    const float y = ha.rgbs[row * 3 + r];
+                    gf[r] = (half_t)(ha.grad_rgbs[row * 3 + r] * y * (1.0f - y));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+            gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
         }
-        const h4 gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < KT0; kt++) *reinterpret_cast<h4*>(T + C::X_OFF + c * C::LDX + kt * 16 + 4 * g) = xf[kt];
         *reinterpret_cast<h4*>(T + C::G_OFF + c * C::LDG + 4 * g) = gf;
         // ---- recompute the hidden activations (post-ReLU), keep them in registers and in the H tiles
         h4 h[NH + 1][4];
@@ -552,7 +645,21 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(
                 dW0[mt][nt] = mfma16(a, b, dW0[mt][nt]);
             }
         }
-        if (grad_in) {
+        if constexpr (MODE == 1) {
+            f4 acc = f4{0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                const h4 a = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp);            // W0^T, features 16..31
+                acc = mfma16(a, d[kt], acc);
+            }
+            const half_t v3 = (half_t)acc[3];
+            const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
+            h4 v;
+            v[0] = prev;
+            if (g == 0) v[0] = (half_t)(ha.grad_sigmas[row] * ha.density_scale * expf(lae::clampf((float)hq[0], -15.0f, 15.0f)));
+            v[1] = (half_t)acc[0]; v[2] = (half_t)acc[1]; v[3] = (half_t)acc[2];
+            *reinterpret_cast<h4*>(grad_in + row * 16 + 4 * g) = v;
+        } else if (grad_in) {
 #pragma unroll
             for (int it = 0; it < KT0; it++) {
                 f4 acc = f4{0, 0, 0, 0};
@@ -611,24 +718,69 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(
     }
 }
 
-template <int IN, int NH>
-int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s) {
+template <int IN, int NH, int MODE = 0>
+int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
+                     HeadBwdArgs ha = HeadBwdArgs{}) {
     using C = FusedCfg<IN, NH>;
     const uint32_t nW = 64 * (IN + 64 * NH + 16);
     const uint32_t n_tiles = B / 16;
     const size_t lds_bytes = std::max((size_t)C::LDS_HALVES * 2, (size_t)C::N_TILES * 1024);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
         attr_set = true;
     }
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
     float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
     if (!ws) return LAE_ELAUNCH;
-    k_mlp_bwd_fused<IN, NH><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW);
+    k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     k_dw_reduce<<<lae::cdiv(nW, 64), 256, 0, s>>>(ws, blocks, nW, gw);
     return LAE_OK;
+}
+
+__global__ __launch_bounds__(256) void k_nerf_head_fwd(
+    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
+    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    using C = HeadCfg;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    stage_rows(lds + C::S0, C::LDX, Ws, 64, 32);
+    stage_rows(lds + C::S1, C::LDH, Ws + 64 * 32, 64, 64);
+    stage_rows(lds + C::SO, C::LDH, Ws + 64 * 32 + 4096, 16, 64);
+    stage_rows(lds + C::C0, C::LDX, Wc, 64, 32);
+    stage_rows(lds + C::C1, C::LDH, Wc + 64 * 32, 64, 64);
+    stage_rows(lds + C::C2, C::LDH, Wc + 64 * 32 + 4096, 64, 64);
+    stage_rows(lds + C::CO, C::LDH, Wc + 64 * 32 + 8192, 16, 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
+        const size_t row = (size_t)tile * 16 + c;
+        h4 xf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) xf[kt] = *reinterpret_cast<const h4*>(enc + row * 32 + kt * 16 + 4 * g);
+        f4 acc[4];
+        h4 a0[4], a1[4];
+        layer64<2>(lds + C::S0, C::LDX, xf, c, g, acc); relu4(acc, a0);
+        layer64<4>(lds + C::S1, C::LDH, a0, c, g, acc); relu4(acc, a1);
+        const f4 so = out16(lds + C::SO, C::LDH, a1, c, g);
+        h4 hq;
+#pragma unroll
+        for (int r = 0; r < 4; r++) hq[r] = (half_t)so[r];
+        *reinterpret_cast<h4*>(h_out + row * 16 + 4 * g) = hq;
+        if (g == 0) sigmas[row] = density_scale * expf((float)hq[0]);                    // trunc_exp forward (activation.py:9)
+        h4 cin[2];
+        color_inputs(dirs, row, hq, g, cin);
+        layer64<2>(lds + C::C0, C::LDX, cin, c, g, acc); relu4(acc, a0);
+        layer64<4>(lds + C::C1, C::LDH, a0, c, g, acc); relu4(acc, a1);
+        layer64<4>(lds + C::C2, C::LDH, a1, c, g, acc); relu4(acc, a0);
+        const f4 co = out16(lds + C::CO, C::LDH, a0, c, g);
+        if (g == 0) {
+#pragma unroll
+            // sigmoid of the fp16 output, rounded to fp16 like torch.sigmoid on a half tensor (network_ff.py:79 under autocast)
+            for (int r = 0; r < 3; r++) rgbs[row * 3 + r] = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)co[r])));
+        }
+    }
 }
 
 // 0 = fused backward where available (default), 1 = always the buffer-faithful three-kernel path
@@ -767,6 +919,49 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
     }
     if (rc) return rc;
     return lae::check_launch("ffmlp_backward");
+}
+
+int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, void* stream) {
+    if (M == 0) return LAE_OK;
+    if (!enc || !dirs || !sigma_weights || !color_weights || !h_out || !sigmas || !rgbs) return LAE_ENULL;
+    if (M % 16 != 0) return LAE_EINVAL;
+    const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+        attr_set = true;
+    }
+    const uint32_t n_tiles = M / 16;
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    k_nerf_head_fwd<<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
+        (half_t*)h_out, sigmas, rgbs);
+    return lae::check_launch("nerf_head_forward");
+}
+
+int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
+                           const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
+                           float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
+                           void* grad_color_weights, void* stream) {
+    if (!grad_sigma_weights || !grad_color_weights) return LAE_ENULL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M == 0) {                                        // no samples: zero weight gradients (like the reference's GEMMs on empty batches)
+        if (hipMemsetAsync(grad_sigma_weights, 0, 64 * (32 + 64 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
+        if (hipMemsetAsync(grad_color_weights, 0, 64 * (32 + 128 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
+        return LAE_OK;
+    }
+    if (!grad_sigmas || !grad_rgbs || !enc || !dirs || !h || !rgbs || !sigma_weights || !color_weights || !grad_h) return LAE_ENULL;
+    if (M % 16 != 0) return LAE_EINVAL;
+    HeadBwdArgs ha{dirs, rgbs, grad_rgbs, grad_sigmas, density_scale};
+    int rc = launch_bwd_fused<32, 2, 1>(nullptr, (const half_t*)h, (const half_t*)color_weights, M, (half_t*)grad_h,
+                                        (half_t*)grad_color_weights, s, ha);
+    if (rc != LAE_OK) return rc;
+    rc = launch_bwd_fused<32, 1, 0>((const half_t*)grad_h, (const half_t*)enc, (const half_t*)sigma_weights, M, (half_t*)grad_enc,
+                                    (half_t*)grad_sigma_weights, s);
+    if (rc != LAE_OK) return rc;
+    return lae::check_launch("nerf_head_backward");
 }
 
 int lae_ffmlp_set_mode(int mode) {

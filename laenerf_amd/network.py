@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .activation import trunc_exp
 from .encoding import get_encoder
-from .ffmlp import FFMLP
+from .ffmlp import FFMLP, nerf_head
 
 
 class NeRFNetwork(nn.Module):
@@ -30,10 +30,17 @@ class NeRFNetwork(nn.Module):
         self.in_dim_color += self.geo_feat_dim + 1          # padded to 32 (network_ff.py:42)
         self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=self.hidden_dim_color,
                                num_layers=self.num_layers_color)
+        # MI355X: the default architecture runs everything after the encoder as ONE kernel (ffmlp/head.py);
+        # set fused_head = False for the operator-by-operator path of the reference.
+        self.fused_head = (encoding_dir == "sphere_harmonics" and self.in_dim == 32 and self.in_dim_color == 32
+                           and num_layers == 2 and num_layers_color == 3 and hidden_dim == 64 and hidden_dim_color == 64
+                           and geo_feat_dim == 15 and getattr(self.encoder_dir, "degree", 0) == 4)
 
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N] fp32, rgb [N,3]   (network_ff.py:51-81)"""
         x = self.encoder(x, bound=self.bound)
+        if self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and x.dtype == torch.half and not d.requires_grad:
+            return nerf_head(x, d, self.sigma_net.weights, self.color_net.weights)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

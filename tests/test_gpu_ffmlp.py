@@ -97,3 +97,62 @@ def test_ffmlp_module_matches_linear_chain(O):
     gw_ref = torch.cat([l.weight.grad.reshape(-1) for l in lin])
     assert np.abs(N(m.weights.grad) - N(gw_ref)).max() < 2e-2 * N(gw_ref).max()
     assert np.abs(N(x.grad) - N(xr.grad)).max() < 2e-2 * np.abs(N(xr.grad)).max() + 1e-3
+
+
+@pytest.mark.parametrize("M", [128, 4096 + 16])
+def test_nerf_head_matches_operator_chain_and_oracle(O, M):
+    """fused head (one forward kernel, two backward kernels) == sigma_net -> trunc_exp/geo_feat -> SH(4) -> cat ->
+    color_net -> sigmoid built from the separate operators, and == the same chain on the CPU oracle."""
+    from laenerf_amd.network import NeRFNetwork
+    rng = np.random.default_rng(M)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=12).to(DEV)
+    net.train()
+    enc_np = (rng.standard_normal((M, 32)) * 0.3).astype(np.float16)
+    d = rng.standard_normal((M, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    gs = (rng.standard_normal(M) * 0.1).astype(np.float32)
+    gr = (rng.standard_normal((M, 3)) * 0.1).astype(np.float32)
+
+    def run(fused):
+        enc = T(enc_np).requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            if fused:
+                from laenerf_amd.ffmlp import nerf_head
+                sigma, rgb = nerf_head(enc, T(d), net.sigma_net.weights, net.color_net.weights)
+            else:
+                from laenerf_amd.activation import trunc_exp
+                h = net.sigma_net(enc)
+                sigma = trunc_exp(h[..., 0])
+                geo = h[..., 1:]
+                sh = net.encoder_dir(T(d))
+                cin = torch.cat([sh.to(geo.dtype), geo, torch.zeros_like(geo[..., :1])], dim=-1)
+                rgb = torch.sigmoid(net.color_net(cin))
+        (sigma.float() * T(gs)).sum().add((rgb.float() * T(gr)).sum()).backward()
+        return (N(sigma.float()), N(rgb.float()), N(enc.grad.float()), N(net.sigma_net.weights.grad), N(net.color_net.weights.grad))
+
+    s1, c1, ge1, gws1, gwc1 = run(True)
+    s0, c0, ge0, gws0, gwc0 = run(False)
+    assert np.allclose(s1, s0, rtol=1e-5, atol=1e-7)                 # same fp16 h, expf vs torch.exp
+    assert np.abs(c1 - c0).max() <= 5e-4                              # both round the sigmoid to fp16 (<= 1 ulp apart)
+    assert close_f16(ge1, ge0, floor=5e-4) and close_f16(gws1, gws0, rel=1e-2) and close_f16(gwc1, gwc0, rel=1e-2)
+    # CPU oracle chain (forward)
+    ws_h = O.to_f16_bits(N(net.sigma_net.weights)); wc_h = O.to_f16_bits(N(net.color_net.weights))
+    h, _ = O.ffmlp_forward(enc_np.view(np.uint16), ws_h, 32, 16, 64, 2)
+    hf = O.from_f16_bits(h)
+    sh, _ = O.sh_encode_forward(d, 4)
+    cin = O.to_f16_bits(np.concatenate([sh, hf[:, 1:], np.zeros((M, 1), np.float32)], 1))
+    oc, _ = O.ffmlp_forward(cin, wc_h, 32, 16, 64, 3)
+    assert np.allclose(s1, np.exp(hf[:, 0]), rtol=2e-2, atol=1e-6)    # 1 fp16 ulp of h0 -> ~1e-3 relative in exp
+    assert np.abs(c1 - 1 / (1 + np.exp(-O.from_f16_bits(oc)[:, :3]))).max() < 3e-3
+    # determinism
+    s2, c2, ge2, gws2, gwc2 = run(True)
+    assert np.array_equal(s1, s2) and np.array_equal(c1, c2) and np.array_equal(ge1, ge2) and np.array_equal(gwc1, gwc2)
+
+
+def test_nerf_head_rejects_bad_shapes():
+    from laenerf_amd.ffmlp import nerf_head
+    w1 = torch.zeros(64 * 112, device=DEV); w2 = torch.zeros(64 * 176, device=DEV)
+    with pytest.raises(RuntimeError):
+        nerf_head(torch.zeros(24, 32, device=DEV, dtype=torch.half), torch.zeros(24, 3, device=DEV), w1, w2)
+    with pytest.raises(RuntimeError):
+        nerf_head(torch.zeros(32, 16, device=DEV, dtype=torch.half), torch.zeros(32, 3, device=DEV), w1, w2)
