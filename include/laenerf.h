@@ -249,6 +249,11 @@ LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void*
 LAE_API int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
                           uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, void* stream);
 
+/* The density query of NeRFNetwork.density (nerf/network_ff.py:83-96) after the encoder: sigma FFMLP -> sigma =
+ * density_scale * exp(h[0]); h_out [M,16] fp16 (h[1..15] = geo_feat) may be NULL.  Used by update_extra_state. */
+LAE_API int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_t M, float density_scale, void* h_out,
+                             float* sigmas, void* stream);
+
 /* Backward of lae_nerf_head_forward: grad_sigmas [M], grad_rgbs [M,3] fp32 (as produced by
  * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).
  * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused. */
@@ -256,6 +261,22 @@ LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_r
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
                            void* grad_color_weights, void* stream);
+
+/* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
+ * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
+ *   (renderer.py:580-592).  coords NULL: c = (j / H^2, (j / H) % H, j % H) (full sweep, n <= H^3); else coords [n,3] int32.
+ *   noise [n,3] in [0,1) or NULL (no jitter). */
+LAE_API int lae_density_grid_positions(const int32_t* coords, uint32_t n, uint32_t H, float bound_c, const float* noise,
+                               float* xyzs, int32_t* indices, void* stream);
+/* update: tmp[indices] = sigmas * density_scale (maximum where indices repeat), then on sampled cells with grid >= 0:
+ *   grid = max(grid * decay, tmp)  (renderer.py:596, 627, 633-634).  grid [cells] fp32 is one cascade; tmp [cells] uint32
+ *   scratch must be zero on entry and is zero again on return. */
+LAE_API int lae_density_grid_update(const float* sigmas, const int32_t* indices, uint32_t n, float density_scale, float decay,
+                            uint32_t cells, float* grid, uint32_t* tmp, void* stream);
+/* mark_untrained_grid (renderer.py:482-554): grid[cas, morton(c)] = -1 for cells seen by no camera or closer than
+ *   min_near to one.  poses [B,4,4] fp32 camera-to-world, intrinsics (fx, fy, cx, cy), grid [C, H^3] fp32 in place. */
+LAE_API int lae_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H,
+                            float bound, float min_near, int filter_close_point, float* grid, void* stream);
 
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the

@@ -81,6 +81,31 @@ class _RayMarching:
         assert bitfield.dtype == torch.uint8
         check(_lib.load().lae_packbits(ptr(grid), N, float(density_thresh), ptr(bitfield), stream()), "packbits")
 
+    # ---- occupancy-grid maintenance (Python in the reference, nerf/renderer.py:482-649; kernels here)
+    @staticmethod
+    def density_grid_positions(coords, n, H, bound_c, noise, xyzs, indices):
+        need_cuda(coords, noise, xyzs, indices); need_contig(coords, noise, xyzs, indices); _need_f32(noise, xyzs)
+        assert indices.dtype == torch.int32 and (coords is None or coords.dtype == torch.int32)
+        assert xyzs.numel() == 3 * n and indices.numel() == n and (noise is None or noise.numel() == 3 * n)
+        check(_lib.load().lae_density_grid_positions(ptr(coords), n, H, float(bound_c), ptr(noise), ptr(xyzs), ptr(indices),
+                                                     stream()), "density_grid_positions")
+
+    @staticmethod
+    def density_grid_update(sigmas, indices, n, density_scale, decay, cells, grid, tmp):
+        need_cuda(sigmas, indices, grid, tmp); need_contig(sigmas, indices, grid, tmp); _need_f32(sigmas, grid)
+        assert indices.dtype == torch.int32 and tmp.dtype == torch.int32
+        assert grid.numel() == cells and tmp.numel() == cells and sigmas.numel() >= n and indices.numel() >= n
+        check(_lib.load().lae_density_grid_update(ptr(sigmas), ptr(indices), n, float(density_scale), float(decay), cells,
+                                                  ptr(grid), ptr(tmp), stream()), "density_grid_update")
+
+    @staticmethod
+    def mark_untrained_grid(poses, B, fx, fy, cx, cy, C, H, bound, min_near, filter_close_point, grid):
+        need_cuda(poses, grid); need_contig(poses, grid); _need_f32(poses, grid)
+        assert poses.numel() == B * 16 and grid.numel() == C * H ** 3
+        check(_lib.load().lae_mark_untrained_grid(ptr(poses), B, float(fx), float(fy), float(cx), float(cy), C, H,
+                                                  float(bound), float(min_near), int(bool(filter_close_point)), ptr(grid),
+                                                  stream()), "mark_untrained_grid")
+
     @staticmethod
     def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
                          rays, counter, noises):
@@ -269,6 +294,13 @@ class _FFMLP:
               "nerf_head_forward")
 
     @staticmethod
+    def nerf_density_forward(enc, sigma_weights, M, density_scale, h_out, sigmas):
+        need_cuda(enc, sigma_weights, h_out, sigmas); need_contig(enc, sigma_weights, h_out, sigmas)
+        _FFMLP._half(enc, sigma_weights, h_out)
+        check(_lib.load().lae_nerf_density_forward(ptr(enc), ptr(sigma_weights), M, float(density_scale), ptr(h_out),
+                                                   ptr(sigmas), stream()), "nerf_density_forward")
+
+    @staticmethod
     def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,
                            grad_h, grad_enc, grad_sigma_weights, grad_color_weights):
         ts = (grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, grad_h, grad_enc,
@@ -303,7 +335,7 @@ class _FFMLP:
 # backend calls; used by bench.py for the roofline figure.  Off by default: zero overhead in the product path.
 _timing = {"on": False, "only": None, "events": []}
 _UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "ffmlp_forward": 2, "ffmlp_inference": 2,
-          "ffmlp_backward": 4, "nerf_head_forward": 4, "nerf_head_backward": 8, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
+          "ffmlp_backward": 4, "nerf_head_forward": 4, "nerf_head_backward": 8, "nerf_density_forward": 2, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
           "composite_rays_train_backward": 9}
 
 

@@ -739,6 +739,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
     return LAE_OK;
 }
 
+template <bool COLOR>
 __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
     uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs) {
@@ -747,10 +748,12 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     stage_rows(lds + C::S0, C::LDX, Ws, 64, 32);
     stage_rows(lds + C::S1, C::LDH, Ws + 64 * 32, 64, 64);
     stage_rows(lds + C::SO, C::LDH, Ws + 64 * 32 + 4096, 16, 64);
-    stage_rows(lds + C::C0, C::LDX, Wc, 64, 32);
-    stage_rows(lds + C::C1, C::LDH, Wc + 64 * 32, 64, 64);
-    stage_rows(lds + C::C2, C::LDH, Wc + 64 * 32 + 4096, 64, 64);
-    stage_rows(lds + C::CO, C::LDH, Wc + 64 * 32 + 8192, 16, 64);
+    if constexpr (COLOR) {
+        stage_rows(lds + C::C0, C::LDX, Wc, 64, 32);
+        stage_rows(lds + C::C1, C::LDH, Wc + 64 * 32, 64, 64);
+        stage_rows(lds + C::C2, C::LDH, Wc + 64 * 32 + 4096, 64, 64);
+        stage_rows(lds + C::CO, C::LDH, Wc + 64 * 32 + 8192, 16, 64);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -767,8 +770,9 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
         h4 hq;
 #pragma unroll
         for (int r = 0; r < 4; r++) hq[r] = (half_t)so[r];
-        *reinterpret_cast<h4*>(h_out + row * 16 + 4 * g) = hq;
+        if (h_out) *reinterpret_cast<h4*>(h_out + row * 16 + 4 * g) = hq;
         if (g == 0) sigmas[row] = density_scale * expf((float)hq[0]);                    // trunc_exp forward (activation.py:9)
+        if constexpr (!COLOR) continue;
         h4 cin[2];
         color_inputs(dirs, row, hq, g, cin);
         layer64<2>(lds + C::C0, C::LDX, cin, c, g, acc); relu4(acc, a0);
@@ -929,16 +933,29 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
     const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
         attr_set = true;
     }
     const uint32_t n_tiles = M / 16;
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
-    k_nerf_head_fwd<<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
+    k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
         (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
         (half_t*)h_out, sigmas, rgbs);
     return lae::check_launch("nerf_head_forward");
+}
+
+int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_t M, float density_scale, void* h_out,
+                             float* sigmas, void* stream) {
+    if (M == 0) return LAE_OK;
+    if (!enc || !sigma_weights || !sigmas) return LAE_ENULL;
+    if (M % 16 != 0) return LAE_EINVAL;
+    const size_t lds_bytes = (size_t)HeadCfg::S_END * 2;                 // sigma-net image only (< 64 KiB)
+    const uint32_t n_tiles = M / 16;
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
+    k_nerf_head_fwd<false><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr);
+    return lae::check_launch("nerf_density_forward");
 }
 
 int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,

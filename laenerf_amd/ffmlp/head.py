@@ -57,3 +57,20 @@ class _nerf_head(Function):
 def nerf_head(enc, dirs, sigma_weights, color_weights, density_scale=1.0):
     """enc [M,32] (grid-encoder output), dirs [M,3] unit fp32 -> sigmas [M] fp32, rgbs [M,3] fp32"""
     return _nerf_head.apply(enc, dirs, sigma_weights, color_weights, float(density_scale))
+
+
+@torch.no_grad()
+def nerf_density(enc, sigma_weights, density_scale=1.0, want_geo_feat=True):
+    """inference-only density query after the encoder (network_ff.py:83-96): enc [M,32] -> sigma [M] fp32 and
+    (optionally) h [M,16] fp16 whose columns 1..15 are geo_feat.  M is padded to a multiple of 16 here."""
+    M = enc.shape[0]
+    if enc.shape[1] != 32 or sigma_weights.numel() != SIGMA_NET_PARAMS:
+        raise RuntimeError("nerf_density: needs the 32-wide encoder and FFMLP(32,64,2 layers,16)")
+    enc = enc.half().contiguous()
+    Mp = (M + 15) // 16 * 16
+    if Mp != M:
+        enc = torch.cat([enc, enc.new_zeros(Mp - M, 32)], dim=0)
+    sigmas = torch.empty(Mp, device=enc.device, dtype=torch.float32)
+    h = torch.empty(Mp, 16, device=enc.device, dtype=torch.half) if want_geo_feat else None
+    _backend.nerf_density_forward(enc, sigma_weights.half().contiguous(), Mp, density_scale, h, sigmas)
+    return sigmas[:M], (h[:M] if want_geo_feat else None)

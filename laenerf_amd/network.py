@@ -1,4 +1,5 @@
-"""NeRFNetwork on the HIP operators: the fused-MLP variant of the reference (nerf/network_ff.py:12-81).
+"""NeRFNetwork on the HIP operators: the fused-MLP variant of the reference (nerf/network_ff.py:12-139) and, as
+`NeRFNetworkLinear`, the default `nn.Linear` variant the shipped scripts run (nerf/network.py:33-165).
 
 hash grid (L=16, F=2, T=2^19, finest resolution 2048*bound) -> sigma FFMLP (32->64->64->16) -> trunc_exp;
 SH(4) of the view direction + 15 geometry features + 1 zero pad -> colour FFMLP (32->64->64->64->16) -> sigmoid.
@@ -9,7 +10,7 @@ import torch.nn as nn
 
 from .activation import trunc_exp
 from .encoding import get_encoder
-from .ffmlp import FFMLP, nerf_head
+from .ffmlp import FFMLP, nerf_density, nerf_head
 
 
 class NeRFNetwork(nn.Module):
@@ -54,8 +55,79 @@ class NeRFNetwork(nn.Module):
     def density(self, x):
         """network_ff.py:83-96"""
         x = self.encoder(x, bound=self.bound)
+        if self.fused_head and x.is_cuda and x.dtype == torch.half and not torch.is_grad_enabled():
+            sigma, h = nerf_density(x, self.sigma_net.weights)
+            return {"sigma": sigma, "geo_feat": h[..., 1:]}
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """masked colour query of the `run` path (network_ff.py:98-139): rows outside `mask` stay zero"""
+        return _masked_color(self, d, mask, geo_feat)
+
+    def _color_rows(self, d, geo_feat):
+        d = self.encoder_dir(d)
+        h = torch.cat([d.to(geo_feat.dtype), geo_feat, torch.zeros_like(geo_feat[..., :1])], dim=-1)
+        return torch.sigmoid(self.color_net(h))
+
+    def get_params(self, lr):
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                {"params": self.color_net.parameters(), "lr": lr}]
+
+
+def _masked_color(net, d, mask, geo_feat):
+    if mask is None:
+        return net._color_rows(d, geo_feat)
+    rgbs = torch.zeros(mask.shape[0], 3, dtype=torch.float32, device=d.device)
+    if not mask.any():
+        return rgbs
+    rgbs[mask] = net._color_rows(d[mask], geo_feat[mask]).to(rgbs.dtype)
+    return rgbs
+
+
+class NeRFNetworkLinear(nn.Module):
+    """The reference's default network (nerf/network.py:33-165): bias-free `nn.Linear` chains (hipBLASLt GEMMs under
+    autocast) -- sigma: in -> 64 -> 1+15 (num_layers 2), colour: 16+15 -> 64 -> 64 -> 3 (num_layers_color 3).  It is
+    the arithmetic the fused MLP replaces and what `ffmlp` is checked against."""
+
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1, num_levels=16, log2_hashmap_size=19):
+        super().__init__()
+        self.bound = bound
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound, num_levels=num_levels,
+                                                log2_hashmap_size=log2_hashmap_size)
+        dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]
+        self.sigma_net = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        dims = [self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3]
+        self.color_net = nn.ModuleList([nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
+
+    @staticmethod
+    def _chain(layers, h):
+        for i, layer in enumerate(layers):
+            h = layer(h)
+            if i != len(layers) - 1:
+                h = torch.relu(h)
+        return h
+
+    def forward(self, x, d):
+        """network.py:95-124"""
+        out = self.density(x)
+        return out["sigma"], self._color_rows(d, out["geo_feat"])
+
+    def density(self, x):
+        """network.py:126-143"""
+        h = self._chain(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def _color_rows(self, d, geo_feat):
+        d = self.encoder_dir(d)
+        return torch.sigmoid(self._chain(self.color_net, torch.cat([d.to(geo_feat.dtype), geo_feat], dim=-1)))
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """network.py:145-180"""
+        return _masked_color(self, d, mask, geo_feat)
 
     def get_params(self, lr):
         return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},

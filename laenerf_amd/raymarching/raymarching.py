@@ -14,7 +14,7 @@ from ..backend import raymarching_backend as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
-           "compact_rays_alive"]
+           "compact_rays_alive", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
 
 
 def _gpu(t):
@@ -261,3 +261,35 @@ def compact_rays_alive(rays_alive, n_alive=None):
     n_out = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
     _backend.compact_rays_alive(rays_alive, n_alive, out, n_out)
     return out, n_out
+
+
+# ---------------------------------------------------------------- occupancy-grid maintenance (MI355X-native kernels)
+@torch.no_grad()
+def density_grid_positions(n, H, bound_c, noise=None, coords=None):
+    """positions + Morton indices of `update_extra_state`'s density queries (nerf/renderer.py:580-592, 602-621).
+    coords None: the n = H^3 cells in meshgrid order (full sweep); else coords [n,3] int32.  noise [n,3] in [0,1)."""
+    dev = (coords if coords is not None else noise).device if (coords is not None or noise is not None) else torch.device("cuda")
+    xyzs = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    indices = torch.empty(n, dtype=torch.int32, device=dev)
+    _backend.density_grid_positions(None if coords is None else _gpu(coords).int().contiguous(), n, H, bound_c,
+                                    None if noise is None else _gpu(noise).float().contiguous(), xyzs, indices)
+    return xyzs, indices
+
+
+@torch.no_grad()
+def density_grid_update(grid_c, sigmas, indices, tmp, density_scale=1.0, decay=0.95):
+    """in place on one cascade `grid_c` [H^3]: tmp[indices] = sigmas * density_scale; grid = max(grid * decay, tmp)
+    on sampled, trainable cells (renderer.py:596, 627, 633-634).  tmp [H^3] int32 scratch, zero before and after."""
+    _backend.density_grid_update(sigmas.float().contiguous(), indices.contiguous(), indices.numel(), density_scale, decay,
+                                 grid_c.numel(), grid_c, tmp)
+    return grid_c
+
+
+@torch.no_grad()
+def mark_untrained_grid(density_grid, poses, intrinsics, bound, min_near=0.2, filter_close_point=False, H=128):
+    """in place: density_grid [C, H^3] = -1 where no training camera sees the cell (renderer.py:482-554)"""
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    poses = _gpu(torch.as_tensor(poses)).float().contiguous()
+    _backend.mark_untrained_grid(poses, poses.shape[0], fx, fy, cx, cy, density_grid.shape[0], H, bound, min_near,
+                                 filter_close_point, density_grid)
+    return density_grid

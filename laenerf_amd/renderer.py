@@ -4,7 +4,12 @@ NeRFRenderer.run_cuda / run_cuda_distill (nerf/renderer.py:259-392, 394-480) on 
 It exists so the repo's own tests and bench.py can exercise the hot path end to end without the
 reference checkout; with the reference present, its unmodified nerf/renderer.py drives the same
 operators instead.  State kept like the reference: aabb_train/aabb_infer,
-density_bitfield [C*128^3/8] uint8, step_counter [16,2] int32 ring, mean_count, local_step.
+density_grid [C,128^3] fp32 (Morton order), density_bitfield [C*128^3/8] uint8, step_counter [16,2] int32 ring,
+mean_density, iter_density, mean_count, local_step.
+
+Also here: `run` (uniform sampling + optional importance resampling, renderer.py:128-256, `sample_pdf` :12-46) and
+the occupancy-grid maintenance `mark_untrained_grid` / `update_extra_state` (renderer.py:482-649) on the
+density-grid kernels of csrc/densitygrid.hip.
 """
 import math
 
@@ -14,8 +19,30 @@ import torch.nn as nn
 from . import raymarching
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """inverse-CDF resampling of NeRF (renderer.py:12-46): bins [B,T], weights [B,T-1] -> [B,n_samples]"""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)                 # [B,T]
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(*cdf.shape[:-1], n_samples)
+    else:
+        u = torch.rand(*cdf.shape[:-1], n_samples, device=weights.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    bin_lo, bin_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    denom = cdf_hi - cdf_lo
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return bin_lo + (u - cdf_lo) / denom * (bin_hi - bin_lo)
+
+
 class NeRFRenderer(nn.Module):
-    def __init__(self, model, bound=1, min_near=0.2, density_scale=1, grid_size=128):
+    def __init__(self, model, bound=1, min_near=0.2, density_scale=1, grid_size=128, density_thresh=0.01,
+                 filter_close_point=False):
         super().__init__()
         self.model = model
         self.bound = bound
@@ -26,10 +53,78 @@ class NeRFRenderer(nn.Module):
         aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
         self.register_buffer("aabb_train", aabb)
         self.register_buffer("aabb_infer", aabb.clone())
+        self.density_thresh = density_thresh
+        self.filter_close_point = filter_close_point
+        self.register_buffer("density_grid", torch.zeros(self.cascade, grid_size ** 3))              # renderer.py:92-94
         self.register_buffer("density_bitfield", torch.zeros(self.cascade * grid_size ** 3 // 8, dtype=torch.uint8))
+        self.register_buffer("_grid_tmp", torch.zeros(grid_size ** 3, dtype=torch.int32), persistent=False)
+        self.mean_density = 0
+        self.iter_density = 0
         self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
         self.mean_count = 0
         self.local_step = 0
+
+    def reset_extra_state(self):
+        """renderer.py:115-126"""
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    def density(self, x):
+        return self.model.density(x)
+
+    # ------------------------------------------------------------------ occupancy-grid maintenance
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic):
+        """cells no training camera covers get density -1 and are never sampled (renderer.py:482-554).
+        poses [B,4,4] camera-to-world, intrinsic (fx, fy, cx, cy).  One kernel, poses staged through LDS."""
+        raymarching.mark_untrained_grid(self.density_grid, poses, intrinsic, self.bound, self.min_near,
+                                        self.filter_close_point, self.grid_size)
+        return int((self.density_grid < 0).sum().item())
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, rng=None):
+        """EMA-max refresh of the density grid + bitfield + mean_count (renderer.py:555-649).
+
+        First 16 calls: every cell of every cascade is queried at a jittered position; afterwards H^3/4 uniformly
+        random cells plus as many draws from the occupied cells.  `rng` (tests) replaces torch's generators:
+        an object with rand(n, 3) -> [n,3] in [0,1) and randint(high, shape) -> int64.
+        Per cascade: positions kernel -> grid encode -> fused sigma head -> scatter-max + EMA kernels.
+        """
+        H, dev = self.grid_size, self.density_grid.device
+        rand = (lambda n: torch.rand(n, 3, device=dev)) if rng is None else (lambda n: rng.rand(n, 3).to(dev))
+        randint = (lambda high, shape: torch.randint(0, high, shape, device=dev)) if rng is None else \
+            (lambda high, shape: rng.randint(high, shape).to(dev))
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            for cas in range(self.cascade):
+                bound_c = min(2 ** cas, self.bound)
+                if self.iter_density < 16:
+                    n = H ** 3
+                    xyzs, indices = raymarching.density_grid_positions(n, H, bound_c, noise=rand(n))
+                else:
+                    n = H ** 3 // 4
+                    coords = randint(H, (n, 3)).int()
+                    occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                    if occ.numel() > 0:
+                        occ = occ[randint(occ.shape[0], (n,))]
+                        coords = torch.cat([coords, raymarching.morton3D_invert(occ.int())], dim=0)
+                    xyzs, indices = raymarching.density_grid_positions(coords.shape[0], H, bound_c,
+                                                                       noise=rand(coords.shape[0]), coords=coords)
+                sigmas = self.density(xyzs)["sigma"].reshape(-1).float()      # caller's autocast state, like the reference
+                raymarching.density_grid_update(self.density_grid[cas], sigmas, indices, self._grid_tmp,
+                                                self.density_scale, decay)
+        finally:
+            self.model.train(was_training)
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        self.update_mean_count()
 
     def update_mean_count(self):
         """the mean_count refresh of update_extra_state (renderer.py:644-647); one D2H read every 16 steps"""
@@ -37,6 +132,58 @@ class NeRFRenderer(nn.Module):
         if total_step > 0:
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
         self.local_step = 0
+
+    # ------------------------------------------------------------------ uniform-sampling render (renderer.py:128-256)
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False):
+        """the reference's non-occupancy-grid path: `num_steps` uniform samples in [near, far] (+ `upsample_steps`
+        importance samples), density for all, colour only where the weight exceeds 1e-4, cumprod compositing."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        sample_dist = (fars - nears) / num_steps
+        z_vals = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0)   # [N,T]
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        def points(z):
+            p = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(p, aabb[:3]), aabb[3:])
+
+        def weights_of(z, sigma):
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+            trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1), dim=-1)
+            return alphas * trans[..., :-1], deltas
+
+        xyzs = points(z_vals)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+        if upsample_steps > 0:
+            with torch.no_grad():
+                w, deltas = weights_of(z_vals, dens["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, w[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = points(new_z)
+            new_dens = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
+            xyzs = torch.gather(xyzs, 1, order.unsqueeze(-1).expand_as(xyzs))
+            for k in dens:
+                both = torch.cat([dens[k], new_dens[k]], dim=1)
+                dens[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+        weights, _ = weights_of(z_vals, dens["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        flat = {k: v.reshape(-1, v.shape[-1]) for k, v in dens.items()}
+        mask = weights > 1e-4
+        rgbs = self.model.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        image = image + (1 - weights_sum).unsqueeze(-1) * (1 if bg_color is None else bg_color)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
 
     # ------------------------------------------------------------------ training render (renderer.py:285-334)
     def render_train(self, rays_o, rays_d, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024,

@@ -886,3 +886,83 @@ ORC_API void orc_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, co
     for (size_t i = 0; i < nW; i++) grad_weights[i] = f32_to_f16_bits(dW[i]);
     free(W); free(dW); free(g); free(gp);
 }
+
+/* ================================================================== occupancy-grid maintenance
+ * Sequential restatement of the Python in nerf/renderer.py:482-649 around the density query.  Pinned by
+ * tests/golden/density_grid.npz: the reference's own mark_untrained_grid / update_extra_state executed here on CPU
+ * (tests/golden/make_golden.py), with the RNG draws recorded so the same noise can be replayed. */
+
+/* renderer.py:580-592 / 602-621: point -> jittered position + Morton index (coords NULL = meshgrid order) */
+ORC_API void orc_density_grid_positions(const int32_t* coords, uint32_t n, uint32_t H, float bound_c, const float* noise,
+                                        float* xyzs, int32_t* indices) {
+    const float hgs = bound_c / (float)H, scale = bound_c - hgs, hm1 = (float)(H - 1);
+    for (uint32_t j = 0; j < n; j++) {
+        int32_t c[3];
+        if (coords) { c[0] = coords[3 * (size_t)j]; c[1] = coords[3 * (size_t)j + 1]; c[2] = coords[3 * (size_t)j + 2]; }
+        else { c[0] = (int32_t)(j / (H * H)); c[1] = (int32_t)((j / H) % H); c[2] = (int32_t)(j % H); }
+        for (int k = 0; k < 3; k++) {
+            float p = ((2.0f * (float)c[k]) / hm1 - 1.0f) * scale;
+            if (noise) p = p + (noise[3 * (size_t)j + k] * 2.0f - 1.0f) * hgs;
+            xyzs[3 * (size_t)j + k] = p;
+        }
+        indices[j] = (int32_t)morton3((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+    }
+}
+
+/* renderer.py:596/627 + 633-634.  rule 0: the last write wins where indices repeat (what torch's CPU index_put_
+ * does, i.e. what the golden vectors hold); rule 1: the maximum wins (the HIP kernel's deterministic choice --
+ * one of the outcomes the reference's GPU scatter can produce). */
+ORC_API void orc_density_grid_update(const float* sigmas, const int32_t* indices, uint32_t n, float density_scale, float decay,
+                                     uint32_t cells, float* grid, int rule) {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)cells);
+    for (uint32_t i = 0; i < cells; i++) tmp[i] = -1.0f;
+    for (uint32_t j = 0; j < n; j++) {
+        const uint32_t idx = (uint32_t)indices[j];
+        const float v = sigmas[j] * density_scale;
+        if (idx >= cells) continue;
+        if (rule == 0) tmp[idx] = v;
+        else if (v >= 0.0f && v > tmp[idx]) tmp[idx] = v;
+    }
+    for (uint32_t i = 0; i < cells; i++)
+        if (grid[i] >= 0.0f && tmp[i] >= 0.0f) grid[i] = fmaxf(grid[i] * decay, tmp[i]);
+    free(tmp);
+}
+
+/* renderer.py:482-554.  margin_out (optional, [C*H^3]) receives the smallest distance of any frustum test from its
+ * decision boundary, so a test can exclude cells whose verdict depends on the rounding of the 3x3 product. */
+ORC_API void orc_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C,
+                                     uint32_t H, float bound, float min_near, int filter_close_point, float* grid,
+                                     float* margin_out) {
+    const uint32_t cells = H * H * H;
+    const float kx = (float)((double)cx / (double)fx), ky = (float)((double)cy / (double)fy), hm1 = (float)(H - 1);
+    for (uint32_t cas = 0; cas < C; cas++) {
+        const float bound_c = fminf((float)(1u << cas), bound), hgs = bound_c / (float)H, margin = hgs * 2.0f;
+        for (uint32_t j = 0; j < cells; j++) {
+            const int32_t c[3] = {(int32_t)(j / (H * H)), (int32_t)((j / H) % H), (int32_t)(j % H)};
+            float w[3];
+            for (int k = 0; k < 3; k++) w[k] = ((2.0f * (float)c[k]) / hm1 - 1.0f) * (bound_c - hgs);
+            uint32_t count = 0, close = 0;
+            float closest = INFINITY;
+            for (uint32_t b = 0; b < B; b++) {
+                const float* Q = poses + (size_t)b * 16;
+                const float dx = w[0] - Q[3], dy = w[1] - Q[7], dz = w[2] - Q[11];
+                const float px = dx * Q[0] + dy * Q[4] + dz * Q[8];
+                const float py = dx * Q[1] + dy * Q[5] + dz * Q[9];
+                const float pz = dx * Q[2] + dy * Q[6] + dz * Q[10];
+                const int in = (pz > 0.0f) && (fabsf(px) < kx * pz + margin) && (fabsf(py) < ky * pz + margin);
+                count += (uint32_t)in;
+                close += (uint32_t)(in && pz < min_near);
+                const float nrm = sqrtf(px * px + py * py + pz * pz);
+                if (filter_close_point) close += (uint32_t)(nrm < min_near);
+                closest = fminf(closest, fabsf(pz));
+                closest = fminf(closest, fabsf(fabsf(px) - (kx * pz + margin)));
+                closest = fminf(closest, fabsf(fabsf(py) - (ky * pz + margin)));
+                closest = fminf(closest, fabsf(pz - min_near));
+                if (filter_close_point) closest = fminf(closest, fabsf(nrm - min_near));
+            }
+            const size_t cell = (size_t)cas * cells + morton3((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+            if (count == 0 || close != 0) grid[cell] = -1.0f;
+            if (margin_out) margin_out[cell] = closest;
+        }
+    }
+}

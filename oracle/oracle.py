@@ -304,3 +304,34 @@ def ffmlp_backward(grad_h, inputs_h, weights_h, forward_buffer, input_dim, outpu
                              u32(output_dim), u32(hidden_dim), u32(num_layers), u32(activation),
                              i32c(int(calc_grad_inputs)), _p(bb), _p(gi), _p(gw))
     return gw, gi, bb
+
+
+# ---------------------------------------------------------------- occupancy-grid maintenance (renderer.py:482-649)
+def density_grid_positions(n, H, bound_c, noise=None, coords=None):
+    xyzs = np.empty((n, 3), np.float32)
+    idx = np.empty(n, np.int32)
+    coords = None if coords is None else _i32(coords)
+    noise = None if noise is None else _f32(noise)
+    lib().orc_density_grid_positions(None if coords is None else _p(coords), u32(n), u32(H), f32c(bound_c),
+                                     None if noise is None else _p(noise), _p(xyzs), _p(idx))
+    return xyzs, idx
+
+
+def density_grid_update(grid_c, sigmas, indices, density_scale=1.0, decay=0.95, rule=0):
+    """-> updated copy of one cascade's grid; rule 0 = last write wins (torch CPU), 1 = maximum wins (HIP kernel)"""
+    g = _f32(grid_c).copy()
+    sigmas, indices = _f32(sigmas), _i32(indices)
+    lib().orc_density_grid_update(_p(sigmas), _p(indices), u32(sigmas.size), f32c(density_scale), f32c(decay), u32(g.size),
+                                  _p(g), ctypes.c_int(rule))
+    return g
+
+
+def mark_untrained_grid(grid, poses, intrinsics, bound, min_near=0.2, filter_close_point=False, H=128):
+    """grid [C, H^3] -> (marked copy, per-cell distance of the closest test from its decision boundary)"""
+    g = _f32(grid).copy()
+    poses = _f32(poses)
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    margin = np.empty(g.shape, np.float32)
+    lib().orc_mark_untrained_grid(_p(poses), u32(poses.shape[0]), f32c(fx), f32c(fy), f32c(cx), f32c(cy), u32(g.shape[0]),
+                                  u32(H), f32c(bound), f32c(min_near), ctypes.c_int(int(filter_close_point)), _p(g), _p(margin))
+    return g, margin

@@ -84,6 +84,7 @@ import raymarching  # noqa: E402  (reference wrappers)
 from nerf.network import NeRFNetwork as LinearNet  # noqa: E402
 from nerf.network_ff import NeRFNetwork as FFNet  # noqa: E402
 from nerf.renderer import NeRFRenderer  # noqa: E402
+import nerf.renderer as ref_renderer  # noqa: E402
 
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from laenerf_amd import synthetic as S  # noqa: E402  (numpy-only generators)
@@ -264,6 +265,87 @@ def gen_e2e(tag, bound):
     save("e2e_" + tag, **out)
 
 
+def gen_run_upsample():
+    """`run` with importance resampling (sample_pdf, det=True in eval mode), renderer.py:170-207"""
+    o, d = S.lego_like_rays(96, seed=6)
+    r = AnalyticField(bound=1, cuda_ray=False, min_near=0.2).eval()
+    with torch.no_grad():
+        res = r.run(torch.from_numpy(o)[None], torch.from_numpy(d)[None], num_steps=48, upsample_steps=32, bg_color=1, perturb=False)
+    g = torch.Generator().manual_seed(4)
+    bins = torch.sort(torch.rand(7, 20, generator=g), dim=-1)[0]
+    w = torch.rand(7, 19, generator=g) ** 3
+    save("run_upsample", rays_o=o, rays_d=d, image=res["image"][0].numpy(), depth=res["depth"][0].numpy(),
+         weights_sum=res["weights_sum"].numpy(), num_steps=np.int64(48), upsample_steps=np.int64(32),
+         pdf_bins=bins.numpy(), pdf_weights=w.numpy(), pdf_samples=ref_renderer.sample_pdf(bins, w, 16, det=True).numpy())
+
+
+# ---------------------------------------------------------------- E2. occupancy-grid maintenance (renderer.py:482-649)
+def look_at_poses(n, radius, seed):
+    """camera-to-world [n,4,4]: cameras on a sphere looking at the origin, +z forward (the convention of
+    mark_untrained_grid: a point is in front when its camera-space z is positive)"""
+    rng = np.random.default_rng(seed)
+    P = np.zeros((n, 4, 4), np.float32)
+    for i in range(n):
+        p = rng.standard_normal(3); p = p / np.linalg.norm(p) * radius
+        f = -p / np.linalg.norm(p)
+        up = np.array([0, 0, 1.0]) if abs(f[2]) < 0.9 else np.array([0, 1.0, 0])
+        r = np.cross(up, f); r /= np.linalg.norm(r)
+        u = np.cross(f, r)
+        P[i, :3, 0], P[i, :3, 1], P[i, :3, 2], P[i, :3, 3], P[i, 3, 3] = r, u, f, p, 1
+    return P
+
+
+def gen_density_grid():
+    bound, H = 2, 16
+    C = 2
+    net = make_ff_net(bound, seed=23)
+    net.grid_size = H
+    net.density_grid = torch.zeros(C, H ** 3)
+    net.density_bitfield = torch.zeros(C * H ** 3 // 8, dtype=torch.uint8)
+    net.train()
+    out = dict(table=net.encoder.embeddings.detach().numpy(), offsets=net.encoder.offsets.numpy(),
+               pls=np.float64(net.encoder.per_level_scale), sigma_w=net.sigma_net.weights.detach().numpy(),
+               color_w=net.color_net.weights.detach().numpy(), bound=np.float64(bound), H=np.int64(H))
+    poses = look_at_poses(5, 1.3, seed=2)
+    intr = np.array([40.0, 40.0, 16.0, 16.0])
+    net.mark_untrained_grid(poses, intr)
+    out.update(poses=poses, intrinsics=intr, grid_marked=net.density_grid.numpy().copy())
+
+    rec = {"rand": [], "randint": [], "sigma": []}
+    real_rand_like, real_randint, real_density = torch.rand_like, torch.randint, net.density
+
+    def rand_like(t, **kw):
+        r = real_rand_like(t, **kw); rec["rand"].append(r.numpy().copy()); return r
+
+    def randint(*a, **kw):
+        r = real_randint(*a, **kw); rec["randint"].append(r.numpy().copy()); return r
+
+    def density(x):
+        o = real_density(x); rec["sigma"].append(o["sigma"].detach().numpy().copy()); return o
+
+    torch.manual_seed(31)
+    torch.rand_like, torch.randint, net.density = rand_like, randint, density
+    try:
+        net.update_extra_state()                                   # iter_density 0: full sweep
+        for c in range(C):
+            out[f"full_noise{c}"], out[f"full_sigma{c}"] = rec["rand"][c], rec["sigma"][c]
+        out.update(full_grid=net.density_grid.numpy().copy(), full_bitfield=net.density_bitfield.numpy().copy(),
+                   full_mean=np.float64(net.mean_density))
+        rec["rand"].clear(); rec["randint"].clear(); rec["sigma"].clear()
+        net.iter_density = 16                                      # partial sweep
+        net.local_step = 3
+        net.step_counter[:3, 0] = torch.tensor([1000, 1200, 1100], dtype=torch.int32)
+        net.update_extra_state()
+        for c in range(C):
+            out[f"part_coords{c}"], out[f"part_pick{c}"] = rec["randint"][2 * c], rec["randint"][2 * c + 1]
+            out[f"part_noise{c}"], out[f"part_sigma{c}"] = rec["rand"][c], rec["sigma"][c]
+        out.update(part_grid=net.density_grid.numpy().copy(), part_bitfield=net.density_bitfield.numpy().copy(),
+                   part_mean=np.float64(net.mean_density), part_mean_count=np.int64(net.mean_count))
+    finally:
+        torch.rand_like, torch.randint, net.density = real_rand_like, real_randint, real_density
+    save("density_grid", **out)
+
+
 # ---------------------------------------------------------------- F. operator-level vectors under the reference's wrappers
 def gen_ops():
     """small vectors produced THROUGH the reference's Python wrappers (shape/padding/alignment rules of
@@ -303,3 +385,5 @@ if __name__ == "__main__":
     gen_ops()
     gen_e2e("b1", 1)
     gen_e2e("b2", 2)
+    gen_run_upsample()
+    gen_density_grid()
