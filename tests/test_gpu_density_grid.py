@@ -19,9 +19,9 @@ def test_positions_bit_exact(O, H, bound_c):
     xyz, idx = rm.density_grid_positions(n, H, bound_c, noise=T(noise))
     rx, ri = O.density_grid_positions(n, H, bound_c, noise=noise)
     assert np.array_equal(N(xyz), rx) and np.array_equal(N(idx), ri)
-    coords = rng.integers(0, H, (5000, 3)).astype(np.int32)
-    xyz, idx = rm.density_grid_positions(5000, H, bound_c, noise=T(noise[:5000]), coords=T(coords))
-    rx, ri = O.density_grid_positions(5000, H, bound_c, noise=noise[:5000], coords=coords)
+    coords = rng.integers(0, H, (3000, 3)).astype(np.int32)
+    xyz, idx = rm.density_grid_positions(3000, H, bound_c, noise=T(noise[:3000]), coords=T(coords))
+    rx, ri = O.density_grid_positions(3000, H, bound_c, noise=noise[:3000], coords=coords)
     assert np.array_equal(N(xyz), rx) and np.array_equal(N(idx), ri)
     xyz, idx = rm.density_grid_positions(n, H, bound_c)                  # no jitter: cell centres
     rx, _ = O.density_grid_positions(n, H, bound_c)
@@ -143,7 +143,9 @@ def test_run_path_matches_reference(name):
         res = r.run(T(g["rays_o"])[None], T(g["rays_d"])[None], num_steps=int(g["num_steps"]), upsample_steps=ups, bg_color=1)
     tol = 2e-5 if ups == 0 else 5e-4        # resampling amplifies last-ulp differences of exp/cumsum between CPU and GPU
     assert np.abs(N(res["image"][0]) - g["image"]).max() < tol
-    assert np.abs(N(res["depth"][0]) - g["depth"]).max() < tol
+    dep = N(res["depth"][0])
+    assert np.array_equal(np.isnan(dep), np.isnan(g["depth"]))            # rays missing the box: (z - near) / (far - near) = 0/0
+    assert np.nanmax(np.abs(dep - g["depth"])) < tol
     assert np.abs(N(res["weights_sum"]) - g["weights_sum"]).max() < tol
 
 
