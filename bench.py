@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
+    p.add_argument("--torch-optimizer", action="store_true",
+                   help="A/B: torch.optim.Adam(fused) + torch.amp.GradScaler instead of laenerf_amd.optim.FusedAdam")
     return p.parse_args()
 
 
@@ -134,9 +136,14 @@ def main():
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
     r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
     r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-    opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True,
-                           capturable=not args.no_graph)                                   # main_nerf.py:223
-    scaler = torch.amp.GradScaler("cuda")
+    # main_nerf.py:223 + nerf/utils.py:1474-1482: Adam(betas=(0.9, 0.99), eps=1e-15) under a GradScaler.  Default: the
+    # same arithmetic as three HIP kernels that also keep the encoder's fp16 table and gradient buffer (optim.py).
+    if args.torch_optimizer:
+        opt = torch.optim.Adam(net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=not args.no_graph)
+        scaler = torch.amp.GradScaler("cuda")
+    else:
+        from laenerf_amd.optim import FusedAdam
+        opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     n_batches = 16
     batches = []
     for b in range(n_batches):
@@ -151,13 +158,22 @@ def main():
             loss = torch.nn.functional.mse_loss(res["image"], gt)
         scaler.scale(loss).backward()
         if not args.no_optimizer:
-            scaler.step(opt)
-            scaler.update()
+            if args.torch_optimizer:
+                scaler.step(opt)
+                scaler.update()
+            else:
+                opt.step()
         return res["n_samples"]
+
+    def zero_grad():
+        if args.torch_optimizer:
+            opt.zero_grad(set_to_none=True)
+        elif args.no_optimizer:
+            opt.zero_grad()                                # FusedAdam.step() zeroes what it consumes
 
     def step(i):
         o, d, gt = batches[i % n_batches]
-        opt.zero_grad(set_to_none=True)
+        zero_grad()
         return step_body(o, d, gt)
 
     # warm-up: the first 16 steps run in the reference's "mean_count <= 0" mode (sized by a D2H read), then the
@@ -173,29 +189,30 @@ def main():
     # Steady state has static shapes (sample buffers are sized by mean_count, renderer.py:644-646), no host sync,
     # a fused capturable Adam and device-side GradScaler, so the ~100 launches of one step are captured once into a
     # HIP graph and replayed: the eager step is bound by host launch overhead (~15 us per launch), not by the GPU.
+    # One graph per resident ray batch (the batches already live in HBM, so a replay reads them in place); the graphs
+    # share one memory pool because they never run concurrently.
     graph = None
     if not args.no_graph:
-        so, sd, sgt = (torch.empty_like(t) for t in batches[0])
-        for t, b in zip((so, sd, sgt), batches[0]):
-            t.copy_(b)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations, workspaces)
             for _ in range(3):
-                opt.zero_grad(set_to_none=True)
-                step_body(so, sd, sgt)
+                zero_grad()
+                step_body(*batches[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            n_graph_samples = step_body(so, sd, sgt)
+        graphs, n_graph_samples = [], []
+        for b in range(n_batches):
+            zero_grad()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None):
+                n_graph_samples.append(step_body(*batches[b]))
+            graphs.append(g)
+        graph = graphs[0]
 
         def step(i):                                        # noqa: F811  (replaces the eager step)
-            o, d, gt = batches[i % n_batches]
-            so.copy_(o); sd.copy_(d); sgt.copy_(gt)
-            graph.replay()
-            return n_graph_samples
+            graphs[i % n_batches].replay()
+            return n_graph_samples[i % n_batches]
         for i in range(5):
             step(i)
     backend.enable_kernel_timing(not graph)
@@ -220,7 +237,7 @@ def main():
     n_diag = 20
     for i in range(n_diag):
         o, d, gt = batches[i % n_batches]
-        opt.zero_grad(set_to_none=True)
+        zero_grad()
         step_body(o, d, gt)
     timing_all = backend.collect_kernel_timing()
     backend.enable_kernel_timing(False)

@@ -278,6 +278,23 @@ LAE_API int lae_density_grid_update(const float* sigmas, const int32_t* indices,
 LAE_API int lae_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H,
                             float bound, float min_near, int filter_close_point, float* grid, void* stream);
 
+/* ---- fused Adam + GradScaler (torch.optim.Adam / torch.cuda.amp.GradScaler in the reference: main_nerf.py:223,
+ * nerf/utils.py:1474-1482).  `state` is a 64-byte device block:
+ *   [0] f32 scale  [1] i32 growth_tracker  [2] i32 found_inf  [3] i32 skip  [4] i32 step  [5] f32 1/(1-beta1^step)
+ *   [6] f32 sqrt(1-beta2^step)  [7] f32 1/scale of this step  [8] i32 skipped steps  [9..15] reserved.
+ * Per step: lae_adam_check on every gradient, ONE lae_adam_begin, lae_adam_apply on every parameter.
+ * check: found_inf |= any non-finite element (grad fp16 or fp32, 16-byte aligned). */
+LAE_API int lae_adam_check(const void* grad, int grad_is_half, uint64_t n, void* state, void* stream);
+/* begin: found_inf -> skip (scale *= backoff, tracker = 0) or step += 1 with bias corrections (double precision) and
+ * scale growth after `growth_interval` finite steps (grad_scaler.py _amp_update_scale_).  use_scaler = 0: plain Adam. */
+LAE_API int lae_adam_begin(void* state, float beta1, float beta2, int growth_interval, float growth_factor, float backoff_factor,
+                   int use_scaler, void* stream);
+/* apply: g = grad / scale; Adam update of param / exp_avg / exp_avg_sq (fp32, torch.optim.Adam formulas); optional fp16
+ * copy of the new parameters into shadow_half (the table the grid encoder gathers from); grad is zeroed.  lr is read
+ * from device memory.  On a skipped step only the gradient is zeroed. */
+LAE_API int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void* grad, int grad_is_half, void* shadow_half, uint64_t n,
+                   const void* state, const float* lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the
  * three-kernel path that fills both buffers exactly like the reference. */

@@ -1,0 +1,186 @@
+// optimizer.hip -- fused Adam + GradScaler for the NeRF parameters on gfx950.
+//
+// The reference trains with torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler
+// (main_nerf.py:223, nerf/utils.py:1474-1482).  Around the 12.2 M-parameter hash table that is, per step: a 25 MB
+// zero fill of the fp16 gradient, a fp16->fp32 gradient cast, an unscale pass, the multi-tensor Adam passes and a
+// fp32->fp16 cast of the table for the next forward (~575 MB of HBM traffic in ~20 launches).  Here:
+//   k_check   any non-finite gradient?                                  (reads the fp16 gradient once)
+//   k_begin   one thread: skip/step decision, bias corrections in double, scale growth/backoff (GradScaler.update)
+//   k_apply   one pass: unscale, Adam, write p/m/v, write the fp16 shadow table the encoder gathers from,
+//             zero the gradient buffer for the next accumulation       (30 B per parameter)
+// All state lives on the device (OptState), so the whole step is HIP-graph capturable.
+#include "lae_common.h"
+#include <hip/hip_fp16.h>
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+namespace {
+
+typedef _Float16 half_t;
+
+struct OptState {          // 16 words, see include/laenerf.h
+    float scale;           // 0  current loss scale
+    int32_t growth_tracker;// 1  consecutive finite steps
+    int32_t found_inf;     // 2  accumulator written by k_check
+    int32_t skip;          // 3  decision for k_apply
+    int32_t step;          // 4  number of optimizer steps taken
+    float inv_bc1;         // 5  1 / (1 - beta1^step)
+    float bc2_sqrt;        // 6  sqrt(1 - beta2^step)
+    float inv_scale;       // 7  1 / scale used by this step's gradients
+    int32_t skipped_total; // 8  number of skipped steps (diagnostics)
+    int32_t pad[7];
+};
+
+template <typename G> __device__ __forceinline__ float ldg(const G* g, size_t i) { return (float)g[i]; }
+
+template <typename G>
+__global__ __launch_bounds__(256) void k_check(const G* __restrict__ grad, size_t n, OptState* __restrict__ st) {
+    bool bad = false;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            if constexpr (sizeof(G) == 2) {
+                const uint4 v = *reinterpret_cast<const uint4*>(grad + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) bad |= ((w[k] & 0x7c00u) == 0x7c00u) || ((w[k] & 0x7c000000u) == 0x7c000000u);   // exponent all ones
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(grad + i), b = *reinterpret_cast<const float4*>(grad + i + 4);
+                bad |= !isfinite(a.x) || !isfinite(a.y) || !isfinite(a.z) || !isfinite(a.w) || !isfinite(b.x) || !isfinite(b.y) ||
+                       !isfinite(b.z) || !isfinite(b.w);
+            }
+        } else {
+            for (size_t j = i; j < n; j++) bad |= !isfinite(ldg(grad, j));
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->found_inf, 1);
+}
+
+// GradScaler.step + update (torch/amp/grad_scaler.py) and the scalar part of Adam (torch/optim/adam.py, non-capturable
+// formulas: bias corrections from beta ** step evaluated in double)
+__global__ void k_begin(OptState* __restrict__ st, float beta1, float beta2, int growth_interval, float growth, float backoff,
+                        int use_scaler) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool bad = use_scaler && st->found_inf != 0;
+    st->found_inf = 0;
+    st->skip = bad;
+    st->inv_scale = use_scaler ? (float)(1.0 / (double)st->scale) : 1.0f;
+    if (bad) {
+        st->scale = st->scale * backoff;
+        st->growth_tracker = 0;
+        st->skipped_total += 1;
+        return;
+    }
+    st->step += 1;
+    st->inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)st->step)));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st->step));
+    if (use_scaler) {
+        st->growth_tracker += 1;
+        if (st->growth_tracker == growth_interval) { st->scale = st->scale * growth; st->growth_tracker = 0; }
+    }
+}
+
+struct AdamHyper { float beta1, beta2, eps, weight_decay; };
+
+__device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, float lr_over_bc1, float bc2_sqrt, const AdamHyper& h) {
+    if (h.weight_decay != 0.0f) g = g + h.weight_decay * p;                 // adam.py: grad.add(param, alpha=weight_decay)
+    m = m + (g - m) * (1.0f - h.beta1);                                     // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * h.beta2 + (1.0f - h.beta2) * (g * g);                           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + h.eps;                        // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - lr_over_bc1 * (m / denom);                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+template <typename G>
+__global__ __launch_bounds__(256) void k_apply(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                               G* __restrict__ grad, half_t* __restrict__ shadow, size_t n,
+                                               const OptState* __restrict__ st, const float* __restrict__ lr_ptr, AdamHyper h) {
+    const bool skip = st->skip != 0;
+    const float inv_scale = st->inv_scale, bc2_sqrt = st->bc2_sqrt;
+    const float lr_over_bc1 = (float)((double)lr_ptr[0] * (double)st->inv_bc1);     // step_size = lr / bias_correction1
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float g[4];
+            if constexpr (sizeof(G) == 2) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(grad + i);
+                const half_t* gh = reinterpret_cast<const half_t*>(&raw);
+#pragma unroll
+                for (int k = 0; k < 4; k++) g[k] = (float)gh[k];
+                *reinterpret_cast<uint2*>(grad + i) = uint2{0u, 0u};
+            } else {
+                const float4 raw = *reinterpret_cast<const float4*>(grad + i);
+                g[0] = raw.x; g[1] = raw.y; g[2] = raw.z; g[3] = raw.w;
+                *reinterpret_cast<float4*>(grad + i) = float4{0, 0, 0, 0};
+            }
+            if (skip) continue;
+            float4 pp = *reinterpret_cast<const float4*>(p + i), mm = *reinterpret_cast<const float4*>(m + i),
+                   vv = *reinterpret_cast<const float4*>(v + i);
+            adam1(pp.x, mm.x, vv.x, g[0] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.y, mm.y, vv.y, g[1] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.z, mm.z, vv.z, g[2] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.w, mm.w, vv.w, g[3] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+            if (shadow) {
+                half_t s[4] = {(half_t)pp.x, (half_t)pp.y, (half_t)pp.z, (half_t)pp.w};
+                *reinterpret_cast<uint2*>(shadow + i) = *reinterpret_cast<const uint2*>(s);
+            }
+        } else {
+            for (size_t j = i; j < n; j++) {
+                const float gj = ldg(grad, j) * inv_scale;
+                grad[j] = (G)0.0f;
+                if (skip) continue;
+                float pj = p[j], mj = m[j], vj = v[j];
+                adam1(pj, mj, vj, gj, lr_over_bc1, bc2_sqrt, h);
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (shadow) shadow[j] = (half_t)pj;
+            }
+        }
+    }
+}
+
+uint32_t stream_blocks(size_t n, int per_thread) {
+    const size_t want = (n + 256ull * per_thread - 1) / (256ull * per_thread);
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (size_t)lae::num_cus() * 16));
+}
+
+}  // namespace
+
+extern "C" {
+
+int lae_adam_check(const void* grad, int grad_is_half, uint64_t n, void* state, void* stream) {
+    if (n == 0) return LAE_OK;
+    if (!grad || !state) return LAE_ENULL;
+    if ((reinterpret_cast<uintptr_t>(grad) & 15) != 0) return LAE_EINVAL;
+    OptState* st = reinterpret_cast<OptState*>(state);
+    if (grad_is_half) k_check<half_t><<<stream_blocks(n, 8), 256, 0, STREAM(stream)>>>((const half_t*)grad, n, st);
+    else k_check<float><<<stream_blocks(n, 8), 256, 0, STREAM(stream)>>>((const float*)grad, n, st);
+    return lae::check_launch("adam_check");
+}
+
+int lae_adam_begin(void* state, float beta1, float beta2, int growth_interval, float growth_factor, float backoff_factor,
+                   int use_scaler, void* stream) {
+    if (!state) return LAE_ENULL;
+    k_begin<<<1, 64, 0, STREAM(stream)>>>(reinterpret_cast<OptState*>(state), beta1, beta2, growth_interval, growth_factor,
+                                          backoff_factor, use_scaler);
+    return lae::check_launch("adam_begin");
+}
+
+int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void* grad, int grad_is_half, void* shadow_half, uint64_t n,
+                   const void* state, const float* lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (n == 0) return LAE_OK;
+    if (!param || !exp_avg || !exp_avg_sq || !grad || !state || !lr) return LAE_ENULL;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
+                         reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(shadow_half);
+    if (al & 15) return LAE_EINVAL;
+    const AdamHyper h{beta1, beta2, eps, weight_decay};
+    const OptState* st = reinterpret_cast<const OptState*>(state);
+    if (grad_is_half)
+        k_apply<half_t><<<stream_blocks(n, 4), 256, 0, STREAM(stream)>>>(param, exp_avg, exp_avg_sq, (half_t*)grad, (half_t*)shadow_half, n, st, lr, h);
+    else
+        k_apply<float><<<stream_blocks(n, 4), 256, 0, STREAM(stream)>>>(param, exp_avg, exp_avg_sq, (float*)grad, (half_t*)shadow_half, n, st, lr, h);
+    return lae::check_launch("adam_apply");
+}
+
+}  // extern "C"

@@ -23,7 +23,7 @@ class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False, interpolation=0):
+                align_corners=False, interpolation=0, shadow=None):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -31,8 +31,13 @@ class _grid_encode(Function):
         S = np.log2(per_level_scale)
         H = base_resolution
         # autocast: half-precision table, float coordinates; odd C stays float (grid.py:41-44)
+        ctx.shadow = None
         if torch.is_autocast_enabled("cuda") and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
+            if shadow is not None:                     # fp16 table + fp16 gradient accumulator kept by the fused optimizer
+                embeddings = shadow.table_half(embeddings)
+                ctx.shadow = shadow
+            else:
+                embeddings = embeddings.to(torch.half)
         outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
@@ -50,13 +55,31 @@ class _grid_encode(Function):
         grad = grad.contiguous()                       # [B, L*C], consumed in place by the _blc kernel
         if grad.dtype != embeddings.dtype:
             grad = grad.to(embeddings.dtype)
-        grad_embeddings = torch.zeros_like(embeddings)
+        # with a shadow the gradient is accumulated straight into the optimizer's persistent fp16 buffer (zeroed by the
+        # optimizer after it has consumed it) and autograd sees no gradient for `embeddings`
+        grad_embeddings = ctx.shadow.grad_half if ctx.shadow is not None else torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
                                       grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+        return grad_inputs, (None if ctx.shadow is not None else grad_embeddings), None, None, None, None, None, None, None, None
+
+
+class TableShadow:
+    """fp16 copy of a GridEncoder table + persistent fp16 gradient accumulator, owned by `laenerf_amd.optim.FusedAdam`
+    (replaces the per-step `embeddings.to(half)` of grid.py:43-44 and the `zeros_like` of grid.py:77)"""
+
+    def __init__(self, embeddings):
+        self.half = embeddings.detach().to(torch.half).contiguous()
+        self.grad_half = torch.zeros_like(self.half)
+        self.version = embeddings._version
+
+    def table_half(self, embeddings):
+        if embeddings._version != self.version:        # someone else wrote the fp32 table (load_state_dict, init, ...)
+            self.half.copy_(embeddings.detach())
+            self.version = embeddings._version
+        return self.half
 
 
 grid_encode = _grid_encode.apply
@@ -103,6 +126,7 @@ class GridEncoder(nn.Module):
         self.register_buffer("offsets", torch.from_numpy(offsets))
         self.n_params = int(offsets[-1]) * level_dim
         self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
+        self.shadow = None                                 # TableShadow once a FusedAdam owns the table
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -120,8 +144,15 @@ class GridEncoder(nn.Module):
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
         outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, self.shadow)
         return outputs.view(prefix_shape + [self.output_dim])
+
+    def attach_shadow(self):
+        """called by FusedAdam: keep an fp16 table + gradient accumulator next to the fp32 parameter"""
+        if self.level_dim % 2 != 0 or not self.embeddings.is_cuda:
+            raise RuntimeError("GridEncoder.attach_shadow: needs an even level_dim (fp16 path, grid.py:41-44) on the GPU")
+        self.shadow = TableShadow(self.embeddings)
+        return self.shadow
 
     @torch.amp.autocast("cuda", enabled=False)
     def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):

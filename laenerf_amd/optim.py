@@ -1,0 +1,130 @@
+"""Fused Adam + GradScaler for the NeRF parameters.
+
+The reference's step is `scaler.scale(loss).backward(); scaler.step(Adam); scaler.update()` (nerf/utils.py:1474-1482)
+with `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` (main_nerf.py:223).  `FusedAdam` reproduces exactly that
+arithmetic (same formulas, same skip / backoff / growth rules) in three kernels of csrc/optimizer.hip, keeps all state
+on the device (HIP-graph capturable) and owns, for every `GridEncoder` table, the fp16 shadow the encoder gathers from
+and the fp16 gradient accumulator the encoder's backward adds into:
+
+    opt = FusedAdam(model, lr=1e-2)                    # or FusedAdam(model, param_groups=model.get_params(lr))
+    loss = ...; opt.scale(loss).backward(); opt.step()  # no zero_grad needed: gradients are consumed and zeroed
+
+`state_dict()` / `load_state_dict()` use torch.optim.Adam's layout (`exp_avg`, `exp_avg_sq`, `step`).
+"""
+import torch
+
+from . import _lib
+from .gridencoder import GridEncoder
+
+
+class FusedAdam:
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, param_groups=None,
+                 grad_scaler=True, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        groups = param_groups if param_groups is not None else [{"params": [p for p in model.parameters() if p.requires_grad], "lr": lr}]
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.use_scaler = bool(grad_scaler)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        tables = {id(m.embeddings): m for m in model.modules() if isinstance(m, GridEncoder)}
+        self.param_groups = []
+        self.items = []                                   # (param, exp_avg, exp_avg_sq, shadow or None, group index)
+        dev = None
+        for gi, g in enumerate(groups):
+            params = [p for p in g["params"] if p.requires_grad]
+            self.param_groups.append({"params": params, "lr": float(g.get("lr", lr))})
+            for p in params:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+                dev = p.device
+                shadow = None
+                enc = tables.get(id(p))
+                if enc is not None and enc.level_dim % 2 == 0:
+                    shadow = enc.attach_shadow()
+                else:
+                    p.grad = torch.zeros_like(p)           # persistent fp32 gradient (stable address for graph replay)
+                self.items.append((p, torch.zeros_like(p), torch.zeros_like(p), shadow, gi))
+        # device state block (include/laenerf.h): scale | tracker | found_inf | skip | step | 1/bc1 | sqrt(bc2) | 1/scale | skipped
+        self.state = torch.zeros(16, dtype=torch.int32, device=dev)
+        self._scale_view = self.state.view(torch.float32)
+        self._scale_view[0] = init_scale if self.use_scaler else 1.0
+        self.lrs = torch.tensor([g["lr"] for g in self.param_groups], dtype=torch.float32, device=dev)
+
+    # ---- GradScaler face
+    def scale(self, loss):
+        return loss * self._scale_view[0] if self.use_scaler else loss
+
+    def get_scale(self):
+        return float(self._scale_view[0].item())
+
+    @property
+    def steps_taken(self):
+        return int(self.state[4].item())
+
+    @property
+    def steps_skipped(self):
+        return int(self.state[8].item())
+
+    def set_lr(self, lr, group=None):
+        """learning-rate schedule hook: writes device memory, so a captured graph picks the new value up"""
+        for gi, g in enumerate(self.param_groups):
+            if group is None or gi == group:
+                g["lr"] = float(lr)
+                self.lrs[gi] = float(lr)
+
+    def sync_shadows(self):
+        """re-derive every fp16 shadow table from its fp32 parameter.  In-place writes to a parameter (load_state_dict,
+        `with torch.no_grad(): p.copy_(...)`) are noticed automatically through the tensor version counter; writes
+        through `p.data` are not visible to it -- call this after them."""
+        for p, _, _, shadow, _ in self.items:
+            if shadow is not None:
+                shadow.half.copy_(p.detach())
+                shadow.version = p._version
+
+    def zero_grad(self, set_to_none=False):
+        """gradients are zeroed by step(); provided for Trainer code that calls it anyway"""
+        for p, _, _, shadow, _ in self.items:
+            (shadow.grad_half if shadow is not None else p.grad).zero_()
+
+    def _grad(self, p, shadow):
+        if shadow is not None:
+            return shadow.grad_half, 1
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+            raise RuntimeError("FusedAdam: fp32 contiguous .grad expected")
+        return p.grad, 0
+
+    @torch.no_grad()
+    def step(self):
+        lib, st, s = _lib.load(), self.state.data_ptr(), _lib.stream()
+        if self.use_scaler:
+            for p, _, _, shadow, _ in self.items:
+                g, is_half = self._grad(p, shadow)
+                _lib.check(lib.lae_adam_check(g.data_ptr(), is_half, g.numel(), st, s), "adam_check")
+        _lib.check(lib.lae_adam_begin(st, self.betas[0], self.betas[1], self.growth_interval, self.growth_factor,
+                                      self.backoff_factor, int(self.use_scaler), s), "adam_begin")
+        for p, m, v, shadow, gi in self.items:
+            g, is_half = self._grad(p, shadow)
+            _lib.check(lib.lae_adam_apply(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), is_half,
+                                          None if shadow is None else shadow.half.data_ptr(), p.numel(), st,
+                                          self.lrs.data_ptr() + 4 * gi, self.betas[0], self.betas[1], self.eps,
+                                          self.weight_decay, s), "adam_apply")
+
+    # ---- torch.optim.Adam-compatible checkpoints
+    def state_dict(self):
+        step = self.steps_taken
+        return {"state": {i: {"step": torch.tensor(float(step)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+                          for i, (_, m, v, _, _) in enumerate(self.items)},
+                "param_groups": [{"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+                                 for g in self.param_groups],
+                "scaler": {"scale": self.get_scale(), "growth_tracker": int(self.state[1].item())}}
+
+    def load_state_dict(self, sd):
+        for i, (_, m, v, _, _) in enumerate(self.items):
+            e = sd["state"][i]
+            m.copy_(e["exp_avg"]); v.copy_(e["exp_avg_sq"])
+            self.state[4] = int(e["step"])
+        for gi, g in enumerate(sd.get("param_groups", [])):
+            self.set_lr(g["lr"], gi)
+        if "scaler" in sd:
+            self._scale_view[0] = sd["scaler"]["scale"]
+            self.state[1] = sd["scaler"]["growth_tracker"]
