@@ -94,7 +94,10 @@ LAE_API int lae_packbits(const float* grid, uint32_t N, float density_thresh, ui
  * reference gives exactly this order).  counter[0] += sum(count),
  * counter[1] += N, like the reference's atomicAdds on a pre-zeroed counter.
  * `scratch` : caller-provided device workspace of lae_march_rays_train_scratch_bytes(N)
- * bytes (may be NULL only when N == 0). */
+ * bytes (may be NULL only when N == 0).
+ * Sample rows no ray owns, [rows_end, M), are zero-filled by the kernel itself (the reference relies on the caller's
+ * torch.zeros, raymarching.py:207-209); rows_end is also stored to rows_end_out (device uint32, may be NULL) for
+ * lae_composite_rays_train_backward_blend. */
 LAE_API uint64_t lae_march_rays_train_scratch_bytes(uint32_t N);
 LAE_API int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid,
                          float bound, float dt_gamma, uint32_t max_steps,
@@ -102,7 +105,7 @@ LAE_API int lae_march_rays_train(const float* rays_o, const float* rays_d, const
                          const float* nears, const float* fars,
                          float* xyzs, float* dirs, float* deltas,
                          int32_t* rays, int32_t* counter, const float* noises,
-                         void* scratch, void* stream);
+                         void* scratch, uint32_t* rows_end_out, void* stream);
 
 /* raymarching.cu:580-588 */
 LAE_API int lae_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
@@ -115,6 +118,23 @@ LAE_API int lae_composite_rays_train_backward(const float* grad_weights_sum, con
                                       const int32_t* rays, const float* weights_sum,
                                       const float* image, uint32_t M, uint32_t N, float T_thresh,
                                       float* grad_sigmas, float* grad_rgbs, void* stream);
+
+/* MI355X-native: composite + the post-ops run_cuda applies to its result (nerf/renderer.py:321, 325) in one kernel:
+ *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, min=0) / (fars - nears).
+ * bg = bg_rays [N,3] when non-NULL, else the constant (bg_r, bg_g, bg_b).  weights_sum / depth / image receive the
+ * un-blended values (saved for the backward). */
+LAE_API int lae_composite_rays_train_forward_blend(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                           uint32_t M, uint32_t N, float T_thresh, const float* nears, const float* fars,
+                                           const float* bg_rays, float bg_r, float bg_g, float bg_b, float* weights_sum,
+                                           float* depth, float* image, float* depth_out, float* image_out, void* stream);
+/* Backward of the above w.r.t. (weights_sum, image_out): grad_ws_eff = grad_ws - sum_c grad_image_c * bg_c.  Writes EVERY
+ * row of grad_sigmas / grad_rgbs in [0, M) (zeros after the early stop and in [rows_end, M)), so they need no
+ * pre-zeroing; requires the contiguous ray-id-order sample layout of lae_march_rays_train. */
+LAE_API int lae_composite_rays_train_backward_blend(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                            const float* rgbs, const float* deltas, const int32_t* rays,
+                                            const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                            float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
+                                            const uint32_t* rows_end, float* grad_sigmas, float* grad_rgbs, void* stream);
 
 /* raymarching.cu:929-936 */
 LAE_API int lae_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,

@@ -25,9 +25,11 @@ SIGNATURES = {
     "lae_morton3D_invert": [vp, u32, vp, vp],
     "lae_packbits": [vp, u32, f32, vp, vp],
     "lae_march_rays_train_scratch_bytes": [u32],
-    "lae_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_march_rays_train": [vp, vp, vp, f32, f32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, vp],
+    "lae_composite_rays_train_forward_blend": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays_train_backward_blend": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, f32, f32, f32, vp, vp, vp, vp],
     "lae_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_march_rays_distill": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],

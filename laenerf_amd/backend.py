@@ -108,7 +108,9 @@ class _RayMarching:
 
     @staticmethod
     def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas,
-                         rays, counter, noises):
+                         rays, counter, noises, rows_end=None):
+        """`rows_end` (optional int32[1], MI355X extension): receives the first sample row no ray owns; rows from there
+        to M are zero-filled by the kernel, so xyzs / dirs / deltas may be allocated uninitialised"""
         need_cuda(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
         need_contig(rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
         _need_f32(rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises)
@@ -117,7 +119,7 @@ class _RayMarching:
         ws = _workspace(rays_o.device, lib.lae_march_rays_train_scratch_bytes(N))
         check(lib.lae_march_rays_train(ptr(rays_o), ptr(rays_d), ptr(grid), bound, dt_gamma, max_steps, N, C, H, M,
                                        ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
-                                       ptr(counter), ptr(noises), ptr(ws), stream()), "march_rays_train")
+                                       ptr(counter), ptr(noises), ptr(ws), ptr(rows_end), stream()), "march_rays_train")
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
@@ -127,6 +129,29 @@ class _RayMarching:
         check(_lib.load().lae_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh,
                                                            ptr(weights_sum), ptr(depth), ptr(image), stream()),
               "composite_rays_train_forward")
+
+    @staticmethod
+    def composite_rays_train_forward_blend(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears, fars, bg_rays, bg, weights_sum,
+                                           depth, image, depth_out, image_out):
+        ts = (sigmas, rgbs, deltas, rays, nears, fars, bg_rays, weights_sum, depth, image, depth_out, image_out)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(sigmas, rgbs, deltas, nears, fars, bg_rays, weights_sum, depth, image, depth_out, image_out)
+        check(_lib.load().lae_composite_rays_train_forward_blend(
+            ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh, ptr(nears), ptr(fars), ptr(bg_rays), bg[0], bg[1],
+            bg[2], ptr(weights_sum), ptr(depth), ptr(image), ptr(depth_out), ptr(image_out), stream()),
+            "composite_rays_train_forward_blend")
+
+    @staticmethod
+    def composite_rays_train_backward_blend(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M,
+                                            N, T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs):
+        ts = (grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_sigmas,
+              grad_rgbs)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, bg_rays, grad_sigmas, grad_rgbs)
+        check(_lib.load().lae_composite_rays_train_backward_blend(
+            ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(weights_sum),
+            ptr(image), M, N, T_thresh, ptr(bg_rays), bg[0], bg[1], bg[2], ptr(rows_end), ptr(grad_sigmas), ptr(grad_rgbs),
+            stream()), "composite_rays_train_backward_blend")
 
     @staticmethod
     def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
@@ -336,7 +361,8 @@ class _FFMLP:
 _timing = {"on": False, "only": None, "events": []}
 _UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "ffmlp_forward": 2, "ffmlp_inference": 2,
           "ffmlp_backward": 4, "nerf_head_forward": 4, "nerf_head_backward": 8, "nerf_density_forward": 2, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
-          "composite_rays_train_backward": 9}
+          "composite_rays_train_backward": 9,
+          "composite_rays_train_forward_blend": 5, "composite_rays_train_backward_blend": 9}
 
 
 def enable_kernel_timing(on, only=("grid_encode_forward",)):

@@ -197,6 +197,15 @@ static MarchCfg make_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32
 //      taken whole, an empty candidate jumps to the first T_j >= tt (ballot + ctz),
 //   4. emitted samples are ranked with popcounts of the emit mask -> consecutive lanes write consecutive rows.
 // Counts, offsets and every emitted float are bit-identical to the serial walk (same probe_at / same sums).
+// cooperative zero fill of sample rows [rows_end, M): wave n of N takes the n-th slice
+__device__ __forceinline__ void zero_tail_rows(uint32_t rows_end, uint32_t M, uint32_t n, uint32_t N, int lane, float* __restrict__ buf,
+                                               uint32_t floats_per_row) {
+    if (rows_end >= M) return;
+    const uint32_t tail = M - rows_end, chunk = (tail + N - 1) / N;
+    const uint32_t lo = rows_end + min(tail, n * chunk), hi = rows_end + min(tail, (n + 1) * chunk);
+    for (size_t e = (size_t)lo * floats_per_row + lane; e < (size_t)hi * floats_per_row; e += 64) buf[e] = 0.0f;
+}
+
 constexpr int MARCH_WAVES = 4;                 // rays per 256-thread block
 constexpr int MARCH_BLOCK = 64 * MARCH_WAVES;
 
@@ -216,6 +225,10 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
 
     uint32_t limit = max_steps, offset = 0;
     if (EMIT) {
+        const uint32_t rows_end = prefix[N + 2];
+        zero_tail_rows(rows_end, M, n, N, lane, xyzs, 3);
+        zero_tail_rows(rows_end, M, n, N, lane, dirs, 3);
+        zero_tail_rows(rows_end, M, n, N, lane, deltas, 2);
         limit = counts[n];
         offset = prefix[N] + prefix[n];                   // prefix[N] = counter value before this call (:405)
         if (lane == 0) {
@@ -308,18 +321,31 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
 
 // exclusive scan of the per-ray counts (single block) + counter update (:405-406).
 // prefix[0..N) = exclusive prefix, prefix[N] / prefix[N+1] = counter values before this call.
-__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ counts, uint32_t N,
-                                                       uint32_t* __restrict__ prefix, int32_t* __restrict__ counter) {
+// prefix[N + 2] = rows_end: first sample row not written by this call (end of the last ray that fits into M);
+// the emit pass zero-fills [rows_end, M) so callers need not pre-zero xyzs / dirs / deltas.
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ counts, uint32_t N, uint32_t M,
+                                                       uint32_t* __restrict__ prefix, int32_t* __restrict__ counter,
+                                                       uint32_t* __restrict__ rows_end_out) {
     __shared__ uint32_t lds[17];
-    uint32_t carry = 0;
+    __shared__ uint32_t s_end, s_base;
+    if (threadIdx.x == 0) { s_end = 0; s_base = counter ? (uint32_t)counter[0] : 0u; }
+    __syncthreads();
+    const uint32_t b0u = s_base;
+    uint32_t carry = 0, my_end = 0;
     for (uint32_t base = 0; base < N; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < N ? counts[i] : 0;
         uint32_t total;
         const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
-        if (i < N) prefix[i] = carry + ex;
+        if (i < N) {
+            prefix[i] = carry + ex;
+            const unsigned long long end = (unsigned long long)b0u + carry + ex + v;
+            if (v != 0 && end <= (unsigned long long)M) my_end = max(my_end, carry + ex + v);
+        }
         carry += total;
     }
+    atomicMax(&s_end, my_end);
+    __syncthreads();
     if (threadIdx.x == 0) {
         int32_t b0 = 0, b1 = 0;
         if (counter) {
@@ -328,8 +354,11 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict
         }
         prefix[N] = (uint32_t)b0;
         prefix[N + 1] = (uint32_t)b1;
+        prefix[N + 2] = min(M, (uint32_t)b0 + s_end);
+        if (rows_end_out) rows_end_out[0] = prefix[N + 2];
     }
 }
+
 
 // ---------------------------------------------------------------- K7 / K8 (training composite)
 // raymarching.cu:500-577 / :601-682.  MI355X form: one wavefront per ray, 64 samples per pass.
@@ -356,10 +385,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int COMP_WAVES = 4;
 constexpr int COMP_BLOCK = 64 * COMP_WAVES;
 
+// BLEND: additionally the post-ops of run_cuda (renderer.py:321, 325) in the epilogue:
+//   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - near, min=0) / (far - near);
+// `image` keeps the un-blended colour the backward needs.
+struct Blend { const float* nears; const float* fars; const float* bg_rays; float bg[3]; float* image_out; float* depth_out; };
+
+template <bool BLEND>
 __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
     const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
-    float* __restrict__ depth, float* __restrict__ image) {
+    float* __restrict__ depth, float* __restrict__ image, Blend bl) {
     const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = threadIdx.x & 63;
@@ -397,29 +432,60 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
     if (lane == 0) {
         weights_sum[index] = ws; depth[index] = d;
         image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+        if constexpr (BLEND) {
+            const float* bg = bl.bg_rays ? bl.bg_rays + 3 * (size_t)index : bl.bg;
+            const float rest = 1.0f - ws;
+            bl.image_out[3 * (size_t)index] = r + rest * bg[0];
+            bl.image_out[3 * (size_t)index + 1] = g + rest * bg[1];
+            bl.image_out[3 * (size_t)index + 2] = b + rest * bg[2];
+            const float nr = bl.nears[index];
+            bl.depth_out[index] = fmaxf(d - nr, 0.0f) / (bl.fars[index] - nr);
+        }
     }
 }
 
+// DENSE: (a) the gradient of the BLEND epilogue is folded in: grad_ws_eff = grad_ws - sum_c grad_image_c * bg_c;
+// (b) EVERY row of grad_sigmas / grad_rgbs in [0, M) is written (zeros for samples after the early stop and for the
+// rows [rows_end, M) no ray owns), so the caller allocates them uninitialised.  Needs the contiguous ray-id-order
+// layout lae_march_rays_train produces.
+struct Dense { const float* bg_rays; float bg[3]; const uint32_t* rows_end; };
+
+template <bool DENSE>
 __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
     const float* __restrict__ grad_ws, const float* __restrict__ grad_image, const float* __restrict__ sigmas,
     const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ weights_sum, const float* __restrict__ image, uint32_t M, uint32_t N, float T_thresh,
-    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, Dense dn) {
     const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = threadIdx.x & 63;
+    if constexpr (DENSE) {
+        const uint32_t rows_end = dn.rows_end[0];
+        zero_tail_rows(rows_end, M, n, N, lane, grad_sigmas, 1);
+        zero_tail_rows(rows_end, M, n, N, lane, grad_rgbs, 3);
+    }
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
     if (num_steps == 0 || offset + num_steps > M) return;                   // :624
-    const float gws = grad_ws[index];
+    float gws = grad_ws[index];
     const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
+    if constexpr (DENSE) {
+        const float* bg = dn.bg_rays ? dn.bg_rays + 3 * (size_t)index : dn.bg;
+        gws = gws - ((g0 * bg[0] + g1 * bg[1]) + g2 * bg[2]);
+    }
     const float rf = image[3 * (size_t)index], gf = image[3 * (size_t)index + 1], bf = image[3 * (size_t)index + 2];
     const float tail = gws * (1 - weights_sum[index]);
     float T = 1.0f, r = 0, g = 0, b = 0;
+    bool stopped = false;
     for (uint32_t base = 0; base < num_steps; base += 64) {
         const uint32_t k = base + lane;
         bool valid = k < num_steps;
         const size_t i = (size_t)offset + k;
+        if (DENSE && stopped) {                                             // samples after the early stop: zero gradient
+            if (valid) { grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f; }
+            continue;
+        }
+        const bool in_ray = valid;
         float alpha = 0.f, d0 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
         if (valid) {
             d0 = deltas[2 * i];
@@ -441,8 +507,10 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
             grad_rgbs[3 * i] = g0 * w; grad_rgbs[3 * i + 1] = g1 * w; grad_rgbs[3 * i + 2] = g2 * w;      // :657-659
             grad_sigmas[i] = d0 * (g0 * (T_post * c0 - (rf - rk)) + g1 * (T_post * c1 - (gf - gk)) +
                                    g2 * (T_post * c2 - (bf - bk)) + tail);                                // :662-667
+        } else if (DENSE && in_ray) {
+            grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f;
         }
-        if (done) break;
+        if (done) { if (DENSE) { stopped = true; continue; } break; }
         T *= __shfl(incl, 63, 64);
         r = __shfl(rk, 63, 64); g = __shfl(gk, 63, 64); b = __shfl(bk, 63, 64);
     }
@@ -611,13 +679,13 @@ int lae_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
 }
 
 uint64_t lae_march_rays_train_scratch_bytes(uint32_t N) {
-    return 4ull * (2ull * N + 2) + 64;        // counts[N] | prefix[N + 2]
+    return 4ull * (2ull * N + 3) + 60;        // counts[N] | prefix[N + 2] | rows_end
 }
 
 int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                          const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                         const float* noises, void* scratch, void* stream) {
+                         const float* noises, void* scratch, uint32_t* rows_end_out, void* stream) {
     if (N == 0) return LAE_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !xyzs || !dirs || !deltas || !rays || !noises || !scratch)
         return LAE_ENULL;
@@ -629,7 +697,7 @@ int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
     hipStream_t s = STREAM(stream);
     k_march_train_wave<false><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
                                                            counts, nullptr, nullptr, nullptr, nullptr, nullptr);
-    k_scan_counts<<<1, 1024, 0, s>>>(counts, N, prefix, counter);
+    k_scan_counts<<<1, 1024, 0, s>>>(counts, N, M, prefix, counter, rows_end_out);
     k_march_train_wave<true><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
                                                           counts, prefix, xyzs, dirs, deltas, rays);
     return lae::check_launch("march_rays_train");
@@ -641,9 +709,37 @@ int lae_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
     if (N == 0) return LAE_OK;
     if (!rays || !weights_sum || !depth || !image) return LAE_ENULL;
     if (M > 0 && (!sigmas || !rgbs || !deltas)) return LAE_ENULL;
-    k_composite_train_fwd<<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N,
-                                                                                        T_thresh, weights_sum, depth, image);
+    k_composite_train_fwd<false><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N,
+                                                                                               T_thresh, weights_sum, depth, image, Blend{});
     return lae::check_launch("composite_rays_train_forward");
+}
+
+int lae_composite_rays_train_forward_blend(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                           uint32_t M, uint32_t N, float T_thresh, const float* nears, const float* fars,
+                                           const float* bg_rays, float bg_r, float bg_g, float bg_b, float* weights_sum,
+                                           float* depth, float* image, float* depth_out, float* image_out, void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays || !weights_sum || !depth || !image || !nears || !fars || !depth_out || !image_out) return LAE_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas)) return LAE_ENULL;
+    const Blend bl{nears, fars, bg_rays, {bg_r, bg_g, bg_b}, image_out, depth_out};
+    k_composite_train_fwd<true><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N,
+                                                                                              T_thresh, weights_sum, depth, image, bl);
+    return lae::check_launch("composite_rays_train_forward_blend");
+}
+
+int lae_composite_rays_train_backward_blend(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                            const float* rgbs, const float* deltas, const int32_t* rays,
+                                            const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                            float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
+                                            const uint32_t* rows_end, float* grad_sigmas, float* grad_rgbs, void* stream) {
+    if (N == 0 || M == 0) return LAE_OK;
+    if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image ||
+        !grad_sigmas || !grad_rgbs || !rows_end)
+        return LAE_ENULL;
+    const Dense dn{bg_rays, {bg_r, bg_g, bg_b}, rows_end};
+    k_composite_train_bwd<true><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
+        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, dn);
+    return lae::check_launch("composite_rays_train_backward_blend");
 }
 
 int lae_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
@@ -654,9 +750,9 @@ int lae_composite_rays_train_backward(const float* grad_weights_sum, const float
     if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image ||
         !grad_sigmas || !grad_rgbs)
         return LAE_ENULL;
-    k_composite_train_bwd<<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
+    k_composite_train_bwd<false><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
         grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas,
-        grad_rgbs);
+        grad_rgbs, Dense{});
     return lae::check_launch("composite_rays_train_backward");
 }
 

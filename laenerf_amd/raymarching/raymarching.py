@@ -14,7 +14,7 @@ from ..backend import raymarching_backend as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
-           "compact_rays_alive", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
+           "compact_rays_alive", "composite_rays_train_blend", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
 
 
 def _gpu(t):
@@ -125,15 +125,18 @@ class _march_rays_train(Function):
         M = N * max_steps
         if not force_all_rays and mean_count > 0:
             M = _round_up_always(mean_count, align)
-        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        # rows no ray owns are zero-filled by the kernel (the reference's torch.zeros, raymarching.py:207-209)
+        xyzs = torch.empty(M, 3, dtype=dt, device=dev)
+        dirs = torch.empty(M, 3, dtype=dt, device=dev)
+        deltas = torch.empty(M, 2, dtype=dt, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        rows_end = torch.empty(1, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
         _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
-                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)
+                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises, rows_end)
+        rays.rows_end = rows_end                         # consumed by composite_rays_train_blend (not part of the reference API)
         if force_all_rays or mean_count <= 0:
             m = _round_up_always(int(step_counter[0].item()), align)      # D2H sync, first 16 steps only
             xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
@@ -173,6 +176,60 @@ class _composite_rays_train(Function):
 
 
 composite_rays_train = _composite_rays_train.apply
+
+
+class _composite_rays_train_blend(Function):
+    """MI355X-native: composite_rays_train + the post-ops of run_cuda (nerf/renderer.py:321, 325) in the same kernels:
+    image + (1 - weights_sum) * bg_color and clamp(depth - nears, min=0) / (fars - nears).  The backward writes every
+    gradient row itself (no zero fills).  `rays` must come from this package's march_rays_train (ray-id order)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        dev, dt = sigmas.device, sigmas.dtype
+        weights_sum, depth, image = (torch.empty(N, dtype=dt, device=dev), torch.empty(N, dtype=dt, device=dev),
+                                     torch.empty(N, 3, dtype=dt, device=dev))
+        depth_out, image_out = torch.empty(N, dtype=dt, device=dev), torch.empty(N, 3, dtype=dt, device=dev)
+        _backend.composite_rays_train_forward_blend(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears.contiguous(),
+                                                    fars.contiguous(), bg_rays, bg, weights_sum, depth, image, depth_out, image_out)
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end)
+        ctx.dims = [M, N, T_thresh, bg]
+        ctx.mark_non_differentiable(depth_out)
+        return weights_sum, depth_out, image_out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end = ctx.saved_tensors
+        M, N, T_thresh, bg = ctx.dims
+        if grad_weights_sum is None:
+            grad_weights_sum = torch.zeros_like(weights_sum)
+        grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
+        _backend.composite_rays_train_backward_blend(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
+                                                     deltas, rays, weights_sum, image, M, N, T_thresh, bg_rays, bg, rows_end,
+                                                     grad_sigmas, grad_rgbs)
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
+
+
+def composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars, bg_color=1, T_thresh=1e-4):
+    """-> weights_sum [N], depth normalised to [0,1] [N], image blended over bg_color [N,3]
+    bg_color: number, 3 numbers / tensor of 3, or a per-ray [N,3] tensor (renderer.py:313-321)"""
+    rows_end = getattr(rays, "rows_end", None)
+    if rows_end is None:
+        raise RuntimeError("composite_rays_train_blend: `rays` must be the tensor returned by laenerf_amd march_rays_train")
+    bg_rays, bg = None, (0.0, 0.0, 0.0)
+    if torch.is_tensor(bg_color) and bg_color.numel() > 3:
+        bg_rays = bg_color.to(sigmas.device, torch.float32).reshape(-1, 3).contiguous()
+    elif torch.is_tensor(bg_color):
+        v = [float(x) for x in bg_color.reshape(-1).tolist()]
+        bg = tuple(v * 3 if len(v) == 1 else v)
+    elif isinstance(bg_color, (int, float)):
+        bg = (float(bg_color),) * 3
+    else:
+        bg = tuple(float(x) for x in bg_color)
+    return _composite_rays_train_blend.apply(sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh)
 
 
 def _infer_buffers(n_alive, n_step, align, dt, dev):

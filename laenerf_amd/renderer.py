@@ -60,6 +60,7 @@ class NeRFRenderer(nn.Module):
         self.register_buffer("_grid_tmp", torch.zeros(grid_size ** 3, dtype=torch.int32), persistent=False)
         self.mean_density = 0
         self.iter_density = 0
+        self.fused_post_ops = True
         self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
         self.mean_count = 0
         self.local_step = 0
@@ -200,9 +201,13 @@ class NeRFRenderer(nn.Module):
                                                                 perturb, 128, force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs = self.model(xyzs, dirs)
         sigmas = self.density_scale * sigmas
-        weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        if self.fused_post_ops:      # composite + bg blend + depth normalisation in one kernel, gradients without zero fills
+            weights_sum, depth, image = raymarching.composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars,
+                                                                               bg_color, T_thresh)
+        else:                        # operator-by-operator, as renderer.py:318-325
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return {"image": image, "depth": depth, "weights_sum": weights_sum, "nears": nears, "n_samples": xyzs.shape[0]}
 
     # ------------------------------------------------------------------ inference render (renderer.py:335-387)

@@ -53,11 +53,16 @@ def test_march_rays_train_bit_exact(O, C, bound, dtg, max_steps):
     for M in (Nr * max_steps, total, max(total // 2, 1)):             # exact fit and overflow-drop
         ref = O.march_rays_train(sc["o"], sc["d"], bound, sc["bits"], C, 128, sc["nears"], sc["fars"], noises, M=M,
                                  dt_gamma=dtg, max_steps=max_steps)
-        xyzs = torch.zeros(M, 3, device=DEV); dirs = torch.zeros(M, 3, device=DEV); deltas = torch.zeros(M, 2, device=DEV)
+        # poisoned buffers: the kernel itself must zero the rows no ray owns (the reference relies on torch.zeros)
+        xyzs = torch.full((M, 3), float("nan"), device=DEV); dirs = torch.full((M, 3), float("nan"), device=DEV)
+        deltas = torch.full((M, 2), float("nan"), device=DEV)
         rays = torch.empty(Nr, 3, dtype=torch.int32, device=DEV); counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+        rows_end = torch.full((1,), -1, dtype=torch.int32, device=DEV)
         B.march_rays_train(T(sc["o"]), T(sc["d"]), T(sc["bits"]), bound, dtg, max_steps, Nr, C, 128, M, T(sc["nears"]),
-                           T(sc["fars"]), xyzs, dirs, deltas, rays, counter, T(noises))
+                           T(sc["fars"]), xyzs, dirs, deltas, rays, counter, T(noises), rows_end)
         assert np.array_equal(N(counter), ref[4])
+        fit = ref[3][(ref[3][:, 2] > 0) & (ref[3][:, 1] + ref[3][:, 2] <= M)]
+        assert int(rows_end.item()) == (int((fit[:, 1] + fit[:, 2]).max()) if len(fit) else 0)
         assert np.array_equal(N(rays), ref[3])                       # ids, offsets, counts: bit exact
         assert np.array_equal(N(xyzs), ref[0]) and np.array_equal(N(dirs), ref[1]) and np.array_equal(N(deltas), ref[2])
 
@@ -166,3 +171,40 @@ def test_compaction_sizes(rm):
         out, cnt = rm.compact_rays_alive(T(v))
         keep = v[v >= 0]
         assert cnt.item() == keep.size and np.array_equal(N(out)[:keep.size], keep)
+
+
+@pytest.mark.parametrize("bg_mode", ["const", "rgb", "per_ray"])
+def test_composite_blend_equals_separate_ops(rm, bg_mode):
+    """composite + bg blend + depth normalisation in one kernel == renderer.py:318-325 built from separate ops;
+    its backward defines every gradient row (no pre-zeroing) and folds the blend's gradient in"""
+    from laenerf_amd.backend import raymarching_backend as B
+    sc = scene(1, 1.0, n_rays=500, seed=4)
+    o, d, bits, n, f = T(sc["o"]), T(sc["d"]), T(sc["bits"]), T(sc["nears"]), T(sc["fars"])
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    for mean_count in (-1, 20000):                                   # trimmed buffers / fixed-size buffers with overflow drop
+        counter.zero_()
+        xyzs, dirs, deltas, rays = rm.march_rays_train(o, d, 1.0, bits, 1, 128, n, f, counter, mean_count, False, 128, False, 0, 1024)
+        M = xyzs.shape[0]
+        sig = (torch.rand(M, device=DEV, generator=gen) * 60).requires_grad_()        # dense enough for early stops
+        rgb = torch.rand(M, 3, device=DEV, generator=gen).requires_grad_()
+        bg = {"const": 1, "rgb": torch.tensor([0.2, 0.5, 0.9], device=DEV), "per_ray": torch.rand(500, 3, device=DEV, generator=gen)}[bg_mode]
+        ws, dep, img = rm.composite_rays_train_blend(sig, rgb, deltas, rays, n, f, bg, 1e-4)
+        gimg = torch.randn(500, 3, device=DEV, generator=gen); gws = torch.randn(500, device=DEV, generator=gen)
+        torch.autograd.backward([img, ws], [gimg, gws])
+        g1s, g1c = sig.grad.clone(), rgb.grad.clone(); sig.grad = None; rgb.grad = None
+        ws0, dep0, img0 = rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+        img_b = img0 + (1 - ws0).unsqueeze(-1) * bg
+        dep_b = torch.clamp(dep0 - n, min=0) / (f - n)
+        torch.autograd.backward([img_b, ws0], [gimg, gws])
+        assert torch.equal(ws, ws0) and torch.equal(img, img_b)
+        assert torch.equal(torch.nan_to_num(dep, nan=-1.0), torch.nan_to_num(dep_b, nan=-1.0))
+        assert torch.allclose(g1s, sig.grad, rtol=1e-5, atol=1e-6) and torch.equal(g1c, rgb.grad)
+        # coverage: the backward kernel must overwrite every row of poisoned gradient buffers
+        gs = torch.full_like(sig, float("nan")); gc = torch.full_like(rgb, float("nan"))
+        bgr = bg.contiguous() if bg_mode == "per_ray" else None
+        bgc = (1.0, 1.0, 1.0) if bg_mode == "const" else (0.2, 0.5, 0.9)
+        B.composite_rays_train_backward_blend(gws, gimg, sig.detach(), rgb.detach(), deltas, rays, ws0.detach(), img0.detach(), M, 500,
+                                              1e-4, bgr, bgc, rays.rows_end, gs, gc)
+        assert torch.isfinite(gs).all() and torch.isfinite(gc).all()
+        assert torch.allclose(gs, g1s, rtol=1e-5, atol=1e-6) and torch.equal(gc, g1c)
