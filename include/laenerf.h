@@ -276,11 +276,12 @@ LAE_API int lae_nerf_density_forward(const void* enc, const void* sigma_weights,
 
 /* Backward of lae_nerf_head_forward: grad_sigmas [M], grad_rgbs [M,3] fp32 (as produced by
  * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).
- * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused. */
+ * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused.
+ * accumulate_weight_grads != 0: grad_*_weights += dW (the fused optimizer's persistent buffers) instead of = dW. */
 LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, void* stream);
+                           void* grad_color_weights, int accumulate_weight_grads, void* stream);
 
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
@@ -314,6 +315,13 @@ LAE_API int lae_adam_begin(void* state, float beta1, float beta2, int growth_int
  * from device memory.  On a skipped step only the gradient is zeroed. */
 LAE_API int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void* grad, int grad_is_half, void* shadow_half, uint64_t n,
                    const void* state, const float* lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* multi-tensor forms of check / apply: host arrays of n_tensors (<= 8) device pointers / sizes; one launch each */
+LAE_API int lae_adam_check_multi(uint32_t n_tensors, const void* const* grads, const int* grad_is_half, const uint64_t* sizes, void* state,
+                         void* stream);
+LAE_API int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, void* const* grads,
+                         const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs,
+                         const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the

@@ -327,7 +327,7 @@ class _FFMLP:
 
     @staticmethod
     def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,
-                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights):
+                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights, accumulate=False):
         ts = (grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, grad_h, grad_enc,
               grad_sigma_weights, grad_color_weights)
         need_cuda(*ts); need_contig(*ts)
@@ -335,7 +335,7 @@ class _FFMLP:
         check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
                                                  ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
                                                  ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
-                                                 ptr(grad_color_weights), stream()), "nerf_head_backward")
+                                                 ptr(grad_color_weights), int(bool(accumulate)), stream()), "nerf_head_backward")
 
     @staticmethod
     def ffmlp_set_mode(mode):

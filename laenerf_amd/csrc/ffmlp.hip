@@ -329,8 +329,9 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
 
 // sum the per-slice slabs in a fixed order (deterministic) and round once to fp16.
 // 256 threads = 64 weights x 4 slice groups; unrolled by 4 so several slab loads are in flight per lane.
+// accumulate != 0: gw += sum (the optimizer's persistent gradient buffer) instead of gw = sum.
 __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
-                                                    half_t* __restrict__ gw) {
+                                                    half_t* __restrict__ gw, int accumulate = 0) {
     __shared__ float part[4][64];
     const uint32_t e = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * 64 + e;
@@ -347,7 +348,10 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ sla
     }
     part[sg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sg == 0 && i < nW) gw[i] = (half_t)((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
+    if (sg == 0 && i < nW) {
+        const float sum = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        gw[i] = accumulate ? (half_t)((float)gw[i] + sum) : (half_t)sum;
+    }
 }
 
 // ---------------------------------------------------------------- fused NeRF head (network_ff.py:51-81 in one kernel)
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(
 
 template <int IN, int NH, int MODE = 0>
 int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
-                     HeadBwdArgs ha = HeadBwdArgs{}) {
+                     HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0) {
     using C = FusedCfg<IN, NH>;
     const uint32_t nW = 64 * (IN + 64 * NH + 16);
     const uint32_t n_tiles = B / 16;
@@ -961,10 +965,11 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
 int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, void* stream) {
+                           void* grad_color_weights, int accumulate_weight_grads, void* stream) {
     if (!grad_sigma_weights || !grad_color_weights) return LAE_ENULL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {                                        // no samples: zero weight gradients (like the reference's GEMMs on empty batches)
+        if (accumulate_weight_grads) return LAE_OK;
         if (hipMemsetAsync(grad_sigma_weights, 0, 64 * (32 + 64 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
         if (hipMemsetAsync(grad_color_weights, 0, 64 * (32 + 128 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
         return LAE_OK;
@@ -973,10 +978,10 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
     if (M % 16 != 0) return LAE_EINVAL;
     HeadBwdArgs ha{dirs, rgbs, grad_rgbs, grad_sigmas, density_scale};
     int rc = launch_bwd_fused<32, 2, 1>(nullptr, (const half_t*)h, (const half_t*)color_weights, M, (half_t*)grad_h,
-                                        (half_t*)grad_color_weights, s, ha);
+                                        (half_t*)grad_color_weights, s, ha, accumulate_weight_grads);
     if (rc != LAE_OK) return rc;
     rc = launch_bwd_fused<32, 1, 0>((const half_t*)grad_h, (const half_t*)enc, (const half_t*)sigma_weights, M, (half_t*)grad_enc,
-                                    (half_t*)grad_sigma_weights, s);
+                                    (half_t*)grad_sigma_weights, s, HeadBwdArgs{}, accumulate_weight_grads);
     if (rc != LAE_OK) return rc;
     return lae::check_launch("nerf_head_backward");
 }

@@ -140,6 +140,102 @@ __global__ __launch_bounds__(256) void k_apply(float* __restrict__ p, float* __r
     }
 }
 
+// multi-tensor forms: one launch walks up to MAX_SEGS tensors (the two MLP weight vectors are ~18 k parameters: a launch
+// each would cost more than the work)
+constexpr int MAX_SEGS = 8;
+struct CheckSegs { const void* grad[MAX_SEGS]; size_t n[MAX_SEGS]; int is_half[MAX_SEGS]; int count; };
+struct ApplySegs {
+    float* p[MAX_SEGS]; float* m[MAX_SEGS]; float* v[MAX_SEGS]; void* grad[MAX_SEGS]; half_t* shadow[MAX_SEGS];
+    const float* lr[MAX_SEGS]; size_t n[MAX_SEGS]; int is_half[MAX_SEGS]; int count;
+};
+
+template <typename G>
+__device__ __forceinline__ bool seg_has_nonfinite(const G* __restrict__ grad, size_t n) {
+    bool bad = false;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            if constexpr (sizeof(G) == 2) {
+                const uint4 v = *reinterpret_cast<const uint4*>(grad + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) bad |= ((w[k] & 0x7c00u) == 0x7c00u) || ((w[k] & 0x7c000000u) == 0x7c000000u);
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(grad + i), b = *reinterpret_cast<const float4*>(grad + i + 4);
+                bad |= !isfinite(a.x) || !isfinite(a.y) || !isfinite(a.z) || !isfinite(a.w) || !isfinite(b.x) || !isfinite(b.y) ||
+                       !isfinite(b.z) || !isfinite(b.w);
+            }
+        } else {
+            for (size_t j = i; j < n; j++) bad |= !isfinite(ldg(grad, j));
+        }
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(256) void k_check_multi(CheckSegs sg, OptState* __restrict__ st) {
+    bool bad = false;
+    for (int s = 0; s < sg.count; s++)
+        bad |= sg.is_half[s] ? seg_has_nonfinite((const half_t*)sg.grad[s], sg.n[s]) : seg_has_nonfinite((const float*)sg.grad[s], sg.n[s]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->found_inf, 1);
+}
+
+template <typename G>
+__device__ __forceinline__ void seg_apply(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, G* __restrict__ grad,
+                                          half_t* __restrict__ shadow, size_t n, bool skip, float inv_scale, float bc2_sqrt,
+                                          float lr_over_bc1, const AdamHyper& h) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float g[4];
+            if constexpr (sizeof(G) == 2) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(grad + i);
+                const half_t* gh = reinterpret_cast<const half_t*>(&raw);
+#pragma unroll
+                for (int k = 0; k < 4; k++) g[k] = (float)gh[k];
+                *reinterpret_cast<uint2*>(grad + i) = uint2{0u, 0u};
+            } else {
+                const float4 raw = *reinterpret_cast<const float4*>(grad + i);
+                g[0] = raw.x; g[1] = raw.y; g[2] = raw.z; g[3] = raw.w;
+                *reinterpret_cast<float4*>(grad + i) = float4{0, 0, 0, 0};
+            }
+            if (skip) continue;
+            float4 pp = *reinterpret_cast<const float4*>(p + i), mm = *reinterpret_cast<const float4*>(m + i),
+                   vv = *reinterpret_cast<const float4*>(v + i);
+            adam1(pp.x, mm.x, vv.x, g[0] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.y, mm.y, vv.y, g[1] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.z, mm.z, vv.z, g[2] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            adam1(pp.w, mm.w, vv.w, g[3] * inv_scale, lr_over_bc1, bc2_sqrt, h);
+            *reinterpret_cast<float4*>(p + i) = pp;
+            *reinterpret_cast<float4*>(m + i) = mm;
+            *reinterpret_cast<float4*>(v + i) = vv;
+            if (shadow) {
+                half_t s[4] = {(half_t)pp.x, (half_t)pp.y, (half_t)pp.z, (half_t)pp.w};
+                *reinterpret_cast<uint2*>(shadow + i) = *reinterpret_cast<const uint2*>(s);
+            }
+        } else {
+            for (size_t j = i; j < n; j++) {
+                const float gj = ldg(grad, j) * inv_scale;
+                grad[j] = (G)0.0f;
+                if (skip) continue;
+                float pj = p[j], mj = m[j], vj = v[j];
+                adam1(pj, mj, vj, gj, lr_over_bc1, bc2_sqrt, h);
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (shadow) shadow[j] = (half_t)pj;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_apply_multi(ApplySegs sg, const OptState* __restrict__ st, AdamHyper h) {
+    const bool skip = st->skip != 0;
+    const float inv_scale = st->inv_scale, bc2_sqrt = st->bc2_sqrt;
+    for (int s = 0; s < sg.count; s++) {
+        const float lr_over_bc1 = (float)((double)sg.lr[s][0] * (double)st->inv_bc1);
+        if (sg.is_half[s]) seg_apply(sg.p[s], sg.m[s], sg.v[s], (half_t*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h);
+        else seg_apply(sg.p[s], sg.m[s], sg.v[s], (float*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h);
+    }
+}
+
 uint32_t stream_blocks(size_t n, int per_thread) {
     const size_t want = (n + 256ull * per_thread - 1) / (256ull * per_thread);
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (size_t)lae::num_cus() * 16));
@@ -157,6 +253,48 @@ int lae_adam_check(const void* grad, int grad_is_half, uint64_t n, void* state, 
     if (grad_is_half) k_check<half_t><<<stream_blocks(n, 8), 256, 0, STREAM(stream)>>>((const half_t*)grad, n, st);
     else k_check<float><<<stream_blocks(n, 8), 256, 0, STREAM(stream)>>>((const float*)grad, n, st);
     return lae::check_launch("adam_check");
+}
+
+int lae_adam_check_multi(uint32_t n_tensors, const void* const* grads, const int* grad_is_half, const uint64_t* sizes, void* state,
+                         void* stream) {
+    if (n_tensors == 0) return LAE_OK;
+    if (!grads || !grad_is_half || !sizes || !state) return LAE_ENULL;
+    if (n_tensors > (uint32_t)MAX_SEGS) return LAE_EINVAL;
+    CheckSegs sg{};
+    size_t biggest = 0;
+    for (uint32_t i = 0; i < n_tensors; i++) {
+        if (sizes[i] && !grads[i]) return LAE_ENULL;
+        if (reinterpret_cast<uintptr_t>(grads[i]) & 15) return LAE_EINVAL;
+        sg.grad[i] = grads[i]; sg.n[i] = sizes[i]; sg.is_half[i] = grad_is_half[i];
+        biggest = std::max(biggest, (size_t)sizes[i]);
+    }
+    sg.count = (int)n_tensors;
+    k_check_multi<<<stream_blocks(biggest, 8), 256, 0, STREAM(stream)>>>(sg, reinterpret_cast<OptState*>(state));
+    return lae::check_launch("adam_check_multi");
+}
+
+int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, void* const* grads,
+                         const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs,
+                         const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (n_tensors == 0) return LAE_OK;
+    if (!params || !exp_avgs || !exp_avg_sqs || !grads || !grad_is_half || !shadows_half || !sizes || !lrs || !state) return LAE_ENULL;
+    if (n_tensors > (uint32_t)MAX_SEGS) return LAE_EINVAL;
+    ApplySegs sg{};
+    size_t biggest = 0;
+    for (uint32_t i = 0; i < n_tensors; i++) {
+        if (sizes[i] && (!params[i] || !exp_avgs[i] || !exp_avg_sqs[i] || !grads[i] || !lrs[i])) return LAE_ENULL;
+        const uintptr_t al = reinterpret_cast<uintptr_t>(params[i]) | reinterpret_cast<uintptr_t>(exp_avgs[i]) |
+                             reinterpret_cast<uintptr_t>(exp_avg_sqs[i]) | reinterpret_cast<uintptr_t>(grads[i]) |
+                             reinterpret_cast<uintptr_t>(shadows_half[i]);
+        if (al & 15) return LAE_EINVAL;
+        sg.p[i] = params[i]; sg.m[i] = exp_avgs[i]; sg.v[i] = exp_avg_sqs[i]; sg.grad[i] = grads[i];
+        sg.shadow[i] = (half_t*)shadows_half[i]; sg.lr[i] = lrs[i]; sg.n[i] = sizes[i]; sg.is_half[i] = grad_is_half[i];
+        biggest = std::max(biggest, (size_t)sizes[i]);
+    }
+    sg.count = (int)n_tensors;
+    k_apply_multi<<<stream_blocks(biggest, 4), 256, 0, STREAM(stream)>>>(sg, reinterpret_cast<const OptState*>(state),
+                                                                        AdamHyper{beta1, beta2, eps, weight_decay});
+    return lae::check_launch("adam_apply_multi");
 }
 
 int lae_adam_begin(void* state, float beta1, float beta2, int growth_interval, float growth_factor, float backoff_factor,

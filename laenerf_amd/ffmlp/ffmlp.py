@@ -82,8 +82,16 @@ class FFMLP(nn.Module):
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
+        self.shadow = None                                      # fp16 weights + gradient buffer once a FusedAdam owns them
         self.reset_parameters()
         _backend.allocate_splitk(self.num_layers + 1)
+
+    def attach_shadow(self):
+        from ..gridencoder.grid import TableShadow
+        if not self.weights.is_cuda:
+            raise RuntimeError("FFMLP.attach_shadow: weights must be on the GPU")
+        self.shadow = TableShadow(self.weights)
+        return self.shadow
 
     def cleanup(self):
         _backend.free_splitk()

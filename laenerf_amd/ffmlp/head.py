@@ -20,7 +20,7 @@ COLOR_NET_PARAMS = 64 * (32 + 2 * 64 + 16)      # FFMLP(32 -> 64 -> 64 -> 64 -> 
 class _nerf_head(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, enc, dirs, sigma_weights, color_weights, density_scale):
+    def forward(ctx, enc, dirs, sigma_weights, color_weights, density_scale, sigma_shadow=None, color_shadow=None):
         M = enc.shape[0]
         if enc.shape[1] != 32 or sigma_weights.numel() != SIGMA_NET_PARAMS or color_weights.numel() != COLOR_NET_PARAMS:
             raise RuntimeError("nerf_head: needs the 32-wide encoder, FFMLP(32,64,2 layers,16) and FFMLP(32,64,3 layers,16)")
@@ -28,7 +28,13 @@ class _nerf_head(Function):
             raise RuntimeError("nerf_head: the number of samples must be a multiple of 16 (march_rays_train aligns to 128)")
         enc = enc.half().contiguous()
         dirs = dirs.float().contiguous()
-        ws, wc = sigma_weights.half().contiguous(), color_weights.half().contiguous()
+        # with a FusedAdam attached, the fp16 weights are kept by the optimizer (no per-step cast) and the weight
+        # gradients are added into its persistent fp16 buffers (autograd sees none)
+        ctx.shadows = (sigma_shadow, color_shadow) if sigma_shadow is not None and color_shadow is not None else None
+        if ctx.shadows is not None:
+            ws, wc = sigma_shadow.table_half(sigma_weights), color_shadow.table_half(color_weights)
+        else:
+            ws, wc = sigma_weights.half().contiguous(), color_weights.half().contiguous()
         h = torch.empty(M, 16, device=enc.device, dtype=torch.half)
         sigmas = torch.empty(M, device=enc.device, dtype=torch.float32)
         rgbs = torch.empty(M, 3, device=enc.device, dtype=torch.float32)
@@ -48,15 +54,19 @@ class _nerf_head(Function):
         grad_rgbs = grad_rgbs.float().contiguous()
         grad_h = torch.empty_like(h)
         grad_enc = torch.empty_like(enc) if ctx.need_enc_grad else None
+        if ctx.shadows is not None:
+            _backend.nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h,
+                                        grad_enc, ctx.shadows[0].grad_half, ctx.shadows[1].grad_half, accumulate=True)
+            return grad_enc, None, None, None, None, None, None
         gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
         _backend.nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h,
                                     grad_enc, gws, gwc)
-        return grad_enc, None, gws.to(ctx.wdtypes[0]), gwc.to(ctx.wdtypes[1]), None
+        return grad_enc, None, gws.to(ctx.wdtypes[0]), gwc.to(ctx.wdtypes[1]), None, None, None
 
 
-def nerf_head(enc, dirs, sigma_weights, color_weights, density_scale=1.0):
+def nerf_head(enc, dirs, sigma_weights, color_weights, density_scale=1.0, sigma_shadow=None, color_shadow=None):
     """enc [M,32] (grid-encoder output), dirs [M,3] unit fp32 -> sigmas [M] fp32, rgbs [M,3] fp32"""
-    return _nerf_head.apply(enc, dirs, sigma_weights, color_weights, float(density_scale))
+    return _nerf_head.apply(enc, dirs, sigma_weights, color_weights, float(density_scale), sigma_shadow, color_shadow)
 
 
 @torch.no_grad()

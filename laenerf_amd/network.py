@@ -41,7 +41,7 @@ class NeRFNetwork(nn.Module):
         """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N] fp32, rgb [N,3]   (network_ff.py:51-81)"""
         x = self.encoder(x, bound=self.bound)
         if self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and x.dtype == torch.half and not d.requires_grad:
-            return nerf_head(x, d, self.sigma_net.weights, self.color_net.weights)
+            return nerf_head(x, d, self.sigma_net.weights, self.color_net.weights, 1.0, self.sigma_net.shadow, self.color_net.shadow)
         h = self.sigma_net(x)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
@@ -56,7 +56,8 @@ class NeRFNetwork(nn.Module):
         """network_ff.py:83-96"""
         x = self.encoder(x, bound=self.bound)
         if self.fused_head and x.is_cuda and x.dtype == torch.half and not torch.is_grad_enabled():
-            sigma, h = nerf_density(x, self.sigma_net.weights)
+            sh = self.sigma_net.shadow
+            sigma, h = nerf_density(x, self.sigma_net.weights if sh is None else sh.table_half(self.sigma_net.weights))
             return {"sigma": sigma, "geo_feat": h[..., 1:]}
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}

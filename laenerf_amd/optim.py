@@ -11,9 +11,12 @@ and the fp16 gradient accumulator the encoder's backward adds into:
 
 `state_dict()` / `load_state_dict()` use torch.optim.Adam's layout (`exp_avg`, `exp_avg_sq`, `step`).
 """
+import ctypes
+
 import torch
 
 from . import _lib
+from .ffmlp import FFMLP
 from .gridencoder import GridEncoder
 
 
@@ -24,7 +27,8 @@ class FusedAdam:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.use_scaler = bool(grad_scaler)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
-        tables = {id(m.embeddings): m for m in model.modules() if isinstance(m, GridEncoder)}
+        tables = {id(m.embeddings): m for m in model.modules() if isinstance(m, GridEncoder) and m.level_dim % 2 == 0}
+        tables.update({id(m.weights): m for m in model.modules() if isinstance(m, FFMLP)})
         self.param_groups = []
         self.items = []                                   # (param, exp_avg, exp_avg_sq, shadow or None, group index)
         dev = None
@@ -36,9 +40,9 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU (no CPU fallback)")
                 dev = p.device
                 shadow = None
-                enc = tables.get(id(p))
-                if enc is not None and enc.level_dim % 2 == 0:
-                    shadow = enc.attach_shadow()
+                owner = tables.get(id(p))
+                if owner is not None:
+                    shadow = owner.attach_shadow()         # fp16 copy + fp16 gradient accumulator next to the parameter
                 else:
                     p.grad = torch.zeros_like(p)           # persistent fp32 gradient (stable address for graph replay)
                 self.items.append((p, torch.zeros_like(p), torch.zeros_like(p), shadow, gi))
@@ -47,6 +51,9 @@ class FusedAdam:
         self._scale_view = self.state.view(torch.float32)
         self._scale_view[0] = init_scale if self.use_scaler else 1.0
         self.lrs = torch.tensor([g["lr"] for g in self.param_groups], dtype=torch.float32, device=dev)
+        if len(self.items) > 8:
+            raise RuntimeError("FusedAdam: at most 8 parameter tensors (one multi-tensor launch)")
+        self._args = None                                  # ctypes pointer tables of the multi-tensor kernels
 
     # ---- GradScaler face
     def scale(self, loss):
@@ -82,10 +89,19 @@ class FusedAdam:
     def zero_grad(self, set_to_none=False):
         """gradients are zeroed by step(); provided for Trainer code that calls it anyway"""
         for p, _, _, shadow, _ in self.items:
-            (shadow.grad_half if shadow is not None else p.grad).zero_()
+            if shadow is not None:
+                shadow.grad_half.zero_()
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
 
     def _grad(self, p, shadow):
         if shadow is not None:
+            if p.grad is not None:
+                # the parameter was also used through a path that does not know the shadow (fp32 encoder call, FFMLP
+                # module forward with autograd): fold that gradient into the accumulator
+                shadow.grad_half.add_(p.grad.to(torch.half))
+                p.grad = None
             return shadow.grad_half, 1
         if p.grad is None:
             p.grad = torch.zeros_like(p)
@@ -93,21 +109,35 @@ class FusedAdam:
             raise RuntimeError("FusedAdam: fp32 contiguous .grad expected")
         return p.grad, 0
 
+    def _tables(self):
+        grads = [self._grad(p, sh) for p, _, _, sh, _ in self.items]
+        key = tuple(g.data_ptr() for g, _ in grads)
+        if self._args is None or self._args["key"] != key:
+            n = len(self.items)
+            arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+            self._args = {
+                "key": key, "n": n,
+                "grads": arr(key), "is_half": (ctypes.c_int * n)(*[h for _, h in grads]),
+                "sizes": (ctypes.c_uint64 * n)(*[p.numel() for p, *_ in self.items]),
+                "params": arr([p.data_ptr() for p, *_ in self.items]),
+                "m": arr([m.data_ptr() for _, m, *_ in self.items]), "v": arr([v.data_ptr() for _, _, v, *_ in self.items]),
+                "shadows": arr([None if sh is None else sh.half.data_ptr() for _, _, _, sh, _ in self.items]),
+                "lrs": arr([self.lrs.data_ptr() + 4 * gi for *_, gi in self.items]),
+            }
+        return self._args
+
     @torch.no_grad()
     def step(self):
+        """check (any non-finite gradient?) -> begin (skip / step decision, scale update) -> apply: three launches"""
         lib, st, s = _lib.load(), self.state.data_ptr(), _lib.stream()
+        a = self._tables()
         if self.use_scaler:
-            for p, _, _, shadow, _ in self.items:
-                g, is_half = self._grad(p, shadow)
-                _lib.check(lib.lae_adam_check(g.data_ptr(), is_half, g.numel(), st, s), "adam_check")
+            _lib.check(lib.lae_adam_check_multi(a["n"], a["grads"], a["is_half"], a["sizes"], st, s), "adam_check")
         _lib.check(lib.lae_adam_begin(st, self.betas[0], self.betas[1], self.growth_interval, self.growth_factor,
                                       self.backoff_factor, int(self.use_scaler), s), "adam_begin")
-        for p, m, v, shadow, gi in self.items:
-            g, is_half = self._grad(p, shadow)
-            _lib.check(lib.lae_adam_apply(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), is_half,
-                                          None if shadow is None else shadow.half.data_ptr(), p.numel(), st,
-                                          self.lrs.data_ptr() + 4 * gi, self.betas[0], self.betas[1], self.eps,
-                                          self.weight_decay, s), "adam_apply")
+        _lib.check(lib.lae_adam_apply_multi(a["n"], a["params"], a["m"], a["v"], a["grads"], a["is_half"], a["shadows"],
+                                            a["sizes"], a["lrs"], st, self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, s), "adam_apply")
 
     # ---- torch.optim.Adam-compatible checkpoints
     def state_dict(self):

@@ -200,7 +200,8 @@ class NeRFRenderer(nn.Module):
                                                                 self.grid_size, nears, fars, counter, self.mean_count,
                                                                 perturb, 128, force_all_rays, dt_gamma, max_steps)
         sigmas, rgbs = self.model(xyzs, dirs)
-        sigmas = self.density_scale * sigmas
+        if self.density_scale != 1:
+            sigmas = self.density_scale * sigmas
         if self.fused_post_ops:      # composite + bg blend + depth normalisation in one kernel, gradients without zero fills
             weights_sum, depth, image = raymarching.composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars,
                                                                                bg_color, T_thresh)
