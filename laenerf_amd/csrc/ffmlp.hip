@@ -479,7 +479,7 @@ struct HeadBwdArgs {
 };
 
 template <int IN, int NH, int MODE>
-__global__ __launch_bounds__(256) void k_mlp_bwd_fused(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp_bwd_fused(
     const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
     half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW, HeadBwdArgs ha) {
     using C = FusedCfg<IN, NH>;

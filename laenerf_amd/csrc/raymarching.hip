@@ -211,6 +211,21 @@ constexpr int MARCH_BLOCK = 64 * MARCH_WAVES;
 
 __device__ __forceinline__ float step_of(const MarchCfg& c, float t) { return clampf(t * c.dt_gamma, c.dt_min, c.dt_max); }
 
+// Constant step (dt_gamma == 0, every shipped config): inside one binade [2^(e-1), 2^e) all t are multiples of
+// u = 2^(e-25+1) and fl(t + dt) = t + q with q = dt rounded to a multiple of u -- the SAME q for every t of the binade
+// unless dt lies exactly half-way between two multiples (ties-to-even would then depend on t).  Hence
+// T_k = T_0 + k*q exactly (k*q and the sum are representable while the sum stays below 2^e), and the 63-step serial
+// recurrence collapses to one multiply-add per lane with bit-identical results.
+__device__ __forceinline__ bool uniform_step(float t_base, float dt, float& q) {
+    if (!(t_base > 0.0f)) return false;
+    int e;
+    (void)frexpf(t_base, &e);                               // t_base in [2^(e-1), 2^e)
+    const float top = scalbnf(1.0f, e), half_ulp = scalbnf(1.0f, e - 25);
+    q = (t_base + dt) - t_base;                             // exact when t_base + dt stays in the binade (checked below)
+    const float r = dt - q;                                 // exact (Sterbenz)
+    return (top - t_base) > 64.0f * q && fabsf(r) != half_ulp && q > 0.0f;
+}
+
 // EMIT == false: count the samples of ray n.  EMIT == true: write them at `offset` (num_steps known).
 template <bool EMIT>
 __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
@@ -250,11 +265,15 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
 
     while (t_base < far && emitted < limit) {
         // 1. candidates: lane i gets T_{base+i} by i serial steps (identical rounding to the serial walk)
-        float t = t_base;
+        float t = t_base, q;
+        if (cfg.dt_gamma == 0.0f && uniform_step(t_base, cfg.dt_min, q)) {
+            t = t_base + (float)lane * q;                 // exact, see uniform_step
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < 63; j++) {
-            const float tn = t + step_of(cfg, t);
-            t = (lane > j) ? tn : t;
+            for (int j = 0; j < 63; j++) {
+                const float tn = t + step_of(cfg, t);
+                t = (lane > j) ? tn : t;
+            }
         }
         const float dt = step_of(cfg, t);
         const float t_next = t + dt;                      // == T_{base+i+1}
