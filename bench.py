@@ -116,9 +116,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (one-GPU boxes): LAE_BENCH_DIST_BACKEND=gloo LAE_BENCH_SINGLE_DEVICE=1 runs every rank on cuda:0 over gloo,
+    # which exercises the multi-rank control flow (build barrier, timing barriers, max-over-ranks) without RCCL
+    backend_name = os.environ.get("LAE_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("LAE_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend_name)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -244,7 +252,7 @@ def main():
     if graph:
         timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
