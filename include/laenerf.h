@@ -190,12 +190,15 @@ LAE_API int lae_grid_encode_forward(const float* inputs, const void* embeddings,
                             int align_corners, uint32_t interp, int dtype, void* stream);
 
 /* MI355X-native variant: writes outputs as [B, L*C] directly (what grid.py:57
- * produces with an extra permute+reshape copy).  Same arithmetic. */
+ * produces with an extra permute+reshape copy).  Same arithmetic.
+ * in_shift / in_scale: every coordinate is read as (x + in_shift) * in_scale -- GridEncoder.forward's
+ * `(inputs + bound) / (2 * bound)` (grid.py:149) with in_shift = bound, in_scale = fp32(1 / (2 * bound)); pass 0, 1
+ * for coordinates already in [0, 1]. */
 LAE_API int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings,
                                 const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
                                 uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                 uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                void* stream);
+                                float in_shift, float in_scale, void* stream);
 
 /* gridencoder.cu:473-503  grid_encode_backward(grad[L,B,C], inputs, embeddings, offsets,
  * grad_embeddings[sO,C] (pre-zeroed, accumulated into), B, D, C, L, S, H,
@@ -211,7 +214,8 @@ LAE_API int lae_grid_encode_backward_blc(const void* grad, const float* inputs, 
                                  const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                  uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                  const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                                 int align_corners, uint32_t interp, int dtype, void* stream);
+                                 int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
+                                 void* stream);
 
 /* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
  * 1 = always the generic kernel (one global atomic per corner, what the reference does). */

@@ -37,9 +37,9 @@ SIGNATURES = {
     "lae_compact_scratch_bytes": [u32],
     "lae_compact_rays_alive": [vp, u32, vp, vp, vp, vp],
     "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
-    "lae_grid_encode_forward_blc": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
+    "lae_grid_encode_forward_blc": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, f32, f32, vp],
     "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
-    "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
+    "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, f32, f32, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
     "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],

@@ -218,29 +218,39 @@ class _RayMarching:
 class _GridEncoder:
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
-                            interp, blc=False):
+                            interp, blc=False, in_map=(0.0, 1.0)):
+        """blc / in_map are MI355X extensions: [B, L*C] output layout; coordinates read as (x + in_map[0]) * in_map[1]"""
         need_cuda(inputs, embeddings, offsets, outputs, dy_dx); need_contig(inputs, embeddings, offsets, outputs, dy_dx)
         if inputs.dtype != torch.float32 or offsets.dtype != torch.int32:
             raise RuntimeError("grid_encode_forward: inputs must be float32, offsets int32")   # gridencoder.cu:461-463
         if outputs.dtype != embeddings.dtype or (dy_dx is not None and dy_dx.dtype != embeddings.dtype):
             raise RuntimeError("grid_encode_forward: outputs/dy_dx must have the embeddings dtype")
         lib = _lib.load()
-        fn = lib.lae_grid_encode_forward_blc if blc else lib.lae_grid_encode_forward
-        check(fn(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype,
-                 int(bool(align_corners)), interp, _dtype_code(embeddings), stream()), "grid_encode_forward")
+        args = (ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype,
+                int(bool(align_corners)), interp, _dtype_code(embeddings))
+        if blc:
+            check(lib.lae_grid_encode_forward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_forward")
+        else:
+            if tuple(in_map) != (0.0, 1.0):
+                raise RuntimeError("grid_encode_forward: in_map needs the blc entry point")
+            check(lib.lae_grid_encode_forward(*args, stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                             gridtype, align_corners, interp, blc=False):
+                             gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0)):
         ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
         need_cuda(*ts); need_contig(*ts)
         if grad.dtype != grad_embeddings.dtype:
             raise RuntimeError("grid_encode_backward: grad and grad_embeddings dtypes differ")
         lib = _lib.load()
-        fn = lib.lae_grid_encode_backward_blc if blc else lib.lae_grid_encode_backward
-        check(fn(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
-                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad), stream()),
-              "grid_encode_backward")
+        args = (ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad))
+        if blc:
+            check(lib.lae_grid_encode_backward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_backward")
+        else:
+            if tuple(in_map) != (0.0, 1.0):
+                raise RuntimeError("grid_encode_backward: in_map needs the blc entry point")
+            check(lib.lae_grid_encode_backward(*args, stream()), "grid_encode_backward")
 
     @staticmethod
     def set_backward_mode(mode):

@@ -16,11 +16,15 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "lae_common.h"
+#include <vector>
 
 namespace {
 
 constexpr int MAX_LEVELS = 32;
-struct LevelScales { float scale[MAX_LEVELS]; };
+// scale[l] = exp2(l*S)*H - 1 (host, :138).  in_shift / in_scale: optional affine map applied to every coordinate as it
+// is read, x01 = (x + in_shift) * in_scale -- GridEncoder.forward's `(inputs + bound) / (2 * bound)` (grid.py:149; torch
+// evaluates the division by a Python scalar as a multiplication by its fp32 reciprocal) without two extra kernels.
+struct LevelScales { float scale[MAX_LEVELS]; float in_shift, in_scale; };
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        x[d] = inputs[(size_t)b * D + d];
+        x[d] = (inputs[(size_t)b * D + d] + sc.in_shift) * sc.in_scale;
         oob |= (x[d] < 0.0f) | (x[d] > 1.0f);
     }
     T* out = outputs + (size_t)b * os_b + (size_t)level * os_l;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     uint32_t pg[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const float xv = inputs[(size_t)b * D + d];
+        const float xv = (inputs[(size_t)b * D + d] + sc.in_shift) * sc.in_scale;
         if (xv < 0.0f || xv > 1.0f) return;                // :276-281
         float p = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
         const float fl = floorf(p);
@@ -339,33 +343,6 @@ __device__ __forceinline__ void lds_acc_add(uint32_t* acc, uint32_t e, float v0,
         atomicAdd(a, v0);
         atomicAdd(a + 1, v1);
     }
-}
-
-// per-sample cell data shared by both modes
-struct CellF { float frac[3]; uint32_t pg[3]; float g0, g1; bool ok; };
-
-template <typename T>
-__device__ __forceinline__ CellF load_cell(const float* __restrict__ inputs, const T* __restrict__ g_lvl, uint32_t b, uint32_t B,
-                                           float scale, bool align_corners, uint32_t interp) {
-    CellF c;
-    c.ok = b < B;
-    const uint32_t bb = c.ok ? b : 0;
-    float xv[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) xv[d] = inputs[(size_t)bb * 3 + d];
-    if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[bb]; c.g0 = (float)gv[0]; c.g1 = (float)gv[1]; }
-    else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[bb]; c.g0 = gv.x; c.g1 = gv.y; }
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        c.ok = c.ok && !(xv[d] < 0.0f) && !(xv[d] > 1.0f);
-        float pp = fmaf(xv[d], scale, align_corners ? 0.0f : 0.5f);
-        const float fl = floorf(pp);
-        c.pg[d] = (uint32_t)fl;
-        pp -= (float)c.pg[d];
-        if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
-        c.frac[d] = pp;
-    }
-    return c;
 }
 
 // MI355X grid backward, work-efficient form (D = 3, C = 2).
@@ -448,6 +425,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(
             xs[s_][0] = inputs[(size_t)b * 3]; xs[s_][1] = inputs[(size_t)b * 3 + 1]; xs[s_][2] = inputs[(size_t)b * 3 + 2];
         }
     }
+#pragma unroll
+    for (int s_ = 0; s_ < BIN_SPT; s_++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) xs[s_][d] = (xs[s_][d] + sc.in_shift) * sc.in_scale;
     const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
 #pragma unroll
     for (int s_ = 0; s_ < BIN_SPT; s_++) {
@@ -770,6 +751,7 @@ static int fill_scales(LevelScales& sc, uint32_t L, float S, uint32_t H) {
     if (L == 0 || L > MAX_LEVELS) return LAE_EINVAL;
     for (uint32_t l = 0; l < L; l++) sc.scale[l] = fmaf(exp2f((float)l * S), (float)H, -1.0f);   // :138
     for (uint32_t l = L; l < MAX_LEVELS; l++) sc.scale[l] = 0.f;
+    sc.in_shift = 0.0f; sc.in_scale = 1.0f;
     return LAE_OK;
 }
 
@@ -851,7 +833,8 @@ static int dispatch_bwd_d(const BwdArgs& a, uint32_t D, uint32_t C) {
 
 static int grid_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
                         uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype,
-                        int align_corners, uint32_t interp, int dtype, bool blc, void* stream) {
+                        int align_corners, uint32_t interp, int dtype, bool blc, void* stream, float in_shift = 0.0f,
+                        float in_scale = 1.0f) {
     if (B == 0) return LAE_OK;
     if (!inputs || !embeddings || !offsets || !outputs) return LAE_ENULL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
@@ -859,6 +842,7 @@ static int grid_forward(const float* inputs, const void* embeddings, const int32
     a.inputs = inputs; a.emb = embeddings; a.offsets = offsets; a.out = outputs; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
+    a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
     a.dy_dx = dy_dx; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
     a.stream = reinterpret_cast<hipStream_t>(stream);
     if (dtype != LAE_F32 && dtype != LAE_F16) return LAE_EINVAL;
@@ -881,6 +865,26 @@ static int grid_forward(const float* inputs, const void* embeddings, const int32
         else k_out_transpose<float><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const float*)lbc, (float*)outputs, B, L);
     }
     return lae::check_launch("grid_encode_forward");
+}
+
+// Level sizes on the host: offsets live in device memory (the reference passes a tensor), so the first call with a
+// given (pointer, L) copies the L+1 ints once, synchronously, and later calls reuse them.  First calls happen during
+// eager warm-up (workspaces are allocated there too), never inside a stream capture.
+struct HostOffsets { const int32_t* ptr; uint32_t L; std::vector<int32_t> v; };
+static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t L, hipStream_t stream) {
+    static std::vector<HostOffsets> cache;
+    for (const auto& c : cache)
+        if (c.ptr == offsets && c.L == L) return &c.v;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    HostOffsets h{offsets, L, std::vector<int32_t>(L + 1)};
+    if (hipMemcpy(h.v.data(), offsets, sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;                                    // unknown: callers take the conservative path
+    }
+    if (cache.size() > 64) cache.clear();
+    cache.push_back(std::move(h));
+    return &cache.back().v;
 }
 
 template <typename T>
@@ -907,8 +911,19 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     k_bin<T, true><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
                                                        block_counts, offs, queue);
     k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, counts, offs, queue);
-    // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel, exits at once otherwise
-    {
+    // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel; skipped when the host copy of
+    // the level sizes shows that no level needs it
+    bool need_generic = true;
+    if (const std::vector<int32_t>* ho = host_offsets(offsets, L, a.stream)) {
+        need_generic = false;
+        for (uint32_t l = 0; l < L; l++) {
+            const uint32_t size = (uint32_t)((*ho)[l + 1] - (*ho)[l]);
+            const uint32_t P = (size + (1u << HShift<T>::value) - 1) >> HShift<T>::value;
+            const uint32_t SUB = P >= BK_TARGET ? 1u : (BK_TARGET + P - 1) / P;
+            if (P * SUB > BK_MAX) need_generic = true;
+        }
+    }
+    if (need_generic) {
         const uint32_t nbg = lae::cdiv(B, GRID_BLOCK);
         k_grid_bwd<T, 3, 2><<<nbg * L, GRID_BLOCK, 0, a.stream>>>(g, inputs, offsets, ge, B, L, a.sc, a.gridtype, a.align, a.interp, nbg,
                                                                   (L % 8) == 0, 2, (uint64_t)B * 2, true);
@@ -922,7 +937,7 @@ static int g_force_atomic_bwd = 0;
 static int grid_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                          const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
-                         int dtype, bool blc, void* stream) {
+                         int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f) {
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
@@ -931,6 +946,7 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
+    a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
     a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
     a.gs_b = blc ? (uint64_t)L * C : C;
     a.gs_l = blc ? C : (uint64_t)B * C;
@@ -992,9 +1008,10 @@ int lae_grid_encode_forward(const float* inputs, const void* embeddings, const i
 }
 int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                 uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, void* stream) {
+                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float in_shift,
+                                float in_scale, void* stream) {
     return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
-                        dtype, true, stream);
+                        dtype, true, stream, in_shift, in_scale);
 }
 int lae_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
@@ -1006,9 +1023,10 @@ int lae_grid_encode_backward(const void* grad, const float* inputs, const void* 
 int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                  void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                  uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                                 int align_corners, uint32_t interp, int dtype, void* stream) {
+                                 int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
+                                 void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, dtype, true, stream);
+                         gridtype, align_corners, interp, dtype, true, stream, in_shift, in_scale);
 }
 
 int lae_grid_set_backward_mode(int mode) {

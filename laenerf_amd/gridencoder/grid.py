@@ -23,7 +23,7 @@ class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False, interpolation=0, shadow=None):
+                align_corners=False, interpolation=0, shadow=None, in_map=(0.0, 1.0)):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -41,9 +41,10 @@ class _grid_encode(Function):
         outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                     align_corners, interpolation, blc=True)
+                                     align_corners, interpolation, blc=True, in_map=in_map)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
+        ctx.in_map = in_map
         ctx.align_corners = align_corners
         return outputs
 
@@ -60,10 +61,13 @@ class _grid_encode(Function):
         grad_embeddings = ctx.shadow.grad_half if ctx.shadow is not None else torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                      grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True)
+                                      grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True, in_map=ctx.in_map)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, (None if ctx.shadow is not None else grad_embeddings), None, None, None, None, None, None, None, None
+            if ctx.in_map[1] != 1.0:
+                grad_inputs = grad_inputs * ctx.in_map[1]          # chain rule of the folded affine map
+        return (grad_inputs, (None if ctx.shadow is not None else grad_embeddings), None, None, None, None, None, None, None,
+                None, None)
 
 
 class TableShadow:
@@ -140,11 +144,13 @@ class GridEncoder(nn.Module):
                 f"gridtype={self.gridtype} align_corners={self.align_corners} interpolation={self.interpolation}")
 
     def forward(self, inputs, bound=1):
-        inputs = (inputs + bound) / (2 * bound)            # [-bound, bound] -> [0, 1]
+        # [-bound, bound] -> [0, 1] (grid.py:149) happens inside the kernels as (x + bound) * fp32(1 / (2 * bound)), which
+        # is how torch evaluates `(inputs + bound) / (2 * bound)` on the GPU: no separate add / div kernels
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
+        in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
         outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, self.shadow)
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, self.shadow, in_map)
         return outputs.view(prefix_shape + [self.output_dim])
 
     def attach_shadow(self):
