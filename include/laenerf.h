@@ -94,7 +94,8 @@ LAE_API int lae_packbits(const float* grid, uint32_t N, float density_thresh, ui
  * reference gives exactly this order).  counter[0] += sum(count),
  * counter[1] += N, like the reference's atomicAdds on a pre-zeroed counter.
  * `scratch` : caller-provided device workspace of lae_march_rays_train_scratch_bytes(N)
- * bytes (may be NULL only when N == 0).
+ * bytes (may be NULL only when N == 0): per-ray counts and offsets and, for N <= 2^18, the chunk records
+ * the counting pass leaves for the emitting pass (292 B per ray).
  * Sample rows no ray owns, [rows_end, M), are zero-filled by the kernel itself (the reference relies on the caller's
  * torch.zeros, raymarching.py:207-209); rows_end is also stored to rows_end_out (device uint32, may be NULL) for
  * lae_composite_rays_train_backward_blend. */

@@ -226,17 +226,41 @@ __device__ __forceinline__ bool uniform_step(float t_base, float dt, float& q) {
     return (top - t_base) > 64.0f * q && fabsf(r) != half_ulp && q > 0.0f;
 }
 
+// 64 candidates starting at t_base: lane i gets T_{base+i}, identical rounding to the serial walk
+__device__ __forceinline__ float candidate_t(const MarchCfg& cfg, float t_base, int lane) {
+    float t = t_base, q;
+    if (cfg.dt_gamma == 0.0f && uniform_step(t_base, cfg.dt_min, q)) {
+        t = t_base + (float)lane * q;                     // exact, see uniform_step
+    } else {
+#pragma unroll 8
+        for (int j = 0; j < 63; j++) {
+            const float tn = t + step_of(cfg, t);
+            t = (lane > j) ? tn : t;
+        }
+    }
+    return t;
+}
+
+// The count pass leaves one record per candidate chunk that emitted samples: where the chunk starts and which lanes
+// emit.  The emit pass replays the records (no bitfield probes, no chain resolution): it only rebuilds the candidate
+// times and writes rows.  A ray with more than MARCH_REC_MAX such chunks is flagged and walked again instead.
+constexpr uint32_t MARCH_REC_MAX = 24;
+constexpr uint32_t MARCH_REC_OVERFLOW = 0xffffffffu;
+struct MarchRec { float t_base; uint32_t lo, hi; };
+struct MarchRecs { uint32_t* nrec; MarchRec* rec; };      // nrec[N], rec[N * MARCH_REC_MAX]; both NULL = feature off
+
 // EMIT == false: count the samples of ray n.  EMIT == true: write them at `offset` (num_steps known).
 template <bool EMIT>
 __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchCfg cfg,
     uint32_t max_steps, uint32_t N, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays) {
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays, MarchRecs recs) {
     const uint32_t n = blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;                                   // whole wave
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t n_rec = 0;
 
     uint32_t limit = max_steps, offset = 0;
     if (EMIT) {
@@ -263,18 +287,39 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
     bool pending = false;                                 // walker is skipping towards pending_tt
     float pending_tt = 0.f;
 
+    if (EMIT && recs.nrec && recs.nrec[n] != MARCH_REC_OVERFLOW) {
+        // replay: same candidate times, same emit masks, same row arithmetic as the walk below
+        const uint32_t nr = recs.nrec[n];
+        const MarchRec* __restrict__ rr = recs.rec + (size_t)n * MARCH_REC_MAX;
+        for (uint32_t k = 0; k < nr; k++) {
+            const MarchRec rc = rr[k];
+            const unsigned long long emit = (unsigned long long)rc.lo | ((unsigned long long)rc.hi << 32);
+            const float t = candidate_t(cfg, rc.t_base, lane);
+            const float dt = step_of(cfg, t);
+            const float t_next = t + dt;
+            const unsigned long long pm = emit & below;
+            const int prev_lane = pm ? 63 - __builtin_clzll(pm) : 0;
+            const float prev_next = __shfl(t_next, prev_lane, 64);
+            if ((emit >> lane) & 1ull) {
+                const size_t row = (size_t)offset + emitted + (uint32_t)__builtin_popcountll(pm);
+                float* px = xyzs + 3 * row; float* pd = dirs + 3 * row; float* pl = deltas + 2 * row;
+                px[0] = clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound);
+                px[1] = clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound);
+                px[2] = clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound);
+                pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+                pl[0] = dt;
+                pl[1] = t_next - (pm ? prev_next : last_t);                   // :461
+            }
+            const int top = 63 - __builtin_clzll(emit);
+            last_t = __shfl(t_next, top, 64);
+            emitted += (uint32_t)__builtin_popcountll(emit);
+        }
+        return;
+    }
+
     while (t_base < far && emitted < limit) {
         // 1. candidates: lane i gets T_{base+i} by i serial steps (identical rounding to the serial walk)
-        float t = t_base, q;
-        if (cfg.dt_gamma == 0.0f && uniform_step(t_base, cfg.dt_min, q)) {
-            t = t_base + (float)lane * q;                 // exact, see uniform_step
-        } else {
-#pragma unroll 8
-            for (int j = 0; j < 63; j++) {
-                const float tn = t + step_of(cfg, t);
-                t = (lane > j) ? tn : t;
-            }
-        }
+        const float t = candidate_t(cfg, t_base, lane);
         const float dt = step_of(cfg, t);
         const float t_next = t + dt;                      // == T_{base+i+1}
         const bool valid = t < far;
@@ -315,6 +360,12 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
             cnt = keep;
             done = true;
         }
+        if (!EMIT && recs.nrec && emit) {                 // leave a record for the emit pass
+            if (n_rec < MARCH_REC_MAX) {
+                if (lane == 0) recs.rec[(size_t)n * MARCH_REC_MAX + n_rec] = MarchRec{t_base, (uint32_t)emit, (uint32_t)(emit >> 32)};
+                n_rec++;
+            } else n_rec = MARCH_REC_OVERFLOW;
+        }
         // 4. emit
         if (EMIT && emit) {
             const unsigned long long pm = emit & below;
@@ -335,7 +386,10 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
         if (done || valid_mask != ~0ull) break;           // cap reached, or the ray left [near, far) in this chunk
         t_base = __shfl(t_next, 63, 64);
     }
-    if (!EMIT && lane == 0) counts[n] = emitted;
+    if (!EMIT && lane == 0) {
+        counts[n] = emitted;
+        if (recs.nrec) recs.nrec[n] = n_rec;
+    }
 }
 
 // exclusive scan of the per-ray counts (single block) + counter update (:405-406).
@@ -697,8 +751,11 @@ int lae_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
     return lae::check_launch("packbits");
 }
 
+constexpr uint32_t MARCH_REC_RAYS_MAX = 1u << 18;         // replay records only for batches up to 256 k rays (73 MB of scratch)
+static inline uint64_t march_base_bytes(uint32_t N) { return ((4ull * (2ull * N + 3) + 60) + 15) / 16 * 16; }
 uint64_t lae_march_rays_train_scratch_bytes(uint32_t N) {
-    return 4ull * (2ull * N + 3) + 60;        // counts[N] | prefix[N + 2] | rows_end
+    // counts[N] | prefix[N + 2] | rows_end | (N <= 2^18:) nrec[N] | records[N * 24]
+    return march_base_bytes(N) + (N <= MARCH_REC_RAYS_MAX ? ((4ull * N + 15) / 16 * 16) + (uint64_t)N * MARCH_REC_MAX * sizeof(MarchRec) : 0ull);
 }
 
 int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
@@ -714,11 +771,17 @@ int lae_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* prefix = counts + N;
     hipStream_t s = STREAM(stream);
+    MarchRecs recs{nullptr, nullptr};
+    if (N <= MARCH_REC_RAYS_MAX) {
+        uint8_t* base = reinterpret_cast<uint8_t*>(scratch) + march_base_bytes(N);
+        recs.nrec = reinterpret_cast<uint32_t*>(base);
+        recs.rec = reinterpret_cast<MarchRec*>(base + (4ull * N + 15) / 16 * 16);
+    }
     k_march_train_wave<false><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
-                                                           counts, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                           counts, nullptr, nullptr, nullptr, nullptr, nullptr, recs);
     k_scan_counts<<<1, 1024, 0, s>>>(counts, N, M, prefix, counter, rows_end_out);
     k_march_train_wave<true><<<nblk, MARCH_BLOCK, 0, s>>>(rays_o, rays_d, grid, cfg, max_steps, N, M, nears, fars, noises,
-                                                          counts, prefix, xyzs, dirs, deltas, rays);
+                                                          counts, prefix, xyzs, dirs, deltas, rays, recs);
     return lae::check_launch("march_rays_train");
 }
 

@@ -67,6 +67,25 @@ def test_march_rays_train_bit_exact(O, C, bound, dtg, max_steps):
         assert np.array_equal(N(xyzs), ref[0]) and np.array_equal(N(dirs), ref[1]) and np.array_equal(N(deltas), ref[2])
 
 
+def test_march_rays_train_record_overflow_falls_back_to_walk(O):
+    """a half-occupied random grid at bound 8 spreads a ray's 1024 samples over more candidate chunks than the emit
+    pass keeps records for (24): those rays are walked again and must still be bit-identical"""
+    from laenerf_amd.backend import raymarching_backend as B
+    C, bound, Nr, max_steps = 4, 8.0, 333, 1024
+    sc = scene(C, bound, n_rays=Nr, seed=7, radius_cam=6.0)
+    bits = np.random.default_rng(11).integers(0, 256, sc["bits"].shape[0]).astype(np.uint8)
+    noises = np.random.default_rng(6).random(Nr).astype(np.float32)
+    M = Nr * max_steps
+    ref = O.march_rays_train(sc["o"], sc["d"], bound, bits, C, 128, sc["nears"], sc["fars"], noises, M=M, max_steps=max_steps)
+    assert (ref[3][:, 2] == max_steps).sum() > 50                    # many rays run into the cap, i.e. > 2000 candidates
+    xyzs = torch.empty(M, 3, device=DEV); dirs = torch.empty(M, 3, device=DEV); deltas = torch.empty(M, 2, device=DEV)
+    rays = torch.empty(Nr, 3, dtype=torch.int32, device=DEV); counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    B.march_rays_train(T(sc["o"]), T(sc["d"]), T(bits), bound, 0.0, max_steps, Nr, C, 128, M, T(sc["nears"]), T(sc["fars"]),
+                       xyzs, dirs, deltas, rays, counter, T(noises))
+    assert np.array_equal(N(rays), ref[3]) and np.array_equal(N(counter), ref[4])
+    assert np.array_equal(N(xyzs), ref[0]) and np.array_equal(N(dirs), ref[1]) and np.array_equal(N(deltas), ref[2])
+
+
 def test_march_rays_train_wrapper_modes(O, rm):
     """the autograd.Function front-end: trimming / mean_count sizing (raymarching.py:196-231)"""
     sc = scene(1, 1.0, n_rays=300, seed=2)
