@@ -255,6 +255,39 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
 // ---------------------------------------------------------------- K14
 // gridencoder.cu:248-340: scatter w*grad into grad_grid.  v1: one no-return atomic per
 // (corner, channel pair): global_atomic_add_f32 / global_atomic_pk_add_f16.
+// ---- constants and predicates of the binned backward (defined here because the generic kernel below is its companion)
+constexpr uint32_t BK_MAX = 256;              // buckets per level in the tables
+constexpr uint32_t BK_TARGET = 16;            // target workgroups per level
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_SPT = 8;                    // consecutive samples per lane
+constexpr uint32_t E_NONE = 0xffffu;
+
+template <typename T> struct HShift { static constexpr uint32_t value = sizeof(T) == 2 ? 13 : 14; };
+template <typename T> struct HItem;
+template <> struct HItem<half_t> { uint32_t e; half2_t v0, v1; uint32_t pad; };            // 16 B
+template <> struct HItem<float> { uint32_t e; float v0x, v0y, v1x, v1y; uint32_t pad; };    // 24 B
+
+struct LevelBins { uint32_t P, SUB; };
+template <typename T>
+__host__ __device__ __forceinline__ LevelBins level_bins_of(uint32_t hashmap_size) {
+    constexpr uint32_t SHIFT = HShift<T>::value;
+    LevelBins lb;
+    lb.P = (hashmap_size + (1u << SHIFT) - 1) >> SHIFT;
+    lb.SUB = lb.P >= BK_TARGET ? 1u : (BK_TARGET + lb.P - 1) / lb.P;
+    return lb;
+}
+template <typename T>
+__device__ __forceinline__ LevelBins level_bins(const LevelInfo<3>& li) { return level_bins_of<T>(li.hashmap_size); }
+
+// A level goes through the binned pipeline when its buckets fit the tables and, for hashed levels, both x corners of a
+// (y', z') pair provably share a partition (x' + 1 < 2^SHIFT).  Everything else is left to the generic atomic kernel.
+template <typename T>
+__host__ __device__ __forceinline__ bool level_is_binned(uint32_t hashmap_size, uint32_t resolution, bool use_hash) {
+    const LevelBins lb = level_bins_of<T>(hashmap_size);
+    return lb.P * lb.SUB <= BK_MAX && !(use_hash && resolution + 1 > (1u << HShift<T>::value));
+}
+
+
 template <typename T, int D, int C>
 __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     const T* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
@@ -266,11 +299,8 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
     if (b >= B) return;
     const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
-    if (only_unbinned) {      // companion of the binned fast path: only hashed levels with more partitions than the bucket tables hold
-        constexpr uint32_t SH = sizeof(T) == 2 ? 13 : 14;
-        const uint32_t P_ = (li.hashmap_size + (1u << SH) - 1) >> SH;
-        const uint32_t SUB_ = P_ >= 16u ? 1u : (16u + P_ - 1) / P_;
-        if (P_ * SUB_ <= 256u) return;
+    if (only_unbinned) {      // companion of the binned fast path: only the levels it leaves out
+        if constexpr (D == 3) { if (level_is_binned<T>(li.hashmap_size, li.resolution, li.use_hash)) return; }
     }
     T* __restrict__ tab = grad_grid + (size_t)li.table_off * C;
 
@@ -362,27 +392,6 @@ __device__ __forceinline__ void lds_acc_add(uint32_t* acc, uint32_t e, float v0,
 // fp16 grads accumulate EXACTLY as 2^-24 fixed point in int64 LDS words (ds_add_u64 ~0.8 cycles / lane-op vs ~3.2 for
 // ds_add_f32 / ds_pk_add_f16 on gfx950, tools/ubench/lds_atomic.hip; every fp16 value is a multiple of 2^-24), so the
 // result is the correctly rounded sum of the fp16 contributions, independent of order.  fp32 grads use ds_add_f32.
-constexpr uint32_t BK_MAX = 256;              // buckets per level in the tables
-constexpr uint32_t BK_TARGET = 16;            // target workgroups per level
-constexpr int BIN_THREADS = 256;
-constexpr int BIN_SPT = 8;                    // consecutive samples per lane
-constexpr uint32_t E_NONE = 0xffffu;
-
-template <typename T> struct HShift { static constexpr uint32_t value = sizeof(T) == 2 ? 13 : 14; };
-template <typename T> struct HItem;
-template <> struct HItem<half_t> { uint32_t e; half2_t v0, v1; uint32_t pad; };            // 16 B
-template <> struct HItem<float> { uint32_t e; float v0x, v0y, v1x, v1y; uint32_t pad; };    // 24 B
-
-struct LevelBins { uint32_t P, SUB; };
-template <typename T>
-__device__ __forceinline__ LevelBins level_bins(const LevelInfo<3>& li) {
-    constexpr uint32_t SHIFT = HShift<T>::value;
-    LevelBins lb;
-    lb.P = (li.hashmap_size + (1u << SHIFT) - 1) >> SHIFT;
-    lb.SUB = lb.P >= BK_TARGET ? 1u : (BK_TARGET + lb.P - 1) / lb.P;
-    return lb;
-}
-
 template <typename T, bool FILL>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin(
     const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(
     const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
     const LevelBins lb = level_bins<T>(li);
     const uint32_t nbk = lb.P * lb.SUB;
-    if (nbk > BK_MAX) return;                           // handled by the generic atomic kernel
+    if (!level_is_binned<T>(li.hashmap_size, li.resolution, li.use_hash)) return;   // handled by the generic atomic kernel
     __shared__ uint32_t hist[BK_MAX];
     __shared__ uint32_t base[BK_MAX];
     const uint32_t tid = threadIdx.x;
@@ -575,9 +584,9 @@ __global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
     // with dependent global loads: that serial walk cost ~300 us in an earlier version)
     __shared__ uint32_t s_cnt[MAX_LEVELS], s_sub[MAX_LEVELS];
     if (tid < L) {
-        const LevelBins lb = level_bins<T>(level_info<3>(sc, offsets, tid, gridtype, align_corners));
-        const uint32_t nbk = lb.P * lb.SUB;
-        s_cnt[tid] = nbk <= BK_MAX ? nbk : 0u;
+        const LevelInfo<3> li_ = level_info<3>(sc, offsets, tid, gridtype, align_corners);
+        const LevelBins lb = level_bins<T>(li_);
+        s_cnt[tid] = level_is_binned<T>(li_.hashmap_size, li_.resolution, li_.use_hash) ? lb.P * lb.SUB : 0u;
         s_sub[tid] = lb.SUB;
     }
     __syncthreads();
@@ -918,9 +927,10 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
         need_generic = false;
         for (uint32_t l = 0; l < L; l++) {
             const uint32_t size = (uint32_t)((*ho)[l + 1] - (*ho)[l]);
-            const uint32_t P = (size + (1u << HShift<T>::value) - 1) >> HShift<T>::value;
-            const uint32_t SUB = P >= BK_TARGET ? 1u : (BK_TARGET + P - 1) / P;
-            if (P * SUB > BK_MAX) need_generic = true;
+            const uint32_t res = (uint32_t)ceilf(a.sc.scale[l]) + 1;
+            const uint64_t side = a.align ? res : res + 1;
+            const bool use_hash = a.gridtype == 0 && side * side * side > size;
+            if (!level_is_binned<T>(size, res, use_hash)) need_generic = true;
         }
     }
     if (need_generic) {

@@ -75,9 +75,12 @@ def test_grid_backward_fp32(O, kw):
     assert np.allclose(N(ge2), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("kw", [dict(B=20000), dict(L=8, T_log2=12, desired=512, B=6000), dict(gridtype=1, T_log2=15, desired=1024)])
+@pytest.mark.parametrize("kw", [dict(B=20000), dict(L=8, T_log2=12, desired=512, B=6000), dict(gridtype=1, T_log2=15, desired=1024),
+                                dict(L=8, T_log2=16, desired=32768, B=8000)])
 def test_grid_backward_modes_agree(O, kw):
-    """binned LDS pipeline vs generic global-atomic kernel vs oracle (fp32), incl. hashed levels smaller than a partition"""
+    """binned LDS pipeline vs generic global-atomic kernel vs oracle (fp32), incl. hashed levels smaller than a partition
+    and (desired=32768) levels finer than a partition, whose x-corner pairs may straddle partitions: those levels must be
+    left to the generic kernel"""
     from laenerf_amd.backend import gridencoder_backend as G
     offsets, pls, table, x = grid_case(O, **kw)
     D, C, L, B = 3, 2, offsets.shape[0] - 1, x.shape[0]
