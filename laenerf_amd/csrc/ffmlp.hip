@@ -328,29 +328,35 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
 }
 
 // sum the per-slice slabs in a fixed order (deterministic) and round once to fp16.
-// 256 threads = 64 weights x 4 slice groups; unrolled by 4 so several slab loads are in flight per lane.
+// 1024 threads = 64 weights x 16 slice groups, 8 slab loads in flight per lane (the kernel is pure load latency: 512
+// slabs of 45 KB); the 16 partial sums are combined in a fixed tree.
 // accumulate != 0: gw += sum (the optimizer's persistent gradient buffer) instead of gw = sum.
-__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
-                                                    half_t* __restrict__ gw, int accumulate = 0) {
-    __shared__ float part[4][64];
+constexpr int DWR_GROUPS = 16;
+__global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
+                                                               half_t* __restrict__ gw, int accumulate = 0) {
+    __shared__ float part[DWR_GROUPS][64];
     const uint32_t e = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * 64 + e;
-    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < nW) {
         uint32_t k = sg;
-        for (; k + 12 < n_slices; k += 16) {
-            s0 += slabs[(size_t)k * nW + i];
-            s1 += slabs[(size_t)(k + 4) * nW + i];
-            s2 += slabs[(size_t)(k + 8) * nW + i];
-            s3 += slabs[(size_t)(k + 12) * nW + i];
+        for (; k + 7 * DWR_GROUPS < n_slices; k += 8 * DWR_GROUPS) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) s[u] += slabs[(size_t)(k + u * DWR_GROUPS) * nW + i];
         }
-        for (; k < n_slices; k += 4) s0 += slabs[(size_t)k * nW + i];
+        for (; k < n_slices; k += DWR_GROUPS) s[0] += slabs[(size_t)k * nW + i];
     }
-    part[sg][e] = (s0 + s1) + (s2 + s3);
+    part[sg][e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (sg == 0 && i < nW) {
-        const float sum = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-        gw[i] = accumulate ? (half_t)((float)gw[i] + sum) : (half_t)sum;
+        float t[DWR_GROUPS];
+#pragma unroll
+        for (int u = 0; u < DWR_GROUPS; u++) t[u] = part[u][e];
+#pragma unroll
+        for (int w = DWR_GROUPS / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; u++) t[u] = t[u] + t[u + w];
+        gw[i] = accumulate ? (half_t)((float)gw[i] + t[0]) : (half_t)t[0];
     }
 }
 
@@ -739,7 +745,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
     float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
     if (!ws) return LAE_ELAUNCH;
     k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
-    k_dw_reduce<<<lae::cdiv(nW, 64), 256, 0, s>>>(ws, blocks, nW, gw);
+    k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
     return LAE_OK;
 }
 
@@ -863,7 +869,7 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
     n_slices = lae::cdiv(B, rows_per_slice);
     k_mlp_dw<WIDTH><<<dim3(n_slices, n_jobs), MLP_BLOCK, 0, s>>>(grad, in, fwd_buf, bwd_buf, B, in_dim, n_hidden, g_ws, nW,
                                                                  rows_per_slice);
-    k_dw_reduce<<<lae::cdiv(nW, 64), 256, 0, s>>>(g_ws, n_slices, nW, gw);
+    k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(g_ws, n_slices, nW, gw);
     return LAE_OK;
 }
 

@@ -156,3 +156,28 @@ def test_nerf_head_rejects_bad_shapes():
         nerf_head(torch.zeros(24, 32, device=DEV, dtype=torch.half), torch.zeros(24, 3, device=DEV), w1, w2)
     with pytest.raises(RuntimeError):
         nerf_head(torch.zeros(32, 16, device=DEV, dtype=torch.half), torch.zeros(32, 3, device=DEV), w1, w2)
+
+
+def test_nerf_head_weight_gradients_accumulate_into_shadow_buffers():
+    """with a FusedAdam attached the head adds dW into the optimizer's persistent fp16 buffers: two backward passes
+    before one step() must leave twice the gradient of one"""
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=12).to(DEV)
+    net.train()
+    FusedAdam(net, lr=1e-2, grad_scaler=False)
+    x = torch.rand(2048, 3, device=DEV) * 1.6 - 0.8
+    d = torch.nn.functional.normalize(torch.randn(2048, 3, device=DEV), dim=-1)
+
+    def backward_once():
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = net(x, d)
+        (sigma.mean() + rgb.mean()).backward()
+
+    backward_once()
+    one = [m.shadow.grad_half.float().clone() for m in (net.sigma_net, net.color_net, net.encoder)]
+    assert all(float(g.abs().sum()) > 0 for g in one) and net.sigma_net.weights.grad is None
+    backward_once()
+    for g1, m in zip(one, (net.sigma_net, net.color_net, net.encoder)):
+        assert torch.allclose(m.shadow.grad_half.float(), 2 * g1, rtol=2e-3, atol=1e-6)
