@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
+    p.add_argument("--torch-loss", action="store_true", help="A/B: torch mse_loss + scale() instead of laenerf_amd.losses.mse_loss_scaled")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="A/B: torch.optim.Adam(fused) + torch.amp.GradScaler instead of laenerf_amd.optim.FusedAdam")
     return p.parse_args()
@@ -152,6 +153,9 @@ def main():
     else:
         from laenerf_amd.optim import FusedAdam
         opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    fused_loss = not args.torch_loss and not args.torch_optimizer
+    if fused_loss:
+        from laenerf_amd.losses import mse_loss_scaled
     n_batches = 16
     batches = []
     for b in range(n_batches):
@@ -163,8 +167,11 @@ def main():
     def step_body(o, d, gt):
         with torch.autocast("cuda", dtype=torch.float16):
             res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
-            loss = torch.nn.functional.mse_loss(res["image"], gt)
-        scaler.scale(loss).backward()
+            if fused_loss:                                  # criterion + GradScaler.scale in one kernel (losses.py)
+                loss = mse_loss_scaled(res["image"], gt, scaler)
+            else:
+                loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], gt))
+        loss.backward()
         if not args.no_optimizer:
             if args.torch_optimizer:
                 scaler.step(opt)

@@ -321,6 +321,12 @@ LAE_API int lae_adam_begin(void* state, float beta1, float beta2, int growth_int
 LAE_API int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void* grad, int grad_is_half, void* shadow_half, uint64_t n,
                    const void* state, const float* lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* Trainer criterion + loss scaling in one kernel (nerf/utils.py train_step: MSELoss(reduction='none')(pred, gt).mean(-1)
+ * .mean(), then GradScaler.scale): loss_out[0] = mean((pred - target)^2) * scale, loss_out[1] = the unscaled loss,
+ * grad[i] = d loss_out[0] / d pred[i].  scale: device float (FusedAdam state word 0) or NULL (= 1).  fp32, n elements. */
+LAE_API int lae_mse_loss_forward(const float* pred, const float* target, uint32_t n, const float* scale, float* loss_out, float* grad,
+                         void* stream);
+
 /* multi-tensor forms of check / apply: host arrays of n_tensors (<= 8) device pointers / sizes; one launch each */
 LAE_API int lae_adam_check_multi(uint32_t n_tensors, const void* const* grads, const int* grad_is_half, const uint64_t* sizes, void* state,
                          void* stream);

@@ -128,3 +128,23 @@ def test_training_with_fused_adam_tracks_torch_path():
     a, b = np.array(curves[0]), np.array(curves[1])
     assert a[-1] < a[0] * 0.95                                         # it trains (random targets: slowly)
     assert np.allclose(a, b, rtol=2e-2), (a, b)
+
+
+def test_mse_loss_scaled_matches_torch():
+    from laenerf_amd.losses import mse_loss_scaled
+    from laenerf_amd.optim import FusedAdam
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    pred = torch.rand(4096, 3, device=DEV, generator=gen, requires_grad=True)
+    gt = torch.rand(4096, 3, device=DEV, generator=gen)
+    fa = FusedAdam(small_net(), lr=1e-2, init_scale=512.0)
+    loss = mse_loss_scaled(pred, gt, fa)
+    loss.backward()
+    p2 = pred.detach().clone().requires_grad_()
+    ref = torch.nn.functional.mse_loss(p2, gt)
+    (ref * 512.0).backward()
+    assert torch.allclose(loss.unscaled, ref, rtol=1e-6) and torch.allclose(loss, ref * 512.0, rtol=1e-6)
+    assert torch.allclose(pred.grad, p2.grad, rtol=1e-6, atol=1e-12)
+    # the reference's form: criterion(reduction='none').mean(-1).mean()
+    assert torch.allclose(loss.unscaled, torch.nn.MSELoss(reduction="none")(p2, gt).mean(-1).mean(), rtol=1e-6)
+    plain = mse_loss_scaled(pred.detach(), gt)                        # no scaler
+    assert torch.allclose(plain, ref, rtol=1e-6)
