@@ -25,6 +25,25 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
+// K = 32 form (gfx950: the same 16 cycles as the K = 16 instruction, twice the work).  Lane group g owns k-slots
+// 8g..8g+7 of BOTH operands; we fill slots 8g..8g+3 from k-step `lo` and 8g+4..8g+7 from k-step `hi`, i.e. the two
+// 16-wide fragments a lane already holds in the K = 16 layout are simply concatenated.  A and B use the same
+// permutation of k, so the contraction is unchanged and activations still chain layer to layer in registers.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f4 mfma32(h4 a_lo, h4 a_hi, h4 b_lo, h4 b_hi, f4 c) {
+    const h8 a = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const h8 b = __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// acc += sum_{kt < KT} A(kt) * b[kt]: k-steps two at a time, one K = 16 step for an odd tail
+template <int KT, typename LoadA>
+__device__ __forceinline__ f4 mfma_ksteps(LoadA&& a_of, const h4* b, f4 acc) {
+#pragma unroll
+    for (int kt = 0; kt + 1 < KT; kt += 2) acc = mfma32(a_of(kt), a_of(kt + 1), b[kt], b[kt + 1], acc);
+    if constexpr (KT & 1) acc = mfma16(a_of(KT - 1), b[KT - 1], acc);
+    return acc;
+}
+
 #define K_ACT 10.0f   // ffmlp/src/utils.h:41
 __device__ __forceinline__ float act_fwd(uint32_t a, float v) {           // utils.h:424-470
     switch (a) {
@@ -391,14 +410,9 @@ __device__ __forceinline__ void stage_rows(half_t* dst, int ld, const half_t* __
 template <int KT>
 __device__ __forceinline__ void layer64(const half_t* Wl, int ld, const h4 (&in)[KT], int c, int g, f4 (&acc)[4]) {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        acc[mt] = f4{0, 0, 0, 0};
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) {
-            const h4 a = *reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g);
-            acc[mt] = mfma16(a, in[kt], acc[mt]);
-        }
-    }
+    for (int mt = 0; mt < 4; mt++)
+        acc[mt] = mfma_ksteps<KT>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g); },
+                                  in, f4{0, 0, 0, 0});
 }
 __device__ __forceinline__ void relu4(const f4 (&acc)[4], h4 (&out)[4]) {
 #pragma unroll
@@ -407,13 +421,7 @@ __device__ __forceinline__ void relu4(const f4 (&acc)[4], h4 (&out)[4]) {
         for (int r = 0; r < 4; r++) out[mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
 }
 __device__ __forceinline__ f4 out16(const half_t* Wl, int ld, const h4 (&in)[4], int c, int g) {
-    f4 o = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++) {
-        const h4 a = *reinterpret_cast<const h4*>(Wl + c * ld + kt * 16 + 4 * g);
-        o = mfma16(a, in[kt], o);
-    }
-    return o;
+    return mfma_ksteps<4>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + c * ld + kt * 16 + 4 * g); }, in, f4{0, 0, 0, 0});
 }
 
 // colour-net input fragments of a tile: k-step 0 = SH components 4g..4g+3 of the row's direction,
@@ -559,14 +567,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             f4 acc[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                acc[mt] = f4{0, 0, 0, 0};
-#pragma unroll
-                for (int kt = 0; kt < KT0; kt++) {
-                    const h4 a = *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g);
-                    acc[mt] = mfma16(a, xf[kt], acc[mt]);
-                }
-            }
+            for (int mt = 0; mt < 4; mt++)
+                acc[mt] = mfma_ksteps<KT0>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g); },
+                                           xf, f4{0, 0, 0, 0});
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
 #pragma unroll
@@ -576,14 +579,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int l = 0; l < NH; l++) {
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    acc[mt] = f4{0, 0, 0, 0};
-#pragma unroll
-                    for (int kt = 0; kt < 4; kt++) {
-                        const h4 a = *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g);
-                        acc[mt] = mfma16(a, h[l][kt], acc[mt]);
-                    }
-                }
+                for (int mt = 0; mt < 4; mt++)
+                    acc[mt] = mfma_ksteps<4>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g); },
+                                             h[l], f4{0, 0, 0, 0});
 #pragma unroll
                 for (int mt = 0; mt < 4; mt++) {
 #pragma unroll
@@ -629,12 +627,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             h4 dn[4];
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) {
-                f4 acc = f4{0, 0, 0, 0};
-#pragma unroll
-                for (int kt = 0; kt < 4; kt++) {
-                    const h4 a = lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp);   // W_l^T
-                    acc = mfma16(a, d[kt], acc);
-                }
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp); },   // W_l^T
+                                              d, f4{0, 0, 0, 0});
 #pragma unroll
                 for (int r = 0; r < 4; r++) dn[mt][r] = ((float)h[l - 1][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
             }
@@ -656,12 +650,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if constexpr (MODE == 1) {
-            f4 acc = f4{0, 0, 0, 0};
-#pragma unroll
-            for (int kt = 0; kt < 4; kt++) {
-                const h4 a = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp);            // W0^T, features 16..31
-                acc = mfma16(a, d[kt], acc);
-            }
+            const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp); },   // W0^T, features 16..31
+                                          d, f4{0, 0, 0, 0});
             const half_t v3 = (half_t)acc[3];
             const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
             h4 v;
@@ -672,12 +662,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else if (grad_in) {
 #pragma unroll
             for (int it = 0; it < KT0; it++) {
-                f4 acc = f4{0, 0, 0, 0};
-#pragma unroll
-                for (int kt = 0; kt < 4; kt++) {
-                    const h4 a = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp);    // W0^T
-                    acc = mfma16(a, d[kt], acc);
-                }
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp); },   // W0^T
+                                              d, f4{0, 0, 0, 0});
                 h4 v;
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];

@@ -132,8 +132,8 @@ def test_nerf_head_matches_operator_chain_and_oracle(O, M):
 
     s1, c1, ge1, gws1, gwc1 = run(True)
     s0, c0, ge0, gws0, gwc0 = run(False)
-    assert np.allclose(s1, s0, rtol=1e-5, atol=1e-7)                 # same fp16 h, expf vs torch.exp
-    assert np.abs(c1 - c0).max() <= 5e-4                              # both round the sigmoid to fp16 (<= 1 ulp apart)
+    assert np.allclose(s1, s0, rtol=2e-3, atol=1e-6)                 # h0 may differ by one fp16 ulp (K=32 vs K=16 MFMA summation order)
+    assert np.abs(c1 - c0).max() <= 1.5e-3                            # both round the sigmoid to fp16 (a few ulp apart)
     assert close_f16(ge1, ge0, floor=5e-4) and close_f16(gws1, gws0, rel=1e-2) and close_f16(gwc1, gwc0, rel=1e-2)
     # CPU oracle chain (forward)
     ws_h = O.to_f16_bits(N(net.sigma_net.weights)); wc_h = O.to_f16_bits(N(net.color_net.weights))
