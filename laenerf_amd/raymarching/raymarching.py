@@ -197,6 +197,7 @@ class _composite_rays_train_blend(Function):
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end)
         ctx.dims = [M, N, T_thresh, bg]
         ctx.mark_non_differentiable(depth_out)
+        ctx.set_materialize_grads(False)                 # an unused weights_sum arrives as None, not as a zero fill
         return weights_sum, depth_out, image_out
 
     @staticmethod
@@ -204,8 +205,12 @@ class _composite_rays_train_blend(Function):
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end = ctx.saved_tensors
         M, N, T_thresh, bg = ctx.dims
+        if grad_image is None and grad_weights_sum is None:
+            return None, None, None, None, None, None, None, None, None, None
         if grad_weights_sum is None:
             grad_weights_sum = torch.zeros_like(weights_sum)
+        if grad_image is None:
+            grad_image = torch.zeros_like(image)
         grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
         _backend.composite_rays_train_backward_blend(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
                                                      deltas, rays, weights_sum, image, M, N, T_thresh, bg_rays, bg, rows_end,
