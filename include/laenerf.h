@@ -218,6 +218,18 @@ LAE_API int lae_grid_encode_backward_blc(const void* grad, const float* inputs, 
                                  int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
                                  void* stream);
 
+/* General forms: blc = 0 -> [L,B,C] outputs / gradients (the reference layout, and what the fused field op keeps between
+ * encoder and MLP so that no transpose is needed), blc = 1 -> [B, L*C]; plus the coordinate map. */
+LAE_API int lae_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int blc, float in_shift,
+                               float in_scale, void* stream);
+LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                                int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
+                                void* stream);
+
 /* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
  * 1 = always the generic kernel (one global atomic per corner, what the reference does). */
 LAE_API int lae_grid_set_backward_mode(int mode);
@@ -270,9 +282,11 @@ LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void*
 /* MI355X-native fusion of NeRFNetwork.forward after the encoder (nerf/network_ff.py:57-79): sigma FFMLP(32,64,2 layers)
  * -> sigma = density_scale * exp(h[0]); colour input = [SH degree 4 of dirs | h[1..15] | 0] -> colour FFMLP(32,64,3 layers)
  * -> rgb = sigmoid(out[0..2]).  enc [M,32] fp16, dirs [M,3] fp32, weights in the FFMLP flat fp16 layout, M % 16 == 0.
- * Outputs: h_out [M,16] fp16 (sigma-net output, saved for the backward), sigmas [M] fp32, rgbs [M,3] fp32. */
+ * Outputs: h_out [M,16] fp16 (sigma-net output, saved for the backward), sigmas [M] fp32, rgbs [M,3] fp32.
+ * enc_level_major != 0: enc is the encoder's native [16, M, 2] layout (lae_grid_encode_forward) instead of [M,32]. */
 LAE_API int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
-                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, void* stream);
+                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, int enc_level_major,
+                          void* stream);
 
 /* The density query of NeRFNetwork.density (nerf/network_ff.py:83-96) after the encoder: sigma FFMLP -> sigma =
  * density_scale * exp(h[0]); h_out [M,16] fp16 (h[1..15] = geo_feat) may be NULL.  Used by update_extra_state. */
@@ -282,11 +296,12 @@ LAE_API int lae_nerf_density_forward(const void* enc, const void* sigma_weights,
 /* Backward of lae_nerf_head_forward: grad_sigmas [M], grad_rgbs [M,3] fp32 (as produced by
  * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).
  * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused.
- * accumulate_weight_grads != 0: grad_*_weights += dW (the fused optimizer's persistent buffers) instead of = dW. */
+ * accumulate_weight_grads != 0: grad_*_weights += dW (the fused optimizer's persistent buffers) instead of = dW.
+ * enc_level_major != 0: enc AND grad_enc are [16, M, 2] (what lae_grid_encode_backward consumes directly). */
 LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, int accumulate_weight_grads, void* stream);
+                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream);
 
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index

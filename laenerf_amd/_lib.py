@@ -40,6 +40,8 @@ SIGNATURES = {
     "lae_grid_encode_forward_blc": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, f32, f32, vp],
     "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
     "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, f32, f32, vp],
+    "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp],
+    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
     "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
@@ -47,12 +49,12 @@ SIGNATURES = {
     "lae_ffmlp_forward": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],
-    "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, vp],
+    "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, i32, vp],
     "lae_nerf_density_forward": [vp, vp, u32, f32, vp, vp, vp],
     "lae_density_grid_positions": [vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_density_grid_update": [vp, vp, u32, f32, f32, u32, vp, vp, vp],
     "lae_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, f32, i32, vp, vp],
-    "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, vp],
+    "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, i32, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],

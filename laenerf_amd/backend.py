@@ -230,9 +230,9 @@ class _GridEncoder:
                 int(bool(align_corners)), interp, _dtype_code(embeddings))
         if blc:
             check(lib.lae_grid_encode_forward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_forward")
+        elif tuple(in_map) != (0.0, 1.0):
+            check(lib.lae_grid_encode_forward_ex(*args, 0, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_forward")
         else:
-            if tuple(in_map) != (0.0, 1.0):
-                raise RuntimeError("grid_encode_forward: in_map needs the blc entry point")
             check(lib.lae_grid_encode_forward(*args, stream()), "grid_encode_forward")
 
     @staticmethod
@@ -247,9 +247,9 @@ class _GridEncoder:
                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad))
         if blc:
             check(lib.lae_grid_encode_backward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_backward")
+        elif tuple(in_map) != (0.0, 1.0):
+            check(lib.lae_grid_encode_backward_ex(*args, 0, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_backward")
         else:
-            if tuple(in_map) != (0.0, 1.0):
-                raise RuntimeError("grid_encode_backward: in_map needs the blc entry point")
             check(lib.lae_grid_encode_backward(*args, stream()), "grid_encode_backward")
 
     @staticmethod
@@ -320,13 +320,13 @@ class _FFMLP:
                                              ptr(grad_weights), stream()), "ffmlp_backward")
 
     @staticmethod
-    def nerf_head_forward(enc, dirs, sigma_weights, color_weights, M, density_scale, h_out, sigmas, rgbs):
+    def nerf_head_forward(enc, dirs, sigma_weights, color_weights, M, density_scale, h_out, sigmas, rgbs, level_major=False):
         """MI355X-native: network_ff.py:57-79 after the grid encoder, in one kernel (include/laenerf.h)"""
         ts = (enc, dirs, sigma_weights, color_weights, h_out, sigmas, rgbs)
         need_cuda(*ts); need_contig(*ts); _FFMLP._half(enc, sigma_weights, color_weights, h_out)
         check(_lib.load().lae_nerf_head_forward(ptr(enc), ptr(dirs), ptr(sigma_weights), ptr(color_weights), M,
-                                                float(density_scale), ptr(h_out), ptr(sigmas), ptr(rgbs), stream()),
-              "nerf_head_forward")
+                                                float(density_scale), ptr(h_out), ptr(sigmas), ptr(rgbs),
+                                                int(bool(level_major)), stream()), "nerf_head_forward")
 
     @staticmethod
     def nerf_density_forward(enc, sigma_weights, M, density_scale, h_out, sigmas):
@@ -337,7 +337,7 @@ class _FFMLP:
 
     @staticmethod
     def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,
-                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights, accumulate=False):
+                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights, accumulate=False, level_major=False):
         ts = (grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, grad_h, grad_enc,
               grad_sigma_weights, grad_color_weights)
         need_cuda(*ts); need_contig(*ts)
@@ -345,7 +345,8 @@ class _FFMLP:
         check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
                                                  ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
                                                  ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
-                                                 ptr(grad_color_weights), int(bool(accumulate)), stream()), "nerf_head_backward")
+                                                 ptr(grad_color_weights), int(bool(accumulate)), int(bool(level_major)),
+                                                 stream()), "nerf_head_backward")
 
     @staticmethod
     def ffmlp_set_mode(mode):

@@ -484,12 +484,30 @@ struct FusedCfg {
     static constexpr int LDS_HALVES = W_HALVES + 4 * WAVE_HALVES;
 };
 
+// B fragments of a 32-wide encoder row.  Row-major [M,32]: features 16kt + 4g .. +3 are one 8-byte load.  Level-major
+// [16][M][2] (the grid kernels' native layout): the same four features are the channel pairs of levels 8kt + 2g and
+// 8kt + 2g + 1 -- two 4-byte loads, 64 contiguous bytes per level for the 16 rows of a tile.
+__device__ __forceinline__ void load_enc_frags(const half_t* __restrict__ enc, size_t row, size_t M, int g, int level_major, h4 (&xf)[2]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; kt++) {
+        if (level_major) {
+            const uint32_t lo = *reinterpret_cast<const uint32_t*>(enc + ((size_t)(8 * kt + 2 * g) * M + row) * 2);
+            const uint32_t hi = *reinterpret_cast<const uint32_t*>(enc + ((size_t)(8 * kt + 2 * g + 1) * M + row) * 2);
+            const uint2 v{lo, hi};
+            xf[kt] = __builtin_bit_cast(h4, v);
+        } else {
+            xf[kt] = *reinterpret_cast<const h4*>(enc + row * 32 + kt * 16 + 4 * g);
+        }
+    }
+}
+
 // MODE 1 = colour net of the fused NeRF head: the input rows are built on the fly from (h, dirs) exactly like
 // k_nerf_head_fwd, dL/dout comes from (grad_rgb, rgb) through the sigmoid, and instead of dL/dX the kernel writes
 // dL/dh [M,16] = [ grad_sigma * density_scale * exp(clamp(h0, -15, 15)) | dX[16..30] ] (trunc_exp backward,
 // activation.py:14-17, and the inverse of the one-feature shift) -- the sigma net's backward reads that directly.
 struct HeadBwdArgs {
     const float* dirs; const float* rgbs; const float* grad_rgbs; const float* grad_sigmas; float density_scale;
+    int level_major;        // MODE 0, IN = 32: x and grad_in are [16][B][2] (the grid kernels' layout) instead of [B,32]
 };
 
 template <int IN, int NH, int MODE>
@@ -555,8 +573,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         } else {
+            if constexpr (KT0 == 2) {
+                load_enc_frags(x, row, (size_t)n_tiles * 16, g, ha.level_major, xf);
+            } else {
 #pragma unroll
-            for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+                for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+            }
             gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
         }
 #pragma unroll
@@ -667,7 +689,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 h4 v;
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];
-                *reinterpret_cast<h4*>(grad_in + row * IN + it * 16 + 4 * g) = v;
+                if (KT0 == 2 && ha.level_major) {           // two level planes, 64 contiguous bytes per plane and tile
+                    const uint2 u = __builtin_bit_cast(uint2, v);
+                    const size_t Bn = (size_t)n_tiles * 16;
+                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g) * Bn + row) * 2) = u.x;
+                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g + 1) * Bn + row) * 2) = u.y;
+                } else
+                    *reinterpret_cast<h4*>(grad_in + row * IN + it * 16 + 4 * g) = v;
             }
         }
         wave_lds_fence();                                   // tiles are rewritten by the next iteration
@@ -738,7 +766,8 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
 template <bool COLOR>
 __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
-    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
+    int level_major) {
     using C = HeadCfg;
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     stage_rows(lds + C::S0, C::LDX, Ws, 64, 32);
@@ -756,8 +785,7 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
         const size_t row = (size_t)tile * 16 + c;
         h4 xf[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; kt++) xf[kt] = *reinterpret_cast<const h4*>(enc + row * 32 + kt * 16 + 4 * g);
+        load_enc_frags(enc, row, (size_t)n_tiles * 16, g, level_major, xf);
         f4 acc[4];
         h4 a0[4], a1[4];
         layer64<2>(lds + C::S0, C::LDX, xf, c, g, acc); relu4(acc, a0);
@@ -922,7 +950,8 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
 }
 
 int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
-                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, void* stream) {
+                          uint32_t M, float density_scale, void* h_out, float* sigmas, float* rgbs, int enc_level_major,
+                          void* stream) {
     if (M == 0) return LAE_OK;
     if (!enc || !dirs || !sigma_weights || !color_weights || !h_out || !sigmas || !rgbs) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
@@ -937,7 +966,7 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
     k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
         (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
-        (half_t*)h_out, sigmas, rgbs);
+        (half_t*)h_out, sigmas, rgbs, enc_level_major);
     return lae::check_launch("nerf_head_forward");
 }
 
@@ -950,14 +979,14 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
     const uint32_t n_tiles = M / 16;
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
     k_nerf_head_fwd<false><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr);
+        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr, 0);
     return lae::check_launch("nerf_density_forward");
 }
 
 int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, int accumulate_weight_grads, void* stream) {
+                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream) {
     if (!grad_sigma_weights || !grad_color_weights) return LAE_ENULL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {                                        // no samples: zero weight gradients (like the reference's GEMMs on empty batches)
@@ -968,12 +997,14 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
     }
     if (!grad_sigmas || !grad_rgbs || !enc || !dirs || !h || !rgbs || !sigma_weights || !color_weights || !grad_h) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
-    HeadBwdArgs ha{dirs, rgbs, grad_rgbs, grad_sigmas, density_scale};
+    HeadBwdArgs ha{dirs, rgbs, grad_rgbs, grad_sigmas, density_scale, 0};
+    HeadBwdArgs hs{};
+    hs.level_major = enc_level_major;
     int rc = launch_bwd_fused<32, 2, 1>(nullptr, (const half_t*)h, (const half_t*)color_weights, M, (half_t*)grad_h,
                                         (half_t*)grad_color_weights, s, ha, accumulate_weight_grads);
     if (rc != LAE_OK) return rc;
     rc = launch_bwd_fused<32, 1, 0>((const half_t*)grad_h, (const half_t*)enc, (const half_t*)sigma_weights, M, (half_t*)grad_enc,
-                                    (half_t*)grad_sigma_weights, s, HeadBwdArgs{}, accumulate_weight_grads);
+                                    (half_t*)grad_sigma_weights, s, hs, accumulate_weight_grads);
     if (rc != LAE_OK) return rc;
     return lae::check_launch("nerf_head_backward");
 }

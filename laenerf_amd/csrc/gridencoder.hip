@@ -1039,6 +1039,22 @@ int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const vo
                          gridtype, align_corners, interp, dtype, true, stream, in_shift, in_scale);
 }
 
+int lae_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int blc, float in_shift,
+                               float in_scale, void* stream) {
+    return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                        dtype, blc != 0, stream, in_shift, in_scale);
+}
+int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                                int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
+                                void* stream) {
+    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
+                         gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale);
+}
+
 int lae_grid_set_backward_mode(int mode) {
     if (mode != 0 && mode != 1) return LAE_EINVAL;
     g_force_atomic_bwd = mode;

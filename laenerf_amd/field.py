@@ -1,0 +1,81 @@
+"""Encoder + head as ONE autograd op (MI355X-native): everything `NeRFNetwork.forward` does (nerf/network_ff.py:51-81).
+
+Between the hash-grid kernels and the MLP kernels the features stay in the grid kernels' native level-major layout
+[16, M, 2]: the forward needs no [L,B,C] -> [B,L*C] transpose (grid.py:57 does it with a permute copy) and the backward
+hands the MLP's input gradient to the grid backward without the inverse one (grid.py:75).  Numerically identical to
+`GridEncoder` followed by `nerf_head` (same kernels, same arithmetic; only the addressing differs).
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from .backend import ffmlp_backend as _mlp
+from .backend import gridencoder_backend as _grid
+from .ffmlp.head import COLOR_NET_PARAMS, SIGMA_NET_PARAMS
+
+
+class _nerf_field(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, x, dirs, embeddings, sigma_weights, color_weights, enc, sigma_shadow, color_shadow, bound, density_scale):
+        M = x.shape[0]
+        L = enc.num_levels
+        x = x.float().contiguous()
+        dirs = dirs.float().contiguous()
+        table = enc.shadow.table_half(embeddings) if enc.shadow is not None else embeddings.to(torch.half)
+        shadows = (sigma_shadow, color_shadow) if sigma_shadow is not None and color_shadow is not None else None
+        if shadows is not None:
+            ws, wc = sigma_shadow.table_half(sigma_weights), color_shadow.table_half(color_weights)
+        else:
+            ws, wc = sigma_weights.half().contiguous(), color_weights.half().contiguous()
+        in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+        S, H = np.log2(enc.per_level_scale), enc.base_resolution
+        feats = torch.empty(L, M, 2, device=x.device, dtype=torch.half)                 # level-major
+        _grid.grid_encode_forward(x, table, enc.offsets, feats, M, 3, 2, L, S, H, None, enc.gridtype_id, enc.align_corners,
+                                  enc.interp_id, blc=False, in_map=in_map)
+        h = torch.empty(M, 16, device=x.device, dtype=torch.half)
+        sigmas = torch.empty(M, device=x.device, dtype=torch.float32)
+        rgbs = torch.empty(M, 3, device=x.device, dtype=torch.float32)
+        _mlp.nerf_head_forward(feats, dirs, ws, wc, M, density_scale, h, sigmas, rgbs, level_major=True)
+        ctx.save_for_backward(x, dirs, table, ws, wc, feats, h, rgbs)
+        ctx.enc, ctx.shadows, ctx.in_map, ctx.geom = enc, shadows, in_map, (M, L, S, H)
+        ctx.density_scale = density_scale
+        ctx.wdtypes = (sigma_weights.dtype, color_weights.dtype)
+        return sigmas, rgbs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_sigmas, grad_rgbs):
+        x, dirs, table, ws, wc, feats, h, rgbs = ctx.saved_tensors
+        enc = ctx.enc
+        M, L, S, H = ctx.geom
+        grad_sigmas = grad_sigmas.float().contiguous()
+        grad_rgbs = grad_rgbs.float().contiguous()
+        grad_h = torch.empty_like(h)
+        grad_feats = torch.empty_like(feats)                                              # level-major, like feats
+        if ctx.shadows is not None:
+            gws, gwc = ctx.shadows[0].grad_half, ctx.shadows[1].grad_half
+        else:
+            gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
+        _mlp.nerf_head_backward(grad_sigmas, grad_rgbs, feats, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h, grad_feats,
+                                gws, gwc, accumulate=ctx.shadows is not None, level_major=True)
+        grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
+        _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
+                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map)
+        return (None, None, None if enc.shadow is not None else grad_table,
+                None if ctx.shadows is not None else gws.to(ctx.wdtypes[0]),
+                None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None)
+
+
+def field_supported(enc, sigma_net, color_net):
+    return (enc.input_dim == 3 and enc.level_dim == 2 and enc.num_levels == 16
+            and sigma_net.weights.numel() == SIGMA_NET_PARAMS and color_net.weights.numel() == COLOR_NET_PARAMS)
+
+
+def nerf_field(x, dirs, enc, sigma_net, color_net, bound=1, density_scale=1.0):
+    """x [M,3] in [-bound, bound], dirs [M,3] unit -> sigmas [M] fp32, rgbs [M,3] fp32 (fp16 table and MLPs; M % 16 == 0)"""
+    if x.shape[0] % 16 != 0:
+        raise RuntimeError("nerf_field: the number of samples must be a multiple of 16")
+    return _nerf_field.apply(x, dirs, enc.embeddings, sigma_net.weights, color_net.weights, enc, sigma_net.shadow,
+                             color_net.shadow, float(bound), float(density_scale))

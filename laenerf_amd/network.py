@@ -11,6 +11,7 @@ import torch.nn as nn
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .ffmlp import FFMLP, nerf_density, nerf_head
+from .field import field_supported, nerf_field
 
 
 class NeRFNetwork(nn.Module):
@@ -36,9 +37,14 @@ class NeRFNetwork(nn.Module):
         self.fused_head = (encoding_dir == "sphere_harmonics" and self.in_dim == 32 and self.in_dim_color == 32
                            and num_layers == 2 and num_layers_color == 3 and hidden_dim == 64 and hidden_dim_color == 64
                            and geo_feat_dim == 15 and getattr(self.encoder_dir, "degree", 0) == 4)
+        self.fused_field = self.fused_head and encoding == "hashgrid" and field_supported(self.encoder, self.sigma_net, self.color_net)
 
     def forward(self, x, d):
         """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N] fp32, rgb [N,3]   (network_ff.py:51-81)"""
+        if (self.fused_field and self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and torch.is_autocast_enabled("cuda")
+                and not x.requires_grad and not d.requires_grad):
+            # encoder + head as one op: features stay level-major between the grid and MLP kernels (field.py)
+            return nerf_field(x.view(-1, 3), d, self.encoder, self.sigma_net, self.color_net, self.bound)
         x = self.encoder(x, bound=self.bound)
         if self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and x.dtype == torch.half and not d.requires_grad:
             return nerf_head(x, d, self.sigma_net.weights, self.color_net.weights, 1.0, self.sigma_net.shadow, self.color_net.shadow)

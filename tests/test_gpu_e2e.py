@@ -46,11 +46,14 @@ def test_train_render_and_gradients(tag):
     hit = g["train_ws"] > 0
     assert np.abs(N(res["depth"])[hit] - g["train_depth"][hit]).max() < 2e-3
     assert loss.item() == pytest.approx(float(g["train_loss"]), rel=2e-3)
-    loss.backward()
+    # fp16 gradients need the loss scale the reference trains with (GradScaler): unscaled, the table gradients of this
+    # fixture are ~1e-6, i.e. a handful of fp16 subnormal steps
+    SCALE = 1024.0
+    (loss * SCALE).backward()
     for name, ref in (("sigma_net", g["g_sigma_w"]), ("color_net", g["g_color_w"])):
-        got = N(getattr(net, name).weights.grad)
+        got = N(getattr(net, name).weights.grad) / SCALE
         assert np.abs(got - ref).max() < 0.05 * np.abs(ref).max() + 1e-6, name
-    gt = N(net.encoder.embeddings.grad)
+    gt = N(net.encoder.embeddings.grad) / SCALE
     assert np.linalg.norm(gt) == pytest.approx(float(g["g_table_norm"]), rel=0.05)
     assert np.abs(gt[::997] - g["g_table_sample"]).max() < 0.05 * np.abs(g["g_table_sample"]).max() + 1e-9
     # steady-state sizing with an under-estimated mean_count: overflowing rays drop to background
