@@ -259,7 +259,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
 constexpr uint32_t BK_MAX = 256;              // buckets per level in the tables
 constexpr uint32_t BK_TARGET = 16;            // target workgroups per level
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_SPT = 8;                    // consecutive samples per lane
+constexpr int BIN_SPT = 16;                   // consecutive samples per lane
 constexpr uint32_t E_NONE = 0xffffu;
 
 template <typename T> struct HShift { static constexpr uint32_t value = sizeof(T) == 2 ? 13 : 14; };
