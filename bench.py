@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=40)
     p.add_argument("--rays", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-frame", action="store_true", help="skip the 800x800 inference-frame timing (extra field eval_frame)")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
@@ -110,6 +111,28 @@ def cpu_baseline(n_rays_hint, n_threads):
     return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": n_threads, "kind": "port",
             "sample": f"{n_rays} rays = {n_steps} step(s) of the same 4096-ray workload ({tot} samples), forward+backward "
                       f"without optimizer, oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
+
+
+def eval_frame(net, r, dev, H=800, W=800):
+    """whole-frame inference render (march_rays / composite_rays loop of run_cuda, renderer.py:335-387) of one 800x800
+    view with the network as trained by the timed steps; median of 5 frames after one warm-up"""
+    from laenerf_amd import synthetic as S
+    o, d = S.frame_rays(H, W)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    was_training = net.training
+    net.eval(); r.eval()
+    times = []
+    for it in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            res = r.render_eval(o, d, bg_color=1, max_steps=1024)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    net.train(was_training); r.train(was_training)
+    t = sorted(times[1:])[2]
+    return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
+            "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
+            "note": "800x800 inference render, T_thresh 1e-4, device-side alive-ray compaction"}
 
 
 def main():
@@ -297,6 +320,8 @@ def main():
                          "avg_launch_us": round(gf["ms"] / max(gf["calls"], 1) * 1e3, 2)},
             "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
         }
+        if world == 1 and not args.no_frame:
+            out["eval_frame"] = eval_frame(net, r, dev)        # the "ms/frame" half of BASELINE.json's metric (not `value`)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
