@@ -350,8 +350,9 @@ LAE_API int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float
                          const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
- * backward_buffer untouched: both are scratch the reference's Python never reads); 1 = always the
- * three-kernel path that fills both buffers exactly like the reference. */
+ * backward_buffer untouched: both are scratch the reference's Python never reads), dW tiles divided among the waves of
+ * a workgroup; 1 = always the three-kernel path that fills both buffers exactly like the reference; 2 = fused backward
+ * with every wave accumulating all dW tiles over its own rows (the first fused design, kept for A/B). */
 LAE_API int lae_ffmlp_set_mode(int mode);
 
 /* ffmlp.cu:721-740: the reference keeps process-global side streams for its

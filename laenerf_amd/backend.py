@@ -350,7 +350,8 @@ class _FFMLP:
 
     @staticmethod
     def ffmlp_set_mode(mode):
-        """0 = fused backward (default), 1 = buffer-faithful three-kernel backward (fills forward/backward buffers)"""
+        """0 = fused backward, workgroup-cooperative dW (default); 1 = buffer-faithful three-kernel backward (fills
+        forward/backward buffers); 2 = fused backward with wave-private dW tiles"""
         check(_lib.load().lae_ffmlp_set_mode(int(mode)), "ffmlp_set_mode")
 
     @staticmethod

@@ -742,23 +742,273 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---------------------------------------------------------------- fused backward, workgroup-cooperative dW
+// Same mathematics as k_mlp_bwd_fused, different ownership of the weight-gradient tiles.  There every wave accumulates
+// ALL dW tiles of the net over its own rows (176 accumulator registers for the colour net -> 2 waves/SIMD with spills,
+// and a cross-wave reduction at the end).  Here a workgroup of WAVES waves shares one [16*WAVES rows] tile of X, H, D, G
+// in LDS: each wave still runs the forward recompute and the dL/dH chain for its own 16 rows in registers, but after a
+// barrier the dW tiles are DIVIDED among the waves, each contracted over all 16*WAVES rows with K = 32 MFMAs.  Per wave
+// that is 6 accumulator tiles instead of 44, half as many dW MFMAs, no final reduction, and 4 waves/SIMD.
+template <int IN, int NH, int WAVES>
+struct CoopCfg {
+    static constexpr int KT0 = IN / 16;
+    static constexpr int R = 16 * WAVES;                   // rows per workgroup iteration
+    static constexpr int LDX = IN + 8, LDH = 72, LDG = 24;
+    static constexpr int W0_OFF = 0;
+    static constexpr int WH_OFF = 64 * LDX;
+    static constexpr int WO_OFF = WH_OFF + NH * 64 * LDH;
+    static constexpr int W_HALVES = WO_OFF + 16 * LDH;
+    static constexpr int X_OFF = W_HALVES;
+    static constexpr int H_OFF = X_OFF + R * LDX;
+    static constexpr int D_OFF = H_OFF + R * LDH;
+    static constexpr int G_OFF = D_OFF + R * LDH;
+    static constexpr int LDS_HALVES = G_OFF + R * LDG;
+    static constexpr int TH = 16 / WAVES > 0 ? 16 / WAVES : 1;                      // hidden-layer dW tiles per wave
+    static constexpr int T0 = (4 * KT0 + WAVES - 1) / WAVES;                        // input-layer dW tiles per wave
+};
+
+template <int IN, int NH, int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_mlp_bwd_coop(
+    const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
+    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW, HeadBwdArgs ha) {
+    using C = CoopCfg<IN, NH, WAVES>;
+    constexpr int KT0 = C::KT0, R = C::R, NT = 64 * WAVES;
+    static_assert(16 % WAVES == 0 && WAVES >= 4, "dW tiles are dealt round-robin to 4, 8 or 16 waves");
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* Wl = lds;
+    half_t* Xs = lds + C::X_OFF; half_t* Hs = lds + C::H_OFF; half_t* Ds = lds + C::D_OFF; half_t* Gs = lds + C::G_OFF;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int r0 = 16 * w;                                   // this wave's rows inside the shared tiles
+
+    for (uint32_t e = threadIdx.x; e < 64u * IN / 4; e += NT) {
+        const uint32_t r = (e * 4) / IN, k = (e * 4) % IN;
+        *reinterpret_cast<h4*>(Wl + C::W0_OFF + r * C::LDX + k) = *reinterpret_cast<const h4*>(W + (size_t)r * IN + k);
+    }
+    for (uint32_t e = threadIdx.x; e < (uint32_t)NH * 64 * 64 / 4; e += NT) {
+        const uint32_t m = (e * 4) / 4096, r = ((e * 4) % 4096) / 64, k = (e * 4) % 64;
+        *reinterpret_cast<h4*>(Wl + C::WH_OFF + (m * 64 + r) * C::LDH + k) =
+            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)m * 4096 + r * 64 + k);
+    }
+    for (uint32_t e = threadIdx.x; e < 16u * 64 / 4; e += NT) {
+        const uint32_t r = (e * 4) / 64, k = (e * 4) % 64;
+        *reinterpret_cast<h4*>(Wl + C::WO_OFF + r * C::LDH + k) =
+            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)NH * 4096 + r * 64 + k);
+    }
+
+    f4 aO = f4{0, 0, 0, 0};
+    f4 aH[NH][C::TH], a0[C::T0];
+#pragma unroll
+    for (int m = 0; m < NH; m++)
+#pragma unroll
+        for (int i = 0; i < C::TH; i++) aH[m][i] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < C::T0; i++) a0[i] = f4{0, 0, 0, 0};
+
+    // dW tile (mt, nt) += A^T B over the R shared rows: A block mt of tile `At` (ld lda), B block nt of tile `Bt` (ld ldb)
+    auto dw_tile = [&](const half_t* At, int lda, int mt, const half_t* Bt, int ldb, int nt, f4 acc) {
+#pragma unroll
+        for (int ks = 0; ks < R / 32; ks++) {
+            const half_t* ar = At + (32 * ks + 4 * g + tq) * lda + mt * 16 + 4 * tp;
+            const half_t* br = Bt + (32 * ks + 4 * g + tq) * ldb + nt * 16 + 4 * tp;
+            acc = mfma32(lds_tr_read(ar), lds_tr_read(ar + 16 * lda), lds_tr_read(br), lds_tr_read(br + 16 * ldb), acc);
+        }
+        return acc;
+    };
+
+    const uint32_t n_groups = (n_tiles + WAVES - 1) / WAVES;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t tile = grp * WAVES + w;
+        const bool active = tile < n_tiles;
+        const size_t row = (size_t)(active ? tile : 0) * 16 + c;
+        const h4 zero4 = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+        // ---- inputs of this wave's 16 rows
+        h4 xf[KT0];
+        h4 gf = zero4, hq = zero4;
+        if constexpr (MODE == 1) {
+            hq = *reinterpret_cast<const h4*>(x + row * 16 + 4 * g);
+            color_inputs(ha.dirs, row, hq, g, xf);
+            if (g == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const float y = ha.rgbs[row * 3 + r];
+                    gf[r] = (half_t)(ha.grad_rgbs[row * 3 + r] * y * (1.0f - y));
+                }
+            }
+        } else {
+            if constexpr (KT0 == 2) {
+                load_enc_frags(x, row, (size_t)n_tiles * 16, g, ha.level_major, xf);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+            }
+            gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
+        }
+        if (!active) {                                       // rows past the batch contribute nothing
+#pragma unroll
+            for (int kt = 0; kt < KT0; kt++) xf[kt] = zero4;
+            gf = zero4;
+        }
+        __syncthreads();                                     // S0: readers of X / G / H / D of the previous group are done
+#pragma unroll
+        for (int kt = 0; kt < KT0; kt++) *reinterpret_cast<h4*>(Xs + (r0 + c) * C::LDX + kt * 16 + 4 * g) = xf[kt];
+        *reinterpret_cast<h4*>(Gs + (r0 + c) * C::LDG + 4 * g) = gf;
+        // ---- recompute the hidden activations of the own rows (registers)
+        h4 h[NH + 1][4];
+        {
+            f4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                acc[mt] = mfma_ksteps<KT0>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g); },
+                                           xf, f4{0, 0, 0, 0});
+            relu4(acc, h[0]);
+#pragma unroll
+            for (int l = 0; l < NH; l++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+                    acc[mt] = mfma_ksteps<4>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g); },
+                                             h[l], f4{0, 0, 0, 0});
+                relu4(acc, h[l + 1]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(Hs + (r0 + c) * C::LDH + mt * 16 + 4 * g) = h[NH][mt];
+        __syncthreads();                                     // S1: G and H_NH of all rows are in LDS
+        // ---- output layer: dWout tile nt = w (waves 0..3) ; own rows: dH_NH = (Wout^T G) * relu'
+        if (w < 4) aO = dw_tile(Gs, C::LDG, 0, Hs, C::LDH, w, aO);
+        h4 d[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const h4 a = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);             // A[f][o] = Wout[o][f]
+            const f4 acc = mfma16(a, gf, f4{0, 0, 0, 0});
+#pragma unroll
+            for (int r = 0; r < 4; r++) d[mt][r] = ((float)h[NH][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
+        }
+        // ---- hidden layers, last to first
+#pragma unroll
+        for (int l = NH; l >= 1; l--) {
+            __syncthreads();                                 // S2: readers of H and D are done
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                *reinterpret_cast<h4*>(Ds + (r0 + c) * C::LDH + mt * 16 + 4 * g) = d[mt];
+                *reinterpret_cast<h4*>(Hs + (r0 + c) * C::LDH + mt * 16 + 4 * g) = h[l - 1][mt];
+            }
+            __syncthreads();                                 // S3: D_l and H_{l-1} of all rows are in LDS
+#pragma unroll
+            for (int i = 0; i < C::TH; i++) {
+                const int t = w + i * WAVES;                 // tile (mt, nt) = (t / 4, t % 4)
+                aH[l - 1][i] = dw_tile(Ds, C::LDH, t / 4, Hs, C::LDH, t % 4, aH[l - 1][i]);
+            }
+            h4 dn[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp); },   // W_l^T
+                                              d, f4{0, 0, 0, 0});
+#pragma unroll
+                for (int r = 0; r < 4; r++) dn[mt][r] = ((float)h[l - 1][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) d[mt] = dn[mt];
+        }
+        // ---- input layer: dW0 tiles dealt to the waves ; own rows: dX = W0^T dH_0
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(Ds + (r0 + c) * C::LDH + mt * 16 + 4 * g) = d[mt];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < C::T0; i++) {
+            const int t = w + i * WAVES;                     // tile (mt, nt) = (t / KT0, t % KT0)
+            if (t < 4 * KT0) a0[i] = dw_tile(Ds, C::LDH, t / KT0, Xs, C::LDX, t % KT0, a0[i]);
+        }
+        if constexpr (MODE == 1) {
+            const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp); },   // W0^T, features 16..31
+                                          d, f4{0, 0, 0, 0});
+            const half_t v3 = (half_t)acc[3];
+            const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
+            h4 v;
+            v[0] = prev;
+            if (g == 0) v[0] = (half_t)(ha.grad_sigmas[row] * ha.density_scale * expf(lae::clampf((float)hq[0], -15.0f, 15.0f)));
+            v[1] = (half_t)acc[0]; v[2] = (half_t)acc[1]; v[3] = (half_t)acc[2];
+            if (active) *reinterpret_cast<h4*>(grad_in + row * 16 + 4 * g) = v;
+        } else if (grad_in) {
+#pragma unroll
+            for (int it = 0; it < KT0; it++) {
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp); },   // W0^T
+                                              d, f4{0, 0, 0, 0});
+                h4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];
+                if (!active) continue;
+                if (KT0 == 2 && ha.level_major) {
+                    const uint2 u = __builtin_bit_cast(uint2, v);
+                    const size_t Bn = (size_t)n_tiles * 16;
+                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g) * Bn + row) * 2) = u.x;
+                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g + 1) * Bn + row) * 2) = u.y;
+                } else
+                    *reinterpret_cast<h4*>(grad_in + row * IN + it * 16 + 4 * g) = v;
+            }
+        }
+    }
+
+    // ---- every wave owns its tiles: straight to this workgroup's slab (C/D layout: lane (c, g), reg r = element [4g + r][c])
+    float* slab = slabs + (size_t)blockIdx.x * nW;
+    auto store_tile = [&](size_t base, int ld, const f4& v) {        // element [rr][cc] of the tile -> base + rr * ld + cc
+#pragma unroll
+        for (int r = 0; r < 4; r++) slab[base + (size_t)(4 * g + r) * ld + c] = v[r];
+    };
+#pragma unroll
+    for (int i = 0; i < C::T0; i++) {
+        const int t = w + i * WAVES;
+        if (t < 4 * KT0) store_tile((size_t)((t / KT0) * 16) * IN + (t % KT0) * 16, IN, a0[i]);
+    }
+#pragma unroll
+    for (int m = 0; m < NH; m++)
+#pragma unroll
+        for (int i = 0; i < C::TH; i++) {
+            const int t = w + i * WAVES;
+            store_tile((size_t)64 * IN + (size_t)m * 4096 + (size_t)((t / 4) * 16) * 64 + (t % 4) * 16, 64, aH[m][i]);
+        }
+    if (w < 4) store_tile((size_t)64 * IN + (size_t)NH * 4096 + w * 16, 64, aO);
+}
+
+// 0 = workgroup-cooperative dW (default), 1 = wave-private dW (k_mlp_bwd_fused); A/B switch, see lae_ffmlp_set_mode
+int g_bwd_fused_variant = 0;
+
 template <int IN, int NH, int MODE = 0>
 int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
                      HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0) {
-    using C = FusedCfg<IN, NH>;
     const uint32_t nW = 64 * (IN + 64 * NH + 16);
     const uint32_t n_tiles = B / 16;
-    const size_t lds_bytes = std::max((size_t)C::LDS_HALVES * 2, (size_t)C::N_TILES * 1024);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
-        attr_set = true;
+    uint32_t blocks;
+    float* ws;
+    if (g_bwd_fused_variant == 0) {
+        constexpr int WAVES = 8;
+        using C = CoopCfg<IN, NH, WAVES>;
+        const size_t lds_bytes = (size_t)C::LDS_HALVES * 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_coop<IN, NH, MODE, WAVES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+            attr_set = true;
+        }
+        blocks = std::max(1u, std::min(lae::cdiv(n_tiles, WAVES), (uint32_t)lae::num_cus() * 2));
+        ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        if (!ws) return LAE_ELAUNCH;
+        k_mlp_bwd_coop<IN, NH, MODE, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
+    } else {
+        using C = FusedCfg<IN, NH>;
+        const size_t lds_bytes = std::max((size_t)C::LDS_HALVES * 2, (size_t)C::N_TILES * 1024);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+            attr_set = true;
+        }
+        blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
+        ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        if (!ws) return LAE_ELAUNCH;
+        k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     }
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
-    float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
-    if (!ws) return LAE_ELAUNCH;
-    k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
     return LAE_OK;
 }
@@ -924,7 +1174,7 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
     int rc;
     // fused path: recomputes the activations, never touches forward_buffer / backward_buffer (both are scratch
     // that the reference's Python allocates and never reads, ffmlp.py:31-35,71)
-    if (g_ffmlp_mode == 0 && hidden_dim == 64 && activation == LAE_ACT_RELU && (nh == 1 || nh == 2) &&
+    if (g_ffmlp_mode != 1 && hidden_dim == 64 && activation == LAE_ACT_RELU && (nh == 1 || nh == 2) &&
         (input_dim == 32 || input_dim == 48 || input_dim == 64)) {
         rc = LAE_EINVAL;
         if (nh == 1 && input_dim == 32) rc = launch_bwd_fused<32, 1>(g, in, W, B, gi, gw, s);
@@ -1010,8 +1260,9 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
 }
 
 int lae_ffmlp_set_mode(int mode) {
-    if (mode != 0 && mode != 1) return LAE_EINVAL;
-    g_ffmlp_mode = mode;
+    if (mode < 0 || mode > 2) return LAE_EINVAL;
+    g_ffmlp_mode = mode == 1 ? 1 : 0;                       // 1: buffer-faithful three-kernel backward
+    g_bwd_fused_variant = mode == 2 ? 1 : 0;                // 2: fused backward with wave-private dW tiles
     return LAE_OK;
 }
 

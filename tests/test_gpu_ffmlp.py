@@ -40,9 +40,9 @@ def test_ffmlp_forward_backward(O, IN, H, NL, B):
     # mode 1: the buffer-faithful path (fills backward_buffer like the reference); mode 0: fused path where available
     # (recomputes the activations, needs neither buffer)
     try:
-        for mode in (1, 0):
+        for mode in (1, 0, 2):
             F.ffmlp_set_mode(mode)
-            fused = mode == 0 and F.fused_backward_available(IN, H, NL, 0)
+            fused = mode != 1 and F.fused_backward_available(IN, H, NL, 0)
             gi.zero_(); gw.zero_()
             F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), None if fused else half_from_bits(ref_fb),
                              B, IN, 16, H, NL, 0, 6, True, None if fused else bb, gi, gw)
