@@ -167,6 +167,37 @@ LAE_API int lae_composite_rays_distill(uint32_t n_alive, uint32_t n_step, float 
                                float* depth, float* depth_edit,
                                const uint8_t* edit_occ, float* image, void* stream);
 
+/* MI355X-native extension: the whole inference loop of NeRFRenderer.run_cuda (nerf/renderer.py:335-387) -- and of
+ * run_cuda_distill (:394-480) when edit_grid != NULL -- as ONE call.  near_far_from_aabb, then per iteration
+ * march_rays -> hash-grid encode -> fused sigma/colour head -> composite_rays -> alive-list compaction, with
+ * n_alive / n_step / step kept in device memory and advanced on the device exactly like the Python
+ * (`n_step = max(min(row_budget // n_alive, max_n_step), 1)`; the reference has row_budget = N (pass 0) and
+ * max_n_step = 8; a larger row_budget trades buffer memory for fewer, larger iterations -- per-ray sample sequences
+ * are unchanged, only the float rounding of rays_t between iterations can differ; loop ends when no ray is alive or
+ * step >= max_steps), then `image + (1 - weights_sum) * bg` (blend_bg) and `clamp(depth - nears, 0) / (fars - nears)`
+ * (scale_depth).  The host never waits for the device inside the loop: it sizes launches from a lagging upper bound of
+ * n_alive mirrored into pinned memory.  Not stream-capturable (LAE_EINVAL while capturing).
+ *   table_f16 [sum level sizes, 2] fp16, offsets [L+1] int32, L = 16, S = log2(per_level_scale), base_resolution;
+ *   sigma_weights / color_weights: FFMLP flat fp16 images of the 32->64->64->16 and 32->64->64->64->16 nets;
+ *   noises [N] or NULL (perturb, applied in the first iteration only, renderer.py:365); bg_rays [N,3] or NULL (then
+ *   bg_r/g/b); outputs weights_sum, depth [N], image [N,3] fp32 (+ weights_edit, depth_edit [N] when edit_grid);
+ *   workspace: lae_render_frame_workspace_bytes(N, L, row_budget) bytes of device memory owned by the caller;
+ *   stats_out (host, may be NULL; makes the call wait for the loop's last iteration): [iterations, rows through the
+ *   network, iterations launched]. */
+LAE_API uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_budget);
+/* A/B switch: 1 (default) runs the lookahead marcher on a library-owned side stream beside the encoder / MLP kernels,
+ * 0 runs it in-line on the caller's stream. */
+LAE_API int lae_render_frame_set_overlap(int on);
+LAE_API int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
+                     const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, uint32_t L, float S,
+                     uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp,
+                     const void* sigma_weights, const void* color_weights, float density_scale, float T_thresh,
+                     uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
+                     float bg_b, int blend_bg, int scale_depth, float* weights_sum, float* depth, float* image,
+                     float* weights_edit, float* depth_edit, void* workspace, uint64_t workspace_bytes, uint32_t* stats_out,
+                     void* stream);
+
 /* MI355X-native extension (no reference counterpart; replaces the host-side
  * `rays_alive = rays_alive[rays_alive >= 0]` + size sync at renderer.py:375,459):
  * order-preserving device-side compaction of the alive list.

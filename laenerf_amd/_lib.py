@@ -34,6 +34,10 @@ SIGNATURES = {
     "lae_march_rays_distill": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_composite_rays": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_composite_rays_distill": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_render_frame_workspace_bytes": [u32, u32, u64],
+    "lae_render_frame_set_overlap": [i32],
+    "lae_render_frame": [vp, vp, u32, vp, f32, vp, vp, f32, f32, u32, u32, u32, vp, vp, u32, f32, u32, u32, i32, u32, vp, vp, f32, f32,
+                         u32, u64, vp, vp, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp, vp],
     "lae_compact_scratch_bytes": [u32],
     "lae_compact_rays_alive": [vp, u32, vp, vp, vp, vp],
     "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
@@ -70,6 +74,7 @@ SIGNATURES = {
 _RESTYPES = {
     "lae_march_rays_train_scratch_bytes": u64,
     "lae_compact_scratch_bytes": u64,
+    "lae_render_frame_workspace_bytes": u64,
     "lae_version": ctypes.c_char_p,
     "lae_last_error": ctypes.c_char_p,
 }

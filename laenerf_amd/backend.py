@@ -204,6 +204,43 @@ class _RayMarching:
                                                      ptr(depth_edit), ptr(int_edit), ptr(image), stream()),
               "composite_rays_distill")
 
+    # MI355X-native extension (no reference counterpart): the whole inference loop on the device
+    @staticmethod
+    def render_frame(rays_o, rays_d, N, aabb, min_near, grid, edit_grid, bound, dt_gamma, max_steps, C, H, table_f16, offsets, L, S,
+                     base_resolution, gridtype, align_corners, interp, sigma_weights, color_weights, density_scale, T_thresh,
+                     max_n_step, row_budget, noises, bg_rays, bg_rgb, blend_bg, scale_depth, weights_sum, depth, image,
+                     weights_edit, depth_edit, want_stats=False):
+        """whole inference loop of run_cuda / run_cuda_distill as one call (include/laenerf.h lae_render_frame)"""
+        import ctypes
+        tensors = (rays_o, rays_d, aabb, grid, edit_grid, table_f16, offsets, sigma_weights, color_weights, noises, bg_rays,
+                   weights_sum, depth, image, weights_edit, depth_edit)
+        need_cuda(*tensors); need_contig(*tensors)
+        if rays_o.dtype != torch.float32 or rays_d.dtype != torch.float32 or table_f16.dtype != torch.half or \
+                sigma_weights.dtype != torch.half or color_weights.dtype != torch.half or offsets.dtype != torch.int32 or \
+                grid.dtype != torch.uint8:
+            raise RuntimeError("render_frame: rays float32, table / MLP weights float16, offsets int32, bitfield uint8")
+        lib = _lib.load()
+        nbytes = lib.lae_render_frame_workspace_bytes(N, L, int(row_budget))
+        key = ("frame", rays_o.device.index if rays_o.device.index is not None else torch.cuda.current_device())
+        ws = _scratch.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=rays_o.device)
+            _scratch[key] = ws
+        stats = (ctypes.c_uint32 * 4)() if want_stats else None
+        check(lib.lae_render_frame(ptr(rays_o), ptr(rays_d), N, ptr(aabb), float(min_near), ptr(grid), ptr(edit_grid), float(bound),
+                                   float(dt_gamma), max_steps, C, H, ptr(table_f16), ptr(offsets), L, float(S), base_resolution,
+                                   gridtype, int(bool(align_corners)), interp, ptr(sigma_weights), ptr(color_weights),
+                                   float(density_scale), float(T_thresh), max_n_step, int(row_budget), ptr(noises), ptr(bg_rays), float(bg_rgb[0]),
+                                   float(bg_rgb[1]), float(bg_rgb[2]), int(bool(blend_bg)), int(bool(scale_depth)), ptr(weights_sum),
+                                   ptr(depth), ptr(image), ptr(weights_edit), ptr(depth_edit), ptr(ws), ws.numel(),
+                                   ctypes.cast(stats, ctypes.c_void_p) if want_stats else None, stream()), "render_frame")
+        return {"iterations": stats[0], "rows": stats[1], "iterations_launched": stats[2]} if want_stats else None
+
+    @staticmethod
+    def render_frame_set_overlap(on):
+        """A/B switch: lookahead marcher on a side stream beside the network kernels (default) or in-line"""
+        check(_lib.load().lae_render_frame_set_overlap(int(bool(on))), "render_frame_set_overlap")
+
     # MI355X-native extension (no reference counterpart): device-side alive-list compaction
     @staticmethod
     def compact_rays_alive(rays_alive, n_alive, out_alive, n_out_dev):

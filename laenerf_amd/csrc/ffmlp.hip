@@ -1017,8 +1017,12 @@ template <bool COLOR>
 __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
     uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
-    int level_major) {
+    int level_major, const uint32_t* __restrict__ n_rows_dev, uint32_t lm_rows) {
     using C = HeadCfg;
+    // frame loop: live row count from the device (rounded up to whole 16-row tiles, the producer keeps those rows benign);
+    // lm_rows = row capacity of the level-major feature image
+    if (n_rows_dev) n_tiles = min(n_tiles, (*n_rows_dev + 15u) / 16u);
+    if (n_tiles == 0) return;
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     stage_rows(lds + C::S0, C::LDX, Ws, 64, 32);
     stage_rows(lds + C::S1, C::LDH, Ws + 64 * 32, 64, 64);
@@ -1035,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
         const size_t row = (size_t)tile * 16 + c;
         h4 xf[2];
-        load_enc_frags(enc, row, (size_t)n_tiles * 16, g, level_major, xf);
+        load_enc_frags(enc, row, (size_t)lm_rows, g, level_major, xf);
         f4 acc[4];
         h4 a0[4], a1[4];
         layer64<2>(lds + C::S0, C::LDX, xf, c, g, acc); relu4(acc, a0);
@@ -1139,6 +1143,27 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
 
 }  // namespace
 
+// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], live rows = *n_rows_dev
+int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                                 uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
+                                 float* rgbs, hipStream_t stream) {
+    if (M_launch == 0) return LAE_OK;
+    if (M_cap % 16 != 0) return LAE_EINVAL;
+    const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+        attr_set = true;
+    }
+    const uint32_t n_tiles = M_cap / 16, launch_tiles = lae::cdiv(std::min(M_launch, M_cap), 16);
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(launch_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, stream>>>((const half_t*)enc, dirs, (const half_t*)sigma_weights,
+                                                            (const half_t*)color_weights, n_tiles, density_scale, nullptr, sigmas,
+                                                            rgbs, 1, n_rows_dev, M_cap);
+    return LAE_OK;
+}
+
 extern "C" {
 
 int lae_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
@@ -1216,7 +1241,7 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
     k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
         (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
-        (half_t*)h_out, sigmas, rgbs, enc_level_major);
+        (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M);
     return lae::check_launch("nerf_head_forward");
 }
 
@@ -1229,7 +1254,8 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
     const uint32_t n_tiles = M / 16;
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
     k_nerf_head_fwd<false><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr, 0);
+        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr, 0,
+        nullptr, M);
     return lae::check_launch("nerf_density_forward");
 }
 

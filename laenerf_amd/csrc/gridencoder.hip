@@ -14,6 +14,7 @@
 // the oracle uses the same host libm, so fp32 results are bit-identical to it.
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include "lae_common.h"
 #include <vector>
@@ -108,11 +109,14 @@ template <typename T, int D, int C>
 __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
     const float* __restrict__ inputs, const T* __restrict__ grid, const int32_t* __restrict__ offsets,
     T* __restrict__ outputs, uint32_t B, uint32_t L, LevelScales sc, T* __restrict__ dy_dx, uint32_t gridtype,
-    bool align_corners, uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t os_b, uint64_t os_l) {
+    bool align_corners, uint32_t interp, uint32_t nb, bool xcd_mode, uint64_t os_b, uint64_t os_l,
+    const uint32_t* __restrict__ B_dev) {
     uint32_t level, chunk;
     block_to_level_chunk(nb, xcd_mode, level, chunk);
     if (level >= L) return;
     const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    // B_dev (frame loop): the live row count is produced on the device; B stays the capacity the strides are built from
+    if (B_dev) B = min(B, *B_dev);
     if (b >= B) return;
     const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
     const T* __restrict__ tab = grid + (size_t)li.table_off * C;
@@ -767,15 +771,16 @@ static int fill_scales(LevelScales& sc, uint32_t L, float S, uint32_t H) {
 struct FwdArgs {
     const float* inputs; const void* emb; const int32_t* offsets; void* out; uint32_t B, L; LevelScales sc;
     void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
+    const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
 };
 
 template <typename T, int D, int C>
 static void launch_fwd(const FwdArgs& a) {
-    const uint32_t nb = lae::cdiv(a.B, GRID_BLOCK);
+    const uint32_t nb = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
     const bool xcd = (a.L % 8) == 0;
     k_grid_fwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
                                                                 a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb,
-                                                                xcd, a.os_b, a.os_l);
+                                                                xcd, a.os_b, a.os_l, a.B_dev);
 }
 template <typename T, int D>
 static int dispatch_fwd_c(const FwdArgs& a, uint32_t C) {
@@ -1007,6 +1012,24 @@ static int tv_c(const float* inputs, const float* emb, float* grad, const int32_
 }
 
 }  // namespace
+
+// frame loop (raymarching.hip lae_render_frame): fp16 table, D=3, C=2, level-major output [L, B_cap, 2]; rows beyond
+// *B_dev are not touched.  B_launch = host upper bound of *B_dev (sizes the launch only).
+int lae::grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
+                            uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                            int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream) {
+    if (B_launch == 0) return LAE_OK;
+    FwdArgs a;
+    a.inputs = inputs; a.emb = embeddings; a.offsets = offsets; a.out = outputs; a.B = B_cap; a.L = L;
+    int rc = fill_scales(a.sc, L, S, H);
+    if (rc) return rc;
+    a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
+    a.dy_dx = nullptr; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
+    a.stream = stream; a.os_b = 2; a.os_l = (uint64_t)B_cap * 2;
+    a.B_dev = B_dev; a.B_launch = std::min(B_launch, B_cap);
+    launch_fwd<half_t, 3, 2>(a);
+    return LAE_OK;
+}
 
 extern "C" {
 

@@ -9,6 +9,8 @@ void set_last_error(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
 
+void set_last_error_str(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
+
 static std::mutex g_ws_mutex;
 static void* g_ws[WS_SLOTS] = {};
 static size_t g_ws_bytes[WS_SLOTS] = {};

@@ -17,6 +17,16 @@ enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_GRID_OUT_T = 2, WS_GRID
 void* workspace(WsSlot slot, size_t bytes);
 void free_workspaces();
 int num_cus();
+void set_last_error_str(const char* what);
+
+// entry points of the whole-frame inference loop into the encoder / MLP translation units (lae_render_frame,
+// raymarching.hip): same kernels as the C ABI, live row count read from device memory
+int grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
+                       uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                       int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream);
+int nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                            uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
+                            float* rgbs, hipStream_t stream);
 
 // every launch is followed by this: the reference never checked its launches
 // (SURVEY 8b "Errors"); we do, and surface the error through the return code.

@@ -9,6 +9,10 @@
 // -ffp-contract=off; the a*b+c shapes that nvcc contracts in the reference are
 // explicit fmaf() here, everything else is separate IEEE ops, so t-sequences,
 // voxel indices, sample counts and positions are bit-identical to the oracle.
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <mutex>
 #include "lae_common.h"
 
 namespace {
@@ -706,6 +710,351 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void k_compact_scatter(const int32_t
     if (v >= 0) out[block_prefix[blockIdx.x] + local_prefix[i]] = v;
 }
 
+
+// ---------------------------------------------------------------- whole-frame inference loop (MI355X-native)
+// The reference renders a frame with a HOST loop (renderer.py:352-379): every iteration launches march_rays, the
+// network, composite_rays, compacts the alive list with a boolean mask and reads its length back -- one device sync and
+// ~20 launches per iteration, ~75 iterations per 800x800 frame.  Here the loop state lives in device memory:
+//   * k_frame_composite: each workgroup owns a contiguous range of the alive list and writes its survivors, in order,
+//     into its own segment + a per-segment count (no atomics, deterministic order);
+//   * k_frame_emit of the NEXT iteration: every workgroup sums the <= 512 segment counts (n_alive and its own segment's
+//     offset), derives the loop state exactly like the Python (`n_step = max(min(N // n_alive, 8), 1)`, `step += n_step`,
+//     stop when no ray is alive or step >= max_steps), gathers its rays into the compact alive list and writes their sample rows;
+//     workgroup 0 publishes the state (FrameCtrl, double-buffered) for the encoder / MLP / compositing kernels and
+//     mirrors n_alive into pinned host memory, from which the host sizes later launches without ever synchronising.
+// Marching is split in two, because sample positions are pure geometry (they do not depend on the network):
+//   * k_frame_lookahead walks every alive ray ahead and records the times of its next <= 8 samples (max_n_step); it runs
+//     on a SIDE STREAM concurrently with the encoder / MLP kernels of the same iteration.  A lane walks its ray like the
+//     reference for a few visits; lanes still crossing empty space afterwards (~200 instructions per voxel at 1/64
+//     utilisation; measured: every iteration waited ~100 us for such stragglers when this ran in-line) are finished one
+//     by one with all 64 lanes when they are few (frame_lookahead_coop, the candidate scheme of the training march).
+//   * k_frame_emit (in-line) replays the first n_step recorded samples of every surviving ray into the sample rows:
+//     positions and deltas are recomputed from the recorded times with the reference's arithmetic, no probing.
+// The lookahead also advances its own copy of rays_t with the compositing kernel's arithmetic (t += deltas[1] per
+// sample), so every iteration starts from bit-identical times to the host loop's.
+struct FrameCtrl { uint32_t n_alive, n_step, n_rows, step, iter, done, total_rows, pad; };
+static_assert(sizeof(FrameCtrl) == 32, "FrameCtrl layout");
+struct FrameMirror { volatile uint64_t tag; volatile uint32_t n_alive, done, total_rows, iters; };   // pinned host memory
+constexpr int FRAME_BLOCK = 256;
+constexpr uint32_t FRAME_SEG_MAX = 512;        // compositing workgroups = survivor segments
+constexpr uint32_t FRAME_LA = 8;               // recorded samples per ray (>= max_n_step)
+
+__global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const float* __restrict__ nears,
+                             float* __restrict__ rays_t, float* __restrict__ tc, float* __restrict__ weights_sum,
+                             float* __restrict__ depth, float* __restrict__ image, float* __restrict__ weights_edit,
+                             float* __restrict__ depth_edit) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) ctrl[0] = FrameCtrl{};                    // state "before iteration 0": step = 0, nothing issued
+    if (n >= N) return;
+    rays_t[n] = nears[n];
+    tc[n] = nears[n];
+    weights_sum[n] = 0.0f; depth[n] = 0.0f;
+    image[3 * (size_t)n] = 0.0f; image[3 * (size_t)n + 1] = 0.0f; image[3 * (size_t)n + 2] = 0.0f;
+    if (weights_edit) { weights_edit[n] = 0.0f; depth_edit[n] = 0.0f; }
+}
+
+// Wave-cooperative continuation of ONE ray (state broadcast from lane L): the candidate scheme of k_march_train_wave --
+// 64 consecutive visit candidates T_k per pass, probed in parallel, visited chain resolved from ballots -- recording up
+// to `remaining` sample times at out_t[0..) (+ edit flags).  Exactly the serial walk's samples (same candidate times,
+// same probe arithmetic); ~14 voxels of empty space per pass instead of one visit per ~200 instructions of one lane.
+// Returns the number of samples recorded (wave-uniform).
+template <bool EDIT>
+__device__ __forceinline__ uint32_t frame_lookahead_coop(const Ray& r, const MarchCfg& cfg, const uint8_t* __restrict__ grid,
+                                                         const uint8_t* __restrict__ edit_grid, float t_base, float far,
+                                                         uint32_t remaining, float* __restrict__ out_t, uint8_t* __restrict__ out_e,
+                                                         int lane) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t emitted = 0;
+    bool pending = false;
+    float pending_tt = 0.f;
+    while (t_base < far && emitted < remaining) {
+        const float t = candidate_t(cfg, t_base, lane);
+        const float t_next = t + step_of(cfg, t);
+        const bool valid = t < far;
+        Probe p;
+        p.occ = false; p.tt = t; p.x = p.y = p.z = 0.f; p.dt = 0.f; p.index = 0;
+        if (valid) p = probe_at(r, cfg, grid, t);
+        const unsigned long long valid_mask = __ballot(valid);
+        const unsigned long long occ_mask = __ballot(valid && p.occ);
+        unsigned long long emit = 0ull;
+        int k = 0;
+        if (pending) {
+            const unsigned long long m = __ballot(valid && t >= pending_tt);
+            if (m) { k = __builtin_ctzll(m); pending = false; } else k = 64;
+        }
+        while (k < 64 && ((valid_mask >> k) & 1ull)) {
+            if ((occ_mask >> k) & 1ull) {
+                const unsigned long long inv = (~occ_mask) >> k;
+                const int run = inv ? __builtin_ctzll(inv) : 64 - k;
+                emit |= ((run >= 64) ? ~0ull : ((1ull << run) - 1ull)) << k;
+                k += run;
+            } else {
+                const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.tt), k));
+                unsigned long long m = __ballot(valid && t >= tt);
+                m &= (k >= 63) ? 0ull : ~((2ull << k) - 1ull);                // at least one step (:396-398)
+                if (m) k = __builtin_ctzll(m);
+                else { pending = true; pending_tt = tt; k = 64; }
+            }
+        }
+        uint32_t cnt = (uint32_t)__builtin_popcountll(emit);
+        bool done = false;
+        if (emitted + cnt > remaining) {
+            const uint32_t keep = remaining - emitted;
+            const bool mine = ((emit >> lane) & 1ull) && (uint32_t)__builtin_popcountll(emit & below) < keep;
+            emit = __ballot(mine);
+            cnt = keep;
+            done = true;
+        }
+        if ((emit >> lane) & 1ull) {
+            const uint32_t slot = emitted + (uint32_t)__builtin_popcountll(emit & below);
+            out_t[slot] = t;
+            if (EDIT) out_e[slot] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
+        }
+        emitted += cnt;
+        if (done || valid_mask != ~0ull) break;
+        t_base = __shfl(t_next, 63, 64);
+    }
+    return emitted;
+}
+
+__device__ __forceinline__ float bcast(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// start of the walk in the first iteration: t = near + clamp(near * dt_gamma) * noise (raymarching.cu:746)
+__device__ __forceinline__ float perturbed_start(const MarchCfg& cfg, float t, const float* __restrict__ noises, uint32_t n) {
+    return noises ? fmaf(clampf(t * cfg.dt_gamma, cfg.dt_min, cfg.dt_max), noises[n], t) : t;
+}
+
+// Lookahead marcher.  phase -1: before the loop (walk from the perturbed near).  phase p >= 0: after k_frame_emit of
+// iteration p -- first advance tc[ray] (this loop's copy of rays_t) over the n_step samples that iteration consumes, with
+// the compositing kernel's arithmetic (t += deltas[1]), then walk on from there (march_rays restarts from rays_t,
+// raymarching.cu:736).  Records la_t[ray][0..cnt) = sample times, la_e = edit flags, la_cnt[ray] = cnt <= max_n_step.
+constexpr uint32_t FRAME_LANE_VISITS = 8;      // visits a lane walks alone before the wave decides how to continue
+constexpr int FRAME_COOP_MAX = 8;              // unfinished lanes per wave up to which they are finished cooperatively
+template <bool EDIT>
+__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
+    int phase, const FrameCtrl* __restrict__ ctrl, uint32_t N, uint32_t max_n_step, const int32_t* __restrict__ alive,
+    float* __restrict__ tc, float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
+    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises) {
+    const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
+    const uint32_t n = blockIdx.x * FRAME_BLOCK + threadIdx.x;
+    bool has_ray = n < n_alive;
+    const int lane = threadIdx.x & 63;
+    uint32_t index = 0;
+    Ray r{};
+    float t = 0.f, far = 0.f;
+    if (has_ray) {
+        index = phase < 0 ? n : (uint32_t)alive[n];
+        if (phase >= 0 && la_cnt[index] < n_consumed) has_ray = false;          // the ray ends in this iteration
+    }
+    if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
+    if (has_ray) {
+        r = load_ray(rays_o, rays_d, index);
+        far = fars[index];
+        t = tc[index];
+        if (phase < 0) t = perturbed_start(cfg, t, noises, n);
+        else {
+            float last = phase == 0 ? perturbed_start(cfg, t, noises, n) : t;   // iteration 0 lists rays in identity order
+            for (uint32_t j = 0; j < n_consumed; j++) {
+                const float tj = la_t[(size_t)index * FRAME_LA + j];
+                const float tn = tj + step_of(cfg, tj);
+                t += tn - last;                            // composite: t += deltas[1], deltas[1] = t_next - last_t
+                last = tn;
+            }
+            tc[index] = t;
+        }
+    }
+    float* out_t = la_t + (size_t)index * FRAME_LA;
+    uint8_t* out_e = EDIT ? la_e + (size_t)index * FRAME_LA : nullptr;
+    uint32_t step = 0;
+    for (;;) {
+        uint32_t visits = 0;                               // lane phase: the reference's walk
+        while (has_ray && t < far && step < max_n_step && visits < FRAME_LANE_VISITS) {
+            const Probe p = probe_at(r, cfg, grid, t);
+            if (p.occ) {
+                out_t[step] = t;
+                if (EDIT) out_e[step] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
+                t += p.dt;
+                step++;
+            } else t = skip_to(cfg, t, p.tt);
+            visits++;
+        }
+        const bool unfinished = has_ray && t < far && step < max_n_step;
+        unsigned long long um = __ballot(unfinished);
+        if (um == 0ull) break;
+        if (__builtin_popcountll(um) > FRAME_COOP_MAX) continue;   // most of the wave is in transit: lanes are well used
+        while (um) {                                       // few stragglers: finish each with the whole wave
+            const int L = __builtin_ctzll(um);
+            um &= um - 1ull;
+            Ray rl;
+            rl.ox = bcast(r.ox, L); rl.oy = bcast(r.oy, L); rl.oz = bcast(r.oz, L);
+            rl.dx = bcast(r.dx, L); rl.dy = bcast(r.dy, L); rl.dz = bcast(r.dz, L);
+            rl.rdx = bcast(r.rdx, L); rl.rdy = bcast(r.rdy, L); rl.rdz = bcast(r.rdz, L);
+            const uint32_t step_l = (uint32_t)__builtin_amdgcn_readlane((int)step, L);
+            const uint32_t index_l = (uint32_t)__builtin_amdgcn_readlane((int)index, L);
+            const uint32_t got = frame_lookahead_coop<EDIT>(rl, cfg, grid, edit_grid, bcast(t, L), bcast(far, L), max_n_step - step_l,
+                                                            la_t + (size_t)index_l * FRAME_LA + step_l,
+                                                            EDIT ? la_e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane);
+            if (lane == L) step += got;
+        }
+        break;
+    }
+    if (has_ray) la_cnt[index] = step;
+}
+
+// march_rays (raymarching.cu:700-805 / :811-926) as a replay of the recorded sample times; see the section comment
+template <bool EDIT>
+__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
+    const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, const uint32_t* __restrict__ seg_counts,
+    const int32_t* __restrict__ seg, uint32_t nb_prev, uint32_t R_prev, uint32_t N, uint32_t row_budget, uint32_t max_steps,
+    uint32_t max_n_step, int32_t* __restrict__ alive, const float* __restrict__ tc, const float* __restrict__ la_t,
+    const uint8_t* __restrict__ la_e, const uint32_t* __restrict__ la_cnt, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, MarchCfg cfg, float* __restrict__ xyzs, float* __restrict__ dirs,
+    float* __restrict__ deltas, uint8_t* __restrict__ edit_occ, const float* __restrict__ noises,
+    FrameMirror* __restrict__ mirror, uint64_t frame_id) {
+    __shared__ uint32_t red[2][FRAME_BLOCK / 64];
+    uint32_t n_alive, off_b, cnt_b, b, local;
+    if (nb_prev == 0) {                                    // first iteration: every ray, identity order
+        n_alive = N; b = 0; off_b = 0; cnt_b = N; local = blockIdx.x * FRAME_BLOCK + threadIdx.x;
+    } else {
+        const uint32_t cpb = R_prev / FRAME_BLOCK;         // chunks per segment
+        b = blockIdx.x / cpb; local = (blockIdx.x % cpb) * FRAME_BLOCK + threadIdx.x;
+        uint32_t below = 0, total = 0;
+        for (uint32_t j = threadIdx.x; j < nb_prev; j += FRAME_BLOCK) {
+            const uint32_t c = seg_counts[j];
+            total += c; below += j < b ? c : 0u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { total += __shfl_xor(total, d, 64); below += __shfl_xor(below, d, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = total; red[1][threadIdx.x >> 6] = below; }
+        __syncthreads();
+        total = 0; below = 0;
+#pragma unroll
+        for (int w = 0; w < FRAME_BLOCK / 64; w++) { total += red[0][w]; below += red[1][w]; }
+        n_alive = total; off_b = below; cnt_b = seg_counts[b];
+    }
+    // loop state (renderer.py:352,363,377)
+    const FrameCtrl pv = *prev;
+    FrameCtrl c;
+    c.step = pv.step + pv.n_step;
+    c.total_rows = pv.total_rows + pv.n_rows;
+    c.done = (pv.done || n_alive == 0 || c.step >= max_steps) ? 1u : 0u;
+    c.n_alive = c.done ? 0u : n_alive;
+    c.n_step = c.done ? 0u : max(min(row_budget / n_alive, max_n_step), 1u);
+    c.n_rows = c.n_alive * c.n_step;
+    c.iter = pv.iter + (c.done ? 0u : 1u);
+    c.pad = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *cur = c;
+        mirror->n_alive = c.n_alive; mirror->done = c.done; mirror->total_rows = c.total_rows; mirror->iters = c.iter;
+        __threadfence_system();
+        mirror->tag = frame_id;
+        for (uint32_t row = c.n_rows; row < ((c.n_rows + 15u) & ~15u); row++) {     // pad rows of the last 16-row MLP tile
+            xyzs[3 * (size_t)row] = 0.f; xyzs[3 * (size_t)row + 1] = 0.f; xyzs[3 * (size_t)row + 2] = 0.f;
+            dirs[3 * (size_t)row] = 0.f; dirs[3 * (size_t)row + 1] = 0.f; dirs[3 * (size_t)row + 2] = 0.f;
+        }
+    }
+    if (c.done || local >= cnt_b) return;
+    const uint32_t n = off_b + local, n_step = c.n_step;
+    const int32_t index = nb_prev ? seg[(size_t)b * R_prev + local] : (int32_t)n;
+    alive[n] = index;
+    const Ray r = load_ray(rays_o, rays_d, (uint32_t)index);
+    const uint32_t have = min(la_cnt[index], n_step);
+    float last_t = tc[index];
+    if (nb_prev == 0) last_t = perturbed_start(cfg, last_t, noises, n);
+    const float* st = la_t + (size_t)index * FRAME_LA;
+    size_t row = (size_t)n * n_step;
+    for (uint32_t j = 0; j < n_step; j++, row++) {
+        if (j < have) {                                    // :761-790 with the recorded time
+            const float t = st[j], dt = step_of(cfg, t), tn = t + dt;
+            xyzs[3 * row] = clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound);
+            xyzs[3 * row + 1] = clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound);
+            xyzs[3 * row + 2] = clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound);
+            dirs[3 * row] = r.dx; dirs[3 * row + 1] = r.dy; dirs[3 * row + 2] = r.dz;
+            deltas[2 * row] = dt; deltas[2 * row + 1] = tn - last_t; last_t = tn;
+            if (EDIT) edit_occ[row] = la_e[(size_t)index * FRAME_LA + j];
+        } else {                                           // the reference's buffers are torch.zeros
+            xyzs[3 * row] = 0.f; xyzs[3 * row + 1] = 0.f; xyzs[3 * row + 2] = 0.f;
+            dirs[3 * row] = 0.f; dirs[3 * row + 1] = 0.f; dirs[3 * row + 2] = 0.f;
+            deltas[2 * row] = 0.f; deltas[2 * row + 1] = 0.f;
+            if (EDIT) edit_occ[row] = 0;
+        }
+    }
+}
+
+// composite_rays (raymarching.cu:948-1035 / :1037-1142) + survivors of workgroup b's range [b*R, (b+1)*R) of the alive
+// list into segment b (stable), count into seg_counts[b]
+template <bool EDIT>
+__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_composite(
+    const FrameCtrl* __restrict__ cur, const int32_t* __restrict__ alive, int32_t* __restrict__ seg_next,
+    uint32_t* __restrict__ seg_counts_next, uint32_t R, float* __restrict__ rays_t, const float* __restrict__ sigmas,
+    const float* __restrict__ rgbs, const float* __restrict__ deltas, float* __restrict__ weights_sum,
+    float* __restrict__ weights_edit_sum, float* __restrict__ depth, float* __restrict__ depth_edit,
+    const uint8_t* __restrict__ edit_occ, float* __restrict__ image, float T_thresh) {
+    __shared__ uint32_t lds[FRAME_BLOCK / 64 + 1];
+    const uint32_t n_alive = cur->n_alive, n_step = cur->n_step;
+    const uint32_t lo = blockIdx.x * R, hi = min(lo + R, n_alive);
+    uint32_t running = 0;
+    for (uint32_t base = lo; base < hi; base += FRAME_BLOCK) {
+        const uint32_t n = base + threadIdx.x;
+        uint32_t keep = 0;
+        int32_t index = -1;
+        if (n < hi) {
+            index = alive[n];
+            const float* s = sigmas + (size_t)n * n_step;
+            const float* c = rgbs + 3 * (size_t)n * n_step;
+            const float* dl = deltas + 2 * (size_t)n * n_step;
+            const uint8_t* eo = EDIT ? edit_occ + (size_t)n * n_step : nullptr;
+            float t = rays_t[index];
+            float ws = weights_sum[index], d = depth[index];
+            float wse = 0, de = 0;
+            if (EDIT) { wse = weights_edit_sum[index]; de = depth_edit[index]; }
+            float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+            uint32_t step = 0;
+            while (step < n_step) {
+                const float d0 = dl[2 * step];
+                if (d0 == 0) break;
+                const float alpha = 1.0f - __expf(-s[step] * d0);
+                const float T = 1 - ws;
+                const float w = alpha * T;
+                ws += w;
+                if (EDIT) { if (eo[step]) { wse += w; de = fmaf(w, t, de); } }
+                t += dl[2 * step + 1];
+                d = fmaf(w, t, d);
+                r = fmaf(w, c[3 * step], r); g = fmaf(w, c[3 * step + 1], g); b = fmaf(w, c[3 * step + 2], b);
+                if (T < T_thresh) break;
+                step++;
+            }
+            if (step == n_step) { keep = 1; rays_t[index] = t; }
+            weights_sum[index] = ws; depth[index] = d;
+            if (EDIT) { weights_edit_sum[index] = wse; depth_edit[index] = de; }
+            image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+        }
+        uint32_t total;
+        const uint32_t ex = lae::block_excl_scan<FRAME_BLOCK / 64>(keep, &total, lds);
+        if (keep) seg_next[(size_t)lo + running + ex] = index;
+        running += total;
+    }
+    if (threadIdx.x == 0) seg_counts_next[blockIdx.x] = running;
+}
+
+// renderer.py:381-383: background blend and depth normalisation
+__global__ void k_frame_finish(uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
+                               const float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
+                               const float* __restrict__ bg_rays, float bg_r, float bg_g, float bg_b, int blend_bg, int scale_depth) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (blend_bg) {
+        const float om = 1 - weights_sum[n];
+        const float b0 = bg_rays ? bg_rays[3 * (size_t)n] : bg_r, b1 = bg_rays ? bg_rays[3 * (size_t)n + 1] : bg_g,
+                    b2 = bg_rays ? bg_rays[3 * (size_t)n + 2] : bg_b;
+        image[3 * (size_t)n] += om * b0; image[3 * (size_t)n + 1] += om * b1; image[3 * (size_t)n + 2] += om * b2;
+    }
+    if (scale_depth) depth[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+}
+
 }  // namespace
 
 // =====================================================================
@@ -914,6 +1263,221 @@ int lae_compact_rays_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t*
     k_compact_scan<<<1, 1024, 0, s>>>(totals, nblk, n_out_dev);
     k_compact_scatter<<<nblk, COMPACT_BLOCK, 0, s>>>(rays_alive, n_alive, local_prefix, totals, out_alive);
     return lae::check_launch("compact_rays_alive");
+}
+
+
+// ---- whole-frame inference (MI355X-native; replaces the host loop of NeRFRenderer.run_cuda, renderer.py:335-387,
+// and of run_cuda_distill, :394-480, when edit_grid != NULL)
+static inline uint64_t frame_budget(uint32_t N, uint64_t row_budget) { return row_budget < N ? N : std::min<uint64_t>(row_budget, 0xfffffff0ull); }
+static inline uint64_t frame_cap(uint64_t budget) { return (budget + 15) / 16 * 16 + 16; }
+static inline uint64_t al256(uint64_t b) { return (b + 255) / 256 * 256; }
+static inline uint64_t frame_seg_elems(uint32_t N) { return (uint64_t)N + (uint64_t)FRAME_SEG_MAX * FRAME_BLOCK; }
+uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_budget) {
+    const uint64_t cap = frame_cap(frame_budget(N, row_budget));
+    return 256 /*ctrl x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*segment counts x2*/ + al256(4ull * N) /*alive*/ +
+           2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + 4 * al256(4ull * N) /*rays_t, tc, nears, fars*/ +
+           al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + al256(4ull * N) /*lookahead times, edit flags, counts*/ +
+           2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
+           al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ + al256(4 * cap) /*sigmas*/ + al256(12 * cap) /*rgbs*/;
+}
+
+namespace {
+struct FrameHost {                                        // process-wide helpers of the frame loop, created on first use
+    FrameMirror* mirror_h = nullptr;
+    FrameMirror* mirror_d = nullptr;
+    hipStream_t side = nullptr;                           // lookahead marcher runs here, beside the encoder / MLP kernels
+    static constexpr int NEV = 16;
+    hipEvent_t ev_emit[NEV] = {}, ev_look[NEV] = {};
+    uint64_t frame_counter = 0;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 256, hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return false; }
+        memset(hp, 0, 256);
+        mirror_h = reinterpret_cast<FrameMirror*>(hp); mirror_d = reinterpret_cast<FrameMirror*>(dp);
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess) return false;
+        for (int i = 0; i < NEV; i++) {
+            if (hipEventCreateWithFlags(&ev_emit[i], hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev_look[i], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        ok = true;
+        return true;
+    }
+};
+FrameHost g_frame;
+std::mutex g_frame_mtx;
+int g_frame_overlap = 1;                                  // 0: lookahead in-line on the caller's stream (A/B switch)
+}  // namespace
+
+int lae_render_frame_set_overlap(int on) { g_frame_overlap = on ? 1 : 0; return LAE_OK; }
+
+int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
+                     const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, uint32_t L, float S,
+                     uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp,
+                     const void* sigma_weights, const void* color_weights, float density_scale, float T_thresh,
+                     uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
+                     float bg_b, int blend_bg, int scale_depth, float* weights_sum, float* depth, float* image,
+                     float* weights_edit, float* depth_edit, void* workspace, uint64_t workspace_bytes, uint32_t* stats_out,
+                     void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays_o || !rays_d || !aabb || !grid || !table_f16 || !offsets || !sigma_weights || !color_weights || !weights_sum ||
+        !depth || !image || !workspace)
+        return LAE_ENULL;
+    if (edit_grid && (!weights_edit || !depth_edit)) return LAE_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0 || max_n_step == 0 || max_n_step > FRAME_LA || L != 16) return LAE_EINVAL;
+    if (workspace_bytes < lae_render_frame_workspace_bytes(N, L, row_budget)) return LAE_EINVAL;
+    hipStream_t s = STREAM(stream);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        lae::set_last_error_str("render_frame: the frame loop adapts its launches to the device state and cannot be stream-captured");
+        return LAE_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_frame_mtx);
+    if (!g_frame.init()) { lae::set_last_error_str("render_frame: could not create the pinned mirror / side stream / events"); return LAE_ELAUNCH; }
+    FrameMirror* mirror_h = g_frame.mirror_h;
+    FrameMirror* mirror_d = g_frame.mirror_d;
+    const uint64_t frame_id = ++g_frame.frame_counter;
+    const bool overlap = g_frame_overlap != 0;
+    hipStream_t ls = overlap ? g_frame.side : s;           // stream of the lookahead marcher
+
+    // carve the workspace
+    const uint32_t budget = (uint32_t)frame_budget(N, row_budget);
+    const uint64_t cap = frame_cap(budget);
+    uint8_t* w = reinterpret_cast<uint8_t*>(workspace);
+    auto take = [&](uint64_t bytes) { uint8_t* p = w; w += al256(bytes); return p; };
+    FrameCtrl* ctrl = reinterpret_cast<FrameCtrl*>(take(256));
+    uint32_t* seg_counts[2] = {reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX)), reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX))};
+    int32_t* alive = reinterpret_cast<int32_t*>(take(4ull * N));
+    int32_t* seg[2] = {reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N))), reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N)))};
+    float* rays_t = reinterpret_cast<float*>(take(4ull * N));
+    float* tc = reinterpret_cast<float*>(take(4ull * N));
+    float* nears = reinterpret_cast<float*>(take(4ull * N));
+    float* fars = reinterpret_cast<float*>(take(4ull * N));
+    float* la_t = reinterpret_cast<float*>(take(4ull * FRAME_LA * N));
+    uint8_t* la_e = take((uint64_t)FRAME_LA * N);
+    uint32_t* la_cnt = reinterpret_cast<uint32_t*>(take(4ull * N));
+    float* xyzs = reinterpret_cast<float*>(take(12 * cap));
+    float* dirs = reinterpret_cast<float*>(take(12 * cap));
+    float* deltas = reinterpret_cast<float*>(take(8 * cap));
+    uint8_t* edit_occ = take(cap);
+    void* feats = take((uint64_t)L * cap * 4);
+    float* sigmas = reinterpret_cast<float*>(take(4 * cap));
+    float* rgbs = reinterpret_cast<float*>(take(12 * cap));
+
+    const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
+    const float in_shift = bound, in_scale = 1.0f / (2.0f * bound);        // grid.py:149 (torch multiplies by the fp32 reciprocal)
+    auto lookahead = [&](int phase, const FrameCtrl* c, uint32_t n_bound, hipStream_t q) {
+        const uint32_t blocks = lae::cdiv(n_bound, FRAME_BLOCK);
+        if (edit_grid)
+            k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, rays_o, rays_d, fars,
+                                                                 cfg, grid, edit_grid, noises);
+        else
+            k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, rays_o, rays_d,
+                                                                  fars, cfg, grid, nullptr, noises);
+    };
+    k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
+    k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, rays_t, tc, weights_sum, depth, image,
+                                                    edit_grid ? weights_edit : nullptr, edit_grid ? depth_edit : nullptr);
+    lookahead(-1, nullptr, N, s);
+    uint32_t bound_alive = N, seen_iter = 0;
+    bool done = false;
+    int rc = LAE_OK;
+    const uint32_t LAG = 4;
+    uint32_t it = 0, nb_prev = 0, R_prev = 0;
+    bool look_pending = false;                            // a lookahead on the side stream the caller's stream has not waited for
+    auto join_side = [&]() {                               // every exit path: the caller's stream owns the workspace again
+        if (look_pending) (void)hipStreamWaitEvent(s, g_frame.ev_look[(it + FrameHost::NEV - 1) % FrameHost::NEV], 0);
+        look_pending = false;
+    };
+    auto poll = [&]() {
+        if (mirror_h->tag != frame_id) return;
+        const uint32_t iters = mirror_h->iters, na = mirror_h->n_alive, dn = mirror_h->done;
+        if (iters > seen_iter) seen_iter = iters;
+        if (na < bound_alive) bound_alive = na;
+        if (dn) done = true;
+    };
+    for (; it <= max_steps && !done; it++) {
+        poll();
+        if (done) break;
+        if (it >= seen_iter + LAG) {                       // do not run further ahead than LAG iterations
+            const auto t0 = std::chrono::steady_clock::now();
+            while (it >= seen_iter + LAG && !done) {
+                poll();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    lae::set_last_error_str("render_frame: device made no progress for 20 s");
+                    join_side();
+                    return LAE_ELAUNCH;
+                }
+            }
+            if (done) break;
+        }
+        const FrameCtrl* prev = ctrl + (it & 1u);
+        FrameCtrl* cur = ctrl + ((it + 1u) & 1u);
+        const uint32_t emit_blocks = nb_prev ? nb_prev * (R_prev / FRAME_BLOCK) : lae::cdiv(N, FRAME_BLOCK);
+        const uint32_t rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)budget, (uint64_t)max_n_step * bound_alive);
+        const uint32_t rows_launch = (rows_bound + 15u) & ~15u;
+        const uint32_t p = it & 1u;                        // segments written by this iteration's compositing: [p]; read: [p ^ 1]
+        const int e = (int)(it % FrameHost::NEV);
+        join_side();                                       // samples of this iteration come from the previous lookahead
+        if (edit_grid)
+            k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, seg_counts[p ^ 1u], seg[p ^ 1u], nb_prev, R_prev, N, budget,
+                                                                max_steps, max_n_step, alive, tc, la_t, la_e, la_cnt, rays_o, rays_d, cfg,
+                                                                xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id);
+        else
+            k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, seg_counts[p ^ 1u], seg[p ^ 1u], nb_prev, R_prev, N, budget,
+                                                                 max_steps, max_n_step, alive, tc, la_t, nullptr, la_cnt, rays_o, rays_d, cfg,
+                                                                 xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id);
+        // lookahead for the NEXT iteration: beside the network kernels below
+        if (overlap) {
+            if (hipEventRecord(g_frame.ev_emit[e], s) != hipSuccess || hipStreamWaitEvent(ls, g_frame.ev_emit[e], 0) != hipSuccess) {
+                lae::set_last_error_str("render_frame: event record / wait failed");
+                return LAE_ELAUNCH;
+            }
+        }
+        lookahead((int)it, cur, bound_alive, ls);
+        if (overlap) {
+            if (hipEventRecord(g_frame.ev_look[e], ls) != hipSuccess) { lae::set_last_error_str("render_frame: event record failed"); return LAE_ELAUNCH; }
+            look_pending = true;
+        }
+        rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
+                                     gridtype, align_corners, interp, in_shift, in_scale, s);
+        if (rc == LAE_OK)
+            rc = lae::nerf_head_forward_frame(feats, dirs, sigma_weights, color_weights, (uint32_t)cap, rows_launch, &cur->n_rows,
+                                              density_scale, sigmas, rgbs, s);
+        if (rc) { it++; join_side(); return rc; }
+        // compositing: nb workgroups, each owning R consecutive entries of the alive list (nb * R >= bound_alive >= n_alive)
+        const uint32_t nb = std::max(1u, std::min(lae::cdiv(bound_alive, FRAME_BLOCK), FRAME_SEG_MAX));
+        const uint32_t R = std::max(lae::cdiv(lae::cdiv(bound_alive, nb), FRAME_BLOCK), 1u) * FRAME_BLOCK;
+        if (edit_grid)
+            k_frame_composite<true><<<nb, FRAME_BLOCK, 0, s>>>(cur, alive, seg[p], seg_counts[p], R, rays_t, sigmas, rgbs, deltas, weights_sum,
+                                                             weights_edit, depth, depth_edit, edit_occ, image, T_thresh);
+        else
+            k_frame_composite<false><<<nb, FRAME_BLOCK, 0, s>>>(cur, alive, seg[p], seg_counts[p], R, rays_t, sigmas, rgbs, deltas, weights_sum,
+                                                              nullptr, depth, nullptr, nullptr, image, T_thresh);
+        nb_prev = nb; R_prev = R;
+        rc = lae::check_launch("render_frame");
+        if (rc) { it++; join_side(); return rc; }
+    }
+    join_side();
+    k_frame_finish<<<lae::cdiv(N, 256), 256, 0, s>>>(N, nears, fars, weights_sum, depth, image, bg_rays, bg_r, bg_g, bg_b, blend_bg,
+                                                     scale_depth);
+    rc = lae::check_launch("render_frame(finish)");
+    if (rc) return rc;
+    if (stats_out) {
+        // the loop ends either on `done` (mirror holds the final state) or after max_steps + 1 launched iterations
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!done) {
+            poll();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+        }
+        stats_out[0] = mirror_h->iters; stats_out[1] = mirror_h->total_rows; stats_out[2] = it;
+    }
+    return LAE_OK;
 }
 
 }  // extern "C"

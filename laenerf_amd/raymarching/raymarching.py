@@ -14,7 +14,7 @@ from ..backend import raymarching_backend as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
-           "compact_rays_alive", "composite_rays_train_blend", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
+           "compact_rays_alive", "render_frame", "composite_rays_train_blend", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
 
 
 def _gpu(t):
@@ -323,6 +323,50 @@ def compact_rays_alive(rays_alive, n_alive=None):
     n_out = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
     _backend.compact_rays_alive(rays_alive, n_alive, out, n_out)
     return out, n_out
+
+
+@torch.no_grad()
+def render_frame(rays_o, rays_d, aabb, min_near, density_bitfield, bound, C, H, table_half, offsets, per_level_scale,
+                 base_resolution, sigma_weights_half, color_weights_half, edit_bitfield=None, gridtype_id=0, align_corners=False,
+                 interp_id=0, density_scale=1.0, dt_gamma=0, max_steps=1024, T_thresh=1e-4, max_n_step=8, row_budget=0,
+                 noises=None, bg_color=None, scale_depth=True, want_stats=False):
+    """MI355X-native: the inference loop of NeRFRenderer.run_cuda (nerf/renderer.py:335-387; run_cuda_distill :394-480
+    when `edit_bitfield` is given) as ONE backend call -- loop state on the device, no host sync per iteration.
+    Same per-ray arithmetic and iteration schedule as march_rays / network / composite_rays called in the Python loop.
+
+    row_budget: rows (samples) one iteration may put through the network; 0 = N, the reference's rule
+    `n_step = max(min(N // n_alive, 8), 1)`.  A larger budget means fewer, larger iterations (same per-ray samples).
+    bg_color: None (no blend, as run_cuda_distill), a scalar / 3 numbers, or a [N,3] tensor.
+    Returns dict(image [N,3], depth [N], weights_sum [N]) (+ weights_edit, depth_edit; + stats when want_stats)."""
+    import numpy as np
+    rays_o, rays_d = _rays(rays_o), _rays(rays_d)
+    N, dev = rays_o.shape[0], rays_o.device
+    weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    weights_edit = depth_edit = None
+    if edit_bitfield is not None:
+        weights_edit = torch.empty(N, dtype=torch.float32, device=dev)
+        depth_edit = torch.empty(N, dtype=torch.float32, device=dev)
+    bg_rays, bg_rgb = None, (0.0, 0.0, 0.0)
+    if torch.is_tensor(bg_color) and bg_color.numel() == 3 * N and N > 1:
+        bg_rays = _gpu(bg_color).float().reshape(N, 3).contiguous()
+    elif bg_color is not None:
+        v = [float(x) for x in (bg_color.flatten().tolist() if torch.is_tensor(bg_color) else np.atleast_1d(bg_color))]
+        bg_rgb = tuple(v * 3) if len(v) == 1 else tuple(v)
+    stats = _backend.render_frame(rays_o, rays_d, N, _gpu(aabb).float().contiguous(), min_near, density_bitfield, edit_bitfield,
+                                  bound, dt_gamma, max_steps, C, H, table_half, offsets, offsets.shape[0] - 1,
+                                  np.log2(per_level_scale), base_resolution, gridtype_id, align_corners, interp_id,
+                                  sigma_weights_half, color_weights_half, density_scale, T_thresh, max_n_step, row_budget,
+                                  None if noises is None else _gpu(noises).float().contiguous(), bg_rays, bg_rgb,
+                                  bg_color is not None, scale_depth, weights_sum, depth, image, weights_edit, depth_edit,
+                                  want_stats)
+    out = {"image": image, "depth": depth, "weights_sum": weights_sum}
+    if edit_bitfield is not None:
+        out["weights_edit"], out["depth_edit"] = weights_edit, depth_edit
+    if want_stats:
+        out["stats"] = stats
+    return out
 
 
 # ---------------------------------------------------------------- occupancy-grid maintenance (MI355X-native kernels)

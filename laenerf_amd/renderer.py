@@ -224,13 +224,41 @@ class NeRFRenderer(nn.Module):
         return {"image": image, "depth": depth, "weights_sum": weights_sum, "nears": nears, "n_samples": xyzs.shape[0]}
 
     # ------------------------------------------------------------------ inference render (renderer.py:335-387)
+    def _frame_loop_ok(self, rays_o):
+        """the device-resident frame loop needs the default architecture (fused field) and fp16 evaluation"""
+        m = self.model
+        return (getattr(m, "fused_field", False) and rays_o.is_cuda and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.half)
+
+    def _render_frame(self, rays_o, rays_d, grid, edit_bitfield, bg_color, perturb, dt_gamma, max_steps, T_thresh, scale_depth,
+                      want_stats=False, row_budget=0):
+        m = self.model
+        enc, sn, cn = m.encoder, m.sigma_net, m.color_net
+        table = enc.shadow.table_half(enc.embeddings) if enc.shadow is not None else enc.embeddings.detach().to(torch.half)
+        ws = sn.shadow.table_half(sn.weights) if sn.shadow is not None else sn.weights.detach().half().contiguous()
+        wc = cn.shadow.table_half(cn.weights) if cn.shadow is not None else cn.weights.detach().half().contiguous()
+        noises = torch.rand(rays_o.shape[0], dtype=torch.float32, device=rays_o.device) if perturb else None
+        return raymarching.render_frame(rays_o, rays_d, self.aabb_infer, self.min_near, grid, self.bound, self.cascade,
+                                        self.grid_size, table, enc.offsets, enc.per_level_scale, enc.base_resolution, ws, wc,
+                                        edit_bitfield=edit_bitfield, gridtype_id=enc.gridtype_id, align_corners=enc.align_corners,
+                                        interp_id=enc.interp_id, density_scale=self.density_scale, dt_gamma=dt_gamma,
+                                        max_steps=max_steps, T_thresh=T_thresh, row_budget=row_budget, noises=noises,
+                                        bg_color=bg_color, scale_depth=scale_depth, want_stats=want_stats)
+
     @torch.no_grad()
     def render_eval(self, rays_o, rays_d, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4,
-                    scale_depth=True, dens_grid=None, device_compaction=True):
+                    scale_depth=True, dens_grid=None, device_compaction=True, frame_loop=True, want_stats=False, row_budget=0):
+        """frame_loop=True (default, when the model is the default architecture under fp16 autocast): the whole loop runs
+        as ONE backend call with its state on the device (lae_render_frame).  frame_loop=False: the reference's loop,
+        operator by operator, with one host read of n_alive per iteration.  row_budget (frame loop only): rows per
+        iteration, 0 = N as in the reference (`n_step = max(min(N // n_alive, 8), 1)`, renderer.py:363)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         grid = self.density_bitfield if dens_grid is None else dens_grid
         N, device = rays_o.shape[0], rays_o.device
+        if frame_loop and self._frame_loop_ok(rays_o):
+            return self._render_frame(rays_o, rays_d, grid, None, bg_color, perturb, dt_gamma, max_steps, T_thresh, scale_depth,
+                                      want_stats, row_budget)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
         depth = torch.zeros(N, dtype=torch.float32, device=device)
@@ -263,12 +291,17 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ distillation render (renderer.py:394-480)
     @torch.no_grad()
     def render_distill(self, rays_o, rays_d, edit_bitfield, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4,
-                       grow_grid=False):
+                       grow_grid=False, frame_loop=True):
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, device = rays_o.shape[0], rays_o.device
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         dens = edit_bitfield if grow_grid else self.density_bitfield
+        if frame_loop and self._frame_loop_ok(rays_o):
+            res = self._render_frame(rays_o, rays_d, dens, edit_bitfield, None, perturb, dt_gamma, max_steps, T_thresh, False)
+            return {"image": res["image"], "depth": res["depth"], "depth_edit": res["depth_edit"],
+                    "x_term": rays_o + res["depth"][..., None] * rays_d, "weights_edit": res["weights_edit"],
+                    "weights": res["weights_sum"]}
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
         weights_edit_sum = torch.zeros(N, dtype=torch.float32, device=device)
         depth = torch.zeros(N, dtype=torch.float32, device=device)

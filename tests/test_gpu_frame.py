@@ -1,0 +1,195 @@
+"""-m gpu: the device-resident inference loop (lae_render_frame) against the operator-by-operator loop of
+NeRFRenderer.run_cuda / run_cuda_distill (nerf/renderer.py:335-387, 394-480) on the same kernels, against the oracle's
+loop, and against the vectors captured from the reference's unmodified renderer (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from gpu_util import DEV, N, T
+
+pytestmark = pytest.mark.gpu
+
+
+def make(bound=1, log2_T=14, seed=0, table_amp=0.5):
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(seed)
+    net = NeRFNetwork(bound=bound, log2_hashmap_size=log2_T).to(DEV)
+    net.encoder.embeddings.data.uniform_(-table_amp, table_amp)        # densities spread over orders of magnitude:
+    r = NeRFRenderer(net, bound=bound, min_near=0.2).to(DEV)           # rays terminate after very different step counts
+    C = r.cascade
+    r.density_bitfield = T(S.pack_bits_np(S.sphere_density_grid(cascade=C, bound=float(bound)), 10.0))
+    net.eval(); r.eval()
+    return net, r
+
+
+def rays(n, seed, bound=1):
+    from laenerf_amd import synthetic as S
+    o, d = S.lego_like_rays(n, seed=seed, radius=3.2 if bound == 1 else 2.6)
+    return T(o), T(d)
+
+
+@pytest.mark.parametrize("bound,n", [(1, 5000), (2, 3001), (1, 1), (1, 17)])
+def test_frame_loop_equals_operator_loop(bound, n):
+    net, r = make(bound=bound)
+    o, d = rays(n, seed=3, bound=bound)
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=False)
+        b = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=True, want_stats=True)
+    # same kernels' arithmetic, same schedule: only the order of the alive list differs -> per-ray results identical
+    hit = N(a["weights_sum"]) > 0
+    assert hit.sum() > 0 or n < 20
+    for k in ("image", "weights_sum"):
+        assert np.array_equal(N(a[k]), N(b[k])), k
+    assert np.array_equal(N(a["depth"])[hit], N(b["depth"])[hit])           # missed rays: 0/0 = NaN in both
+    assert np.array_equal(np.isnan(N(a["depth"])), np.isnan(N(b["depth"])))
+    st = b["stats"]
+    assert 1 <= st["iterations"] <= 1024 and st["iterations_launched"] >= st["iterations"]
+    assert st["rows"] >= n                                                   # the first iteration runs every ray once
+
+
+def test_frame_loop_perturb_and_thresholds():
+    net, r = make(bound=1, seed=1)
+    o, d = rays(4096, seed=5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        for T_thresh, max_steps in ((1e-2, 1024), (1e-4, 64)):
+            torch.manual_seed(11)
+            a = r.render_eval(o, d, bg_color=torch.tensor([0.2, 0.4, 0.6], device=DEV), perturb=True, max_steps=max_steps,
+                              T_thresh=T_thresh, frame_loop=False)
+            torch.manual_seed(11)
+            b = r.render_eval(o, d, bg_color=torch.tensor([0.2, 0.4, 0.6], device=DEV), perturb=True, max_steps=max_steps,
+                              T_thresh=T_thresh, frame_loop=True)
+            assert np.array_equal(N(a["image"]), N(b["image"]))
+            assert np.array_equal(N(a["weights_sum"]), N(b["weights_sum"]))
+        # per-ray background
+        bg = torch.rand(4096, 3, device=DEV)
+        a = r.render_eval(o, d, bg_color=bg, frame_loop=False)
+        b = r.render_eval(o, d, bg_color=bg, frame_loop=True)
+        assert np.array_equal(N(a["image"]), N(b["image"]))
+        # lookahead marcher in-line instead of on the side stream: same results
+        from laenerf_amd.backend import raymarching_backend as rb
+        rb.render_frame_set_overlap(False)
+        try:
+            f = r.render_eval(o, d, bg_color=bg, frame_loop=True)
+        finally:
+            rb.render_frame_set_overlap(True)
+        assert np.array_equal(N(f["image"]), N(b["image"]))
+        # two frames back to back on the same stream (the second starts while the first's tail is still queued)
+        c = r.render_eval(o, d, bg_color=bg, frame_loop=True)
+        e = r.render_eval(o, d, bg_color=bg, frame_loop=True)
+        assert np.array_equal(N(c["image"]), N(b["image"])) and np.array_equal(N(e["image"]), N(b["image"]))
+
+
+def test_frame_loop_row_budget():
+    """more rows per iteration than the reference's N: fewer iterations, the same per-ray sample sequences (only the
+    rounding of rays_t between iterations may differ)"""
+    net, r = make(bound=1, seed=3)
+    o, d = rays(6000, seed=2)
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = r.render_eval(o, d, bg_color=1, frame_loop=True, want_stats=True)
+        b = r.render_eval(o, d, bg_color=1, frame_loop=True, want_stats=True, row_budget=4 * 6000)
+        c = r.render_eval(o, d, bg_color=1, frame_loop=True, want_stats=True, row_budget=3)      # below N: clamped to N
+    assert b["stats"]["iterations"] < a["stats"]["iterations"]
+    assert c["stats"] == a["stats"] and np.array_equal(N(c["image"]), N(a["image"]))
+    assert np.abs(N(a["image"]) - N(b["image"])).max() < 1e-5
+    assert np.abs(N(a["weights_sum"]) - N(b["weights_sum"])).max() < 1e-5
+    hit = N(a["weights_sum"]) > 0
+    assert np.abs(N(a["depth"])[hit] - N(b["depth"])[hit]).max() < 1e-5
+
+
+def test_frame_loop_distill():
+    from laenerf_amd import synthetic as S
+    net, r = make(bound=1, seed=2)
+    o, d = rays(4000, seed=7)
+    g = S.sphere_density_grid(radius=0.35, boxes=False)
+    edit = T(S.pack_bits_np(g, 10.0)) & r.density_bitfield                  # edit region: a subset of the occupied cells
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = r.render_distill(o, d, edit, frame_loop=False)
+        b = r.render_distill(o, d, edit, frame_loop=True)
+        a2 = r.render_distill(o, d, edit, grow_grid=True, frame_loop=False)
+        b2 = r.render_distill(o, d, edit, grow_grid=True, frame_loop=True)
+    assert N(a["weights_edit"]).max() > 0
+    for x, y in ((a, b), (a2, b2)):
+        for k in ("image", "depth", "depth_edit", "weights_edit", "weights", "x_term"):
+            assert np.array_equal(N(x[k]), N(y[k])), k
+
+
+def test_frame_loop_vs_oracle_loop(O):
+    """256 rays: the oracle's march / encode / MLP / composite driven by the reference's loop schedule"""
+    net, r = make(bound=1, log2_T=12, seed=4)
+    net.encoder.embeddings.data = net.encoder.embeddings.data.half().float()
+    n = 256
+    o, d = rays(n, seed=9)
+    with torch.autocast("cuda", dtype=torch.float16):
+        got = r.render_eval(o, d, bg_color=1, max_steps=1024, T_thresh=1e-4, frame_loop=True, want_stats=True)
+    on, dn, bits = N(o), N(d), N(r.density_bitfield)
+    nears, fars = O.near_far_from_aabb(on, dn, [-1, -1, -1, 1, 1, 1], 0.2)
+    th = O.to_f16_bits(N(net.encoder.embeddings))
+    ws_h, wc_h = O.to_f16_bits(N(net.sigma_net.weights)), O.to_f16_bits(N(net.color_net.weights))
+    offs = N(net.encoder.offsets)
+    wsum, depth, image = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    alive, rays_t = np.arange(n, dtype=np.int32), nears.copy()
+    step, rows, iters = 0, 0, 0
+    while step < 1024 and alive.size > 0:
+        n_alive = alive.size
+        n_step = max(min(n // n_alive, 8), 1)
+        xyzs, dirs, deltas = O.march_rays(n_alive, n_step, alive, rays_t, on, dn, 1.0, bits, 1, 128, nears, fars,
+                                          np.zeros(n_alive, np.float32))[:3]
+        m = n_alive * n_step
+        pad = (-m) % 128
+        enc, _ = O.grid_encode_forward((xyzs[:m] + 1) / 2, th, offs, net.encoder.per_level_scale, 16, f16=True, out_blc=True)
+        h, _ = O.ffmlp_forward(np.concatenate([enc, np.zeros((pad, 32), np.uint16)]), ws_h, 32, 16, 64, 2)
+        hf = O.from_f16_bits(h)[:m]
+        sigma = np.exp(hf[:, 0]).astype(np.float32)
+        sh, _ = O.sh_encode_forward(dirs[:m], 4)
+        cin = O.to_f16_bits(np.concatenate([sh, hf[:, 1:], np.zeros((m, 1), np.float32)], 1))
+        oc, _ = O.ffmlp_forward(np.concatenate([cin, np.zeros((pad, 32), np.uint16)]), wc_h, 32, 16, 64, 3)
+        rgb = (1 / (1 + np.exp(-O.from_f16_bits(oc)[:m, :3]))).astype(np.float32)
+        O.composite_rays(n_alive, n_step, alive, rays_t, sigma, rgb, deltas[:m], wsum, depth, image, 1e-4)
+        alive = alive[alive >= 0]
+        step += n_step; rows += m; iters += 1
+    image = image + (1 - wsum)[:, None]
+    assert got["stats"]["iterations"] == iters and got["stats"]["rows"] == rows      # schedule and row counts: exact
+    assert np.abs(N(got["weights_sum"]) - wsum).max() < 3e-3                          # fp16 MLP / fast exp tolerance
+    assert np.abs(N(got["image"]) - image).max() < 3e-3
+    hit = wsum > 0
+    dref = np.clip(depth - nears, 0, None)[hit] / (fars - nears)[hit]
+    assert np.abs(N(got["depth"])[hit] - dref).max() < 3e-3
+
+
+@pytest.mark.parametrize("tag", ["b1", "b2"])
+def test_frame_loop_vs_reference_capture(tag):
+    """vectors from the reference's unmodified nerf/renderer.py run_cuda / run_cuda_distill (fp32 table there, fp16 here)"""
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    g = golden("e2e_" + tag)
+    bound = int(g["bound"])
+    net = NeRFNetwork(bound=bound, num_levels=16, log2_hashmap_size=10).to(DEV)
+    net.encoder.embeddings.data = T(g["table"])
+    net.sigma_net.weights.data = T(g["sigma_w"])
+    net.color_net.weights.data = T(g["color_w"])
+    r = NeRFRenderer(net, bound=bound, min_near=0.2).to(DEV)
+    r.density_bitfield = T(g["bitfield"])
+    net.eval()
+    o, d = T(g["rays_o"]), T(g["rays_d"])
+    with torch.autocast("cuda", dtype=torch.float16):
+        ev = r.render_eval(o, d, bg_color=1, max_steps=256, frame_loop=True)
+        ds = r.render_distill(o, d, T(g["edit_bitfield"]), max_steps=256, frame_loop=True)
+    assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 2e-3
+    for k, ref in (("image", "dist_image"), ("weights", "dist_weights"), ("weights_edit", "dist_weights_edit")):
+        assert np.abs(N(ds[k]) - g[ref]).max() < 2e-3, k
+
+
+def test_frame_loop_refuses_capture_and_cpu():
+    net, r = make(bound=1)
+    o, d = rays(256, seed=1)
+    with torch.autocast("cuda", dtype=torch.float16):
+        r.render_eval(o, d, frame_loop=True)                                   # warm: workspace allocation
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError):
+            with torch.cuda.graph(gph):
+                r.render_eval(o, d, frame_loop=True)
+    torch.cuda.synchronize()
