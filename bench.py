@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--rays", type=int, default=4096)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-frame", action="store_true", help="skip the 800x800 inference-frame timing (extra field eval_frame)")
+    p.add_argument("--no-style", action="store_true", help="skip the LAENeRF palette-network step timing (extra field style_step)")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
@@ -114,25 +115,81 @@ def cpu_baseline(n_rays_hint, n_threads):
 
 
 def eval_frame(net, r, dev, H=800, W=800):
-    """whole-frame inference render (march_rays / composite_rays loop of run_cuda, renderer.py:335-387) of one 800x800
-    view with the network as trained by the timed steps; median of 5 frames after one warm-up"""
+    """whole-frame inference render (the march_rays / composite_rays loop of run_cuda, renderer.py:335-387) of one 800x800
+    view with the network as trained by the timed steps; median of 5 frames after one warm-up.  `ms_per_frame`: the loop as
+    ONE backend call with its state on the device (lae_render_frame, reference schedule); `operator_loop_ms`: the same
+    kernels driven operator by operator from Python like the reference's loop (one host read of n_alive per iteration)."""
     from laenerf_amd import synthetic as S
     o, d = S.frame_rays(H, W)
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     was_training = net.training
     net.eval(); r.eval()
-    times = []
-    for it in range(6):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            res = r.render_eval(o, d, bg_color=1, max_steps=1024)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+
+    def timed(**kw):
+        times, res = [], None
+        for it in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+                res = r.render_eval(o, d, bg_color=1, max_steps=1024, **kw)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return sorted(times[1:])[2], res
+    t, res = timed(frame_loop=True, want_stats=True)
+    t_op, res_op = timed(frame_loop=False)
     net.train(was_training); r.train(was_training)
-    t = sorted(times[1:])[2]
     return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
             "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
-            "note": "800x800 inference render, T_thresh 1e-4, device-side alive-ray compaction"}
+            "iterations": res["stats"]["iterations"], "samples_through_network": res["stats"]["rows"],
+            "operator_loop_ms": round(t_op * 1e3, 2),
+            "max_abs_image_diff_vs_operator_loop": float((res["image"] - res_op["image"]).abs().max()),
+            "note": "800x800 inference render, T_thresh 1e-4, device-resident loop (lookahead marcher on a side stream)"}
+
+
+def style_step(dev, P=100000, steps=30):
+    """configs[4]: one optimisation step of LAENeRF's palette network (train_LAENeRF_step, nerf/utils.py:980-1043, point-wise
+    losses) on P region-masked points: hash-grid encode -> weight / offset MLPs -> palette recomposition -> MSE + weight +
+    offset + palette losses -> backward -> Adam(lr 1e-3) under a GradScaler.  Synthetic x_term in a 0.3-radius ball
+    (SURVEY.md 8d).  Captured once into a HIP graph and replayed, like the train step."""
+    from types import SimpleNamespace
+    from laenerf_amd.editing import LAENeRF
+    from laenerf_amd.optim import FusedAdam
+    params = SimpleNamespace(bound=1, num_palette_bases=8, style_weight=0, weight_loss_uniform=1e-3, weight_loss_non_uniform=1e-3,
+                             offset_loss=1e-2, palette_loss_valid=1.0, palette_loss_distinct=1e-2)
+    torch.manual_seed(7)
+    m = LAENeRF(params, dir_encoding="sphere_harmonics").to(dev)
+    m.train()
+    opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
+    v = torch.randn(P, 3, device=dev)
+    x = v / v.norm(dim=-1, keepdim=True) * 0.3 * torch.rand(P, 1, device=dev) ** (1 / 3)
+    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1)
+    target = torch.rand(P, 3, device=dev)
+
+    def body():
+        with torch.autocast("cuda", dtype=torch.float16):
+            pred, w, o = m.forward_train(x, d)
+            loss = torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params) \
+                + m.palet_loss(params)
+        opt.scale(loss).backward()
+        opt.step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 4), "points": P, "Mpoints_per_s": round(P / dt / 1e6, 2),
+            "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam, HIP-graph replay"}
 
 
 def main():
@@ -322,6 +379,8 @@ def main():
         }
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(net, r, dev)        # the "ms/frame" half of BASELINE.json's metric (not `value`)
+        if world == 1 and not args.no_style:
+            out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)

@@ -334,6 +334,21 @@ LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_r
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
                            void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream);
 
+/* ---- LAENeRF palette recomposition (editing/style_encoder.py:135-158 forward_train) ----
+ * w_logits, o_raw: the [M,16] fp16 outputs of the weight net (first P columns) and offset net (first 3 columns);
+ * palette [P,3] fp32 (device); active_mask bit k = palette base k takes part (style_encoder.py `active_palets`).
+ *   w_hat [M, popcount(mask)] fp32 = softmax over the active columns, o_hat [M,3] fp16 = tanh,
+ *   pred [M,3] fp16 = clamp(w_hat @ palette[active].half() + o_hat, 0, 1).
+ * backward: g_pred / g_o fp16 [M,3], g_w fp32 [M, n_active] (each may be NULL = zero) -> g_w_logits, g_o_raw [M,16] fp16
+ * (zeros in padded / inactive columns), g_palette [P,3] fp32 (deterministic two-stage reduction);
+ * scratch: lae_palette_backward_scratch_bytes(M). */
+LAE_API int lae_palette_forward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask,
+                        uint32_t M, void* pred, float* w_hat, void* o_hat, void* stream);
+LAE_API uint64_t lae_palette_backward_scratch_bytes(uint32_t M);
+LAE_API int lae_palette_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask,
+                         uint32_t M, const void* g_pred, const float* g_w, const void* g_o, void* g_w_logits, void* g_o_raw,
+                         float* g_palette, void* scratch, void* stream);
+
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
  *   (renderer.py:580-592).  coords NULL: c = (j / H^2, (j / H) % H, j % H) (full sweep, n <= H^3); else coords [n,3] int32.

@@ -59,6 +59,9 @@ SIGNATURES = {
     "lae_density_grid_update": [vp, vp, u32, f32, f32, u32, vp, vp, vp],
     "lae_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, f32, i32, vp, vp],
     "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, i32, vp],
+    "lae_palette_forward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp],
+    "lae_palette_backward_scratch_bytes": [u32],
+    "lae_palette_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],
@@ -74,6 +77,7 @@ SIGNATURES = {
 _RESTYPES = {
     "lae_march_rays_train_scratch_bytes": u64,
     "lae_compact_scratch_bytes": u64,
+    "lae_palette_backward_scratch_bytes": u64,
     "lae_render_frame_workspace_bytes": u64,
     "lae_version": ctypes.c_char_p,
     "lae_last_error": ctypes.c_char_p,

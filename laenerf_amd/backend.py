@@ -446,6 +446,31 @@ def _wrap_timed(name, fn):
     return timed
 
 
+class _Style:
+    """LAENeRF palette recomposition (include/laenerf.h lae_palette_*; no reference extension: torch ops there)"""
+
+    @staticmethod
+    def palette_forward(w_logits, o_raw, palette, P, active_mask, M, pred, w_hat, o_hat):
+        ts = (w_logits, o_raw, palette, pred, w_hat, o_hat)
+        need_cuda(*ts); need_contig(*ts)
+        if w_logits.dtype != _F16 or o_raw.dtype != _F16 or pred.dtype != _F16 or o_hat.dtype != _F16 or \
+                palette.dtype != torch.float32 or w_hat.dtype != torch.float32:
+            raise RuntimeError("palette_forward: MLP outputs / pred / o_hat float16, palette / w_hat float32")
+        check(_lib.load().lae_palette_forward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(pred), ptr(w_hat),
+                                              ptr(o_hat), stream()), "palette_forward")
+
+    @staticmethod
+    def palette_backward(w_logits, o_raw, palette, P, active_mask, M, g_pred, g_w, g_o, g_w_logits, g_o_raw, g_palette):
+        ts = (w_logits, o_raw, palette, g_pred, g_w, g_o, g_w_logits, g_o_raw, g_palette)
+        need_cuda(*ts); need_contig(*ts)
+        lib = _lib.load()
+        ws = _workspace(w_logits.device, lib.lae_palette_backward_scratch_bytes(M))
+        check(lib.lae_palette_backward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(g_pred), ptr(g_w), ptr(g_o),
+                                       ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws), stream()), "palette_backward")
+
+
+style_backend = _Style
+
 for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):
     for _k, _v in list(vars(_cls).items()):
         if isinstance(_v, staticmethod) and not _k.startswith("_") and _k not in ("fused_backward_available", "ffmlp_set_mode", "set_backward_mode",

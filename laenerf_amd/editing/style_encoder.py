@@ -1,0 +1,184 @@
+"""LAENeRF's palette network on the HIP operators (reference: editing/style_encoder.py:20-256).
+
+x [P,3] --hash grid (L=16, T=2^19)--> 32 features --weight net (64x64, ReLU)--> P_b logits --softmax--> w_hat
+                                      features | SH degree 3 of d (9) | 0-pad to 48 --offset net--> 3 --tanh--> o_hat
+pred = clamp(w_hat @ palette + o_hat, 0, 1)
+
+The reference builds both MLPs with tinycudann's FullyFusedMLP (`tcnn.Network`, style_encoder.py:65-88), an
+un-vendored third-party extension with no pinned version: parity is anchored on the fp32 `nn.Linear` chain of the same
+shapes instead (tests/test_gpu_style.py).  Here they are `FFMLP`s (the repository's MFMA MLP; fused recompute backward
+for the 32- and 48-wide inputs), and softmax / tanh / palette product / clamp and their backward are one kernel each
+(csrc/palette.hip).  tcnn pads the 41-wide offset input to 48 the same way.
+
+Not here (out of scope): the VGG style network (`StyleNetwork`, torchvision), image-space TV / depth losses.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from ..backend import style_backend as _backend
+from ..encoding import get_encoder
+from ..ffmlp import FFMLP
+
+
+class _palette_recompose(Function):
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, w_logits, o_raw, palette, active_mask):
+        M = w_logits.shape[0]
+        w_logits, o_raw = w_logits.half().contiguous(), o_raw.half().contiguous()
+        palette = palette.float().contiguous()
+        P = palette.shape[0]
+        n_active = bin(active_mask & ((1 << P) - 1)).count("1")
+        dev = w_logits.device
+        pred = torch.empty(M, 3, dtype=torch.half, device=dev)
+        w_hat = torch.empty(M, n_active, dtype=torch.float32, device=dev)
+        o_hat = torch.empty(M, 3, dtype=torch.half, device=dev)
+        _backend.palette_forward(w_logits, o_raw, palette, P, active_mask, M, pred, w_hat, o_hat)
+        ctx.save_for_backward(w_logits, o_raw, palette)
+        ctx.meta = (P, active_mask, M)
+        return pred, w_hat, o_hat
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_pred, g_w, g_o):
+        w_logits, o_raw, palette = ctx.saved_tensors
+        P, active_mask, M = ctx.meta
+        g_pred = None if g_pred is None else g_pred.half().contiguous()
+        g_w = None if g_w is None else g_w.float().contiguous()
+        g_o = None if g_o is None else g_o.half().contiguous()
+        g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)
+        g_pal = torch.empty_like(palette)
+        _backend.palette_backward(w_logits, o_raw, palette, P, active_mask, M, g_pred, g_w, g_o, g_wl, g_ol, g_pal)
+        return g_wl, g_ol, g_pal, None
+
+
+def palette_recompose(w_logits, o_raw, palette, active_mask):
+    """w_logits, o_raw [M,16] (the padded FFMLP outputs), palette [P,3], active_mask int (bit k = base k active)
+    -> pred [M,3] fp16, w_hat [M, n_active] fp32, o_hat [M,3] fp16   (style_encoder.py:148-158)"""
+    return _palette_recompose.apply(w_logits, o_raw, palette, int(active_mask))
+
+
+class LAENeRF(nn.Module):
+    """style_encoder.py:20-90.  `params` needs `.bound` and `.num_palette_bases` (and `style_weight`, which must be 0:
+    the VGG style network is out of scope)."""
+
+    def __init__(self, params, encoding="hashgrid", dir_encoding=None, num_layers=3, hidden_dim=64, color_palette=None, size=256,
+                 style_img=None):
+        super().__init__()
+        self.opt = params
+        self.bound = params.bound
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * self.bound, num_levels=16, log2_hashmap_size=19)
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.num_color_bases = params.num_palette_bases
+        if not 0 < self.num_color_bases <= 16:
+            raise ValueError("LAENeRF: 1..16 palette bases (the MLP output tile is 16 wide)")
+        if getattr(params, "style_weight", 0) > 0:
+            raise NotImplementedError("LAENeRF: the VGG style network is outside the MI355X hot path (SURVEY.md 2.1)")
+        self.register_buffer("active_palets", torch.ones(self.num_color_bases, dtype=torch.bool))
+        self._active_mask = (1 << self.num_color_bases) - 1                    # host copy of active_palets (no sync per step)
+        pal = color_palette if color_palette is not None else torch.rand(self.num_color_bases, 3, dtype=torch.float32)
+        self.color_palette = nn.Parameter(pal.detach().clone().float())         # style_encoder.py:46-50 (a leaf with requires_grad)
+        self.original_color_palette = None
+        self.size = size
+        self.dir_encoding, self.in_dim_dir = None, 0
+        if dir_encoding is not None:
+            self.dir_encoding, self.in_dim_dir = get_encoder(dir_encoding, degree=3)
+        # tcnn FullyFusedMLP(n_hidden_layers = num_layers - 1) = in -> 64 -> 64 -> out: FFMLP with num_layers - 1 hidden GEMMs
+        self.offset_in_dim = (self.in_dim + self.in_dim_dir + 15) // 16 * 16     # 41 -> 48, zero columns (tcnn pads alike)
+        self.offset_net = FFMLP(self.offset_in_dim, 3, hidden_dim, num_layers - 1)
+        self.weight_net = FFMLP(self.in_dim, self.num_color_bases, hidden_dim, num_layers - 1)
+
+    # ---- the two heads as the fused MLP writes them: [M,16] fp16 with padded columns
+    def _logits(self, x, d):
+        M = x.shape[0]
+        pad = (16 - M % 16) % 16
+        feat = self.encoder(x, bound=self.bound)
+        if pad:
+            feat = torch.cat([feat, feat.new_zeros(pad, feat.shape[1])], 0)
+        wn, on = self.weight_net, self.offset_net
+        from ..ffmlp.ffmlp import ffmlp_forward
+        w_logits = ffmlp_forward(feat, wn.weights, wn.input_dim, 16, wn.hidden_dim, wn.num_layers, wn.activation, wn.output_activation,
+                                 not self.training, feat.requires_grad)
+        cols = [feat]
+        if self.dir_encoding is not None:
+            enc_d = self.dir_encoding(d).to(feat.dtype)
+            if pad:
+                enc_d = torch.cat([enc_d, enc_d.new_zeros(pad, enc_d.shape[1])], 0)
+            cols.append(enc_d)
+        width = sum(c.shape[1] for c in cols)
+        if width < self.offset_in_dim:
+            cols.append(feat.new_zeros(feat.shape[0], self.offset_in_dim - width))
+        off_in = torch.cat(cols, -1) if len(cols) > 1 else feat
+        o_raw = ffmlp_forward(off_in, on.weights, on.input_dim, 16, on.hidden_dim, on.num_layers, on.activation, on.output_activation,
+                              not self.training, off_in.requires_grad)
+        return w_logits, o_raw, M
+
+    def forward_train(self, x, d=None):
+        """style_encoder.py:135-158 -> (pred_colors [M,3], w_hat [M,n_active], o_hat [M,3])"""
+        if self.dir_encoding is not None:
+            assert d is not None
+        w_logits, o_raw, M = self._logits(x, d)
+        pred, w_hat, o_hat = palette_recompose(w_logits, o_raw, self.color_palette, self._active_mask)
+        return pred[:M], w_hat[:M], o_hat[:M]
+
+    def forward(self, x, d=None):
+        """style_encoder.py:111-133"""
+        return self.forward_train(x, d)[0]
+
+    def get_weights(self, x):
+        """style_encoder.py:93-96"""
+        feat = self.encoder(x, bound=self.bound)
+        w_hat = self.weight_net(feat)[:, self.active_palets]
+        return torch.softmax(w_hat, -1)
+
+    def get_offsets(self, x, d):
+        """style_encoder.py:98-109 (raw offsets, no tanh)"""
+        return self._logits(x, d)[1][:x.shape[0], :3]
+
+    @torch.no_grad()
+    def distill_color_palettes(self, x_terms, n=10, thresh=0.025):
+        """style_encoder.py:160-173: bases whose mean weight over n sampled views is below `thresh` are switched off.
+        x_terms: list of [P_i,3] point sets (the reference indexes its EditDataset)."""
+        idx = torch.randint(0, len(x_terms), (n,))
+        weights = torch.zeros(self.num_color_bases, dtype=torch.float32, device=self.color_palette.device)
+        for i in idx.tolist():
+            weights[self.active_palets] += self.get_weights(x_terms[i].to(weights.device)).float().mean(0)
+        self.set_active_palets(weights / n >= thresh)
+
+    def set_active_palets(self, mask):
+        mask = torch.as_tensor(mask, dtype=torch.bool, device=self.active_palets.device)
+        if not bool(mask.any()):
+            raise ValueError("LAENeRF: at least one palette base must stay active")
+        self.active_palets.copy_(mask)
+        self._active_mask = sum(1 << k for k, on in enumerate(mask.tolist()) if on)
+
+    def get_color_palette(self):
+        return self.color_palette[self.active_palets]
+
+    def set_color_palette(self, palet):
+        if self.original_color_palette is None:
+            self.original_color_palette = self.color_palette.detach().clone()
+        with torch.no_grad():
+            self.color_palette[self.active_palets] = palet
+
+    # ---- point-wise losses of train_LAENeRF_step (nerf/utils.py:993-996; style_encoder.py:183-205)
+    def weights_loss(self, pred_bary_weights, params):
+        uniform_loss = torch.sum(pred_bary_weights, dim=0).max()
+        non_uniform_loss = (1 - pred_bary_weights.max(dim=-1).values).sum()
+        return uniform_loss * params.weight_loss_uniform + non_uniform_loss * params.weight_loss_non_uniform
+
+    def palet_loss(self, params):
+        dists = (torch.pow(self.color_palette[:, None, :] - self.color_palette, 2)).sum(-1)
+        dist_loss = (1 - dists / dists.max()).mean()
+        valid_loss = (torch.floor(self.color_palette) * self.color_palette).sum()
+        return valid_loss * params.palette_loss_valid + dist_loss * params.palette_loss_distinct
+
+    def offset_loss(self, pred_offsets, params):
+        return torch.pow(pred_offsets, 2).sum() * params.offset_loss
+
+    def get_params(self, lr):
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.weight_net.parameters(), "lr": lr},
+                {"params": self.offset_net.parameters(), "lr": lr}, {"params": [self.color_palette], "lr": 2 * lr}]

@@ -1,0 +1,160 @@
+"""-m gpu: LAENeRF's palette network (laenerf_amd/editing/style_encoder.py, csrc/palette.hip) against the fp32 torch
+formulation of editing/style_encoder.py:135-158 (the reference's own MLPs are tinycudann, un-vendored: parity unpinned by
+execution, anchored on the nn.Linear-equivalent chain of the same shapes)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, N
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_recompose(w_logits, o_raw, palette, active):
+    """style_encoder.py:148-158 in fp32"""
+    w_hat = torch.softmax(w_logits[:, :palette.shape[0]][:, active].float(), -1)
+    o_hat = torch.tanh(o_raw[:, :3].float())
+    pre = w_hat @ palette[active].half().float() + o_hat
+    return torch.clamp(pre, 0, 1), w_hat, o_hat
+
+
+@pytest.mark.parametrize("P,mask,M", [(8, 0xFF, 1000), (8, 0b10110101, 777), (5, 0b11111, 64), (16, 0xFFFF, 300), (3, 0b100, 130)])
+def test_palette_recompose_forward_backward(P, mask, M):
+    from laenerf_amd.editing import palette_recompose
+    torch.manual_seed(P * 1000 + M)
+    wl = (torch.randn(M, 16, device=DEV) * 2).half().requires_grad_(True)
+    ol = (torch.randn(M, 16, device=DEV) * 1.5).half().requires_grad_(True)
+    pal = torch.rand(P, 3, device=DEV).requires_grad_(True)
+    active = torch.tensor([(mask >> k) & 1 == 1 for k in range(P)], device=DEV)
+    pred, w_hat, o_hat = palette_recompose(wl, ol, pal, mask)
+    wl2, ol2, pal2 = wl.detach().clone().requires_grad_(True), ol.detach().clone().requires_grad_(True), pal.detach().clone().requires_grad_(True)
+    rp, rw, ro = torch_recompose(wl2, ol2, pal2, active)
+    assert w_hat.shape == rw.shape and w_hat.dtype == torch.float32 and pred.dtype == torch.half
+    assert np.abs(N(w_hat) - N(rw)).max() < 2e-6
+    assert np.abs(N(o_hat) - N(ro)).max() < 1e-3                       # fp16 rounding of tanh
+    assert np.abs(N(pred) - N(rp)).max() < 2e-3
+    assert np.allclose(N(w_hat).sum(-1), 1, atol=1e-5)
+    # backward with all three outputs in the loss, moderate gradients (fp16 storage of dL/dlogits)
+    gp, gw, go = torch.randn_like(rp), torch.randn_like(rw), torch.randn_like(ro)
+    (pred.float() * gp).sum().add((w_hat * gw).sum()).add((o_hat.float() * go).sum()).backward()
+    ((rp * gp).sum() + (rw * gw).sum() + (ro * go).sum()).backward()
+    # the clamp mask is evaluated on fp16-rounded values here and on fp32 values in the torch chain: compare rows
+    # whose pre-clamp value is away from 0 and 1
+    pre = (rw @ pal2[active].half().float() + ro).detach()
+    safe = ((pre - 0).abs() > 5e-3).all(-1) & ((pre - 1).abs() > 5e-3).all(-1)
+    assert safe.float().mean() > 0.9
+    s = N(safe)
+    assert np.abs(N(wl.grad)[s] - N(wl2.grad)[s]).max() < 2e-2
+    assert np.abs(N(ol.grad)[s] - N(ol2.grad)[s]).max() < 2e-2
+    assert (N(wl.grad)[:, P:] == 0).all() and (N(ol.grad)[:, 3:] == 0).all()
+    assert (N(wl.grad)[:, :P][:, ~N(active)] == 0).all()
+    if bool(safe.all()):
+        assert np.abs(N(pal.grad) - N(pal2.grad)).max() < 2e-2 * max(1.0, np.abs(N(pal2.grad)).max())
+    assert (N(pal.grad)[~N(active)] == 0).all()
+    # deterministic
+    wl.grad = None; ol.grad = None; pal.grad = None
+    pred, w_hat, o_hat = palette_recompose(wl, ol, pal, mask)
+    (pred.float() * gp).sum().add((w_hat * gw).sum()).add((o_hat.float() * go).sum()).backward()
+    g1 = pal.grad.clone(); pal.grad = None; wl.grad = None; ol.grad = None
+    pred, w_hat, o_hat = palette_recompose(wl, ol, pal, mask)
+    (pred.float() * gp).sum().add((w_hat * gw).sum()).add((o_hat.float() * go).sum()).backward()
+    assert torch.equal(g1, pal.grad)
+
+
+def chain(x, W, dims):
+    """bias-free ReLU MLP from the FFMLP flat layout W0[h,in] | Wk[h,h] | Wout[16,h]"""
+    off = 0
+    h = x
+    for i, (o, inn) in enumerate(dims):
+        w = W[off:off + o * inn].view(o, inn); off += o * inn
+        h = h @ w.t()
+        if i != len(dims) - 1:
+            h = torch.relu(h)
+    return h
+
+
+def make_model(P=8, dir_encoding="sphere_harmonics"):
+    from laenerf_amd.editing import LAENeRF
+    params = SimpleNamespace(bound=1, num_palette_bases=P, style_weight=0, weight_loss_uniform=1e-3, weight_loss_non_uniform=1e-3,
+                             offset_loss=1e-2, palette_loss_valid=1.0, palette_loss_distinct=1e-2)
+    torch.manual_seed(0)
+    m = LAENeRF(params, dir_encoding=dir_encoding).to(DEV)
+    m.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    m.weight_net.weights.data.uniform_(-0.3, 0.3)
+    m.offset_net.weights.data.uniform_(-0.3, 0.3)
+    return m, params
+
+
+def reference_forward(m, x, d):
+    """fp32 restatement of style_encoder.py:135-158 on the same parameters"""
+    feat = m.encoder(x, bound=m.bound).float()
+    wl = chain(feat, m.weight_net.weights.float(), [(64, 32), (64, 64), (16, 64)])
+    cols = [feat]
+    if m.dir_encoding is not None:
+        cols.append(m.dir_encoding(d).float())
+    cols.append(feat.new_zeros(feat.shape[0], m.offset_in_dim - sum(c.shape[1] for c in cols)))
+    ol = chain(torch.cat(cols, -1), m.offset_net.weights.float(), [(64, m.offset_in_dim), (64, 64), (16, 64)])
+    return torch_recompose(wl, ol, m.color_palette.float(), m.active_palets)
+
+
+@pytest.mark.parametrize("n", [4096, 1000])
+def test_laenerf_forward_train_and_gradients(n):
+    m, params = make_model()
+    m.train()
+    torch.manual_seed(1)
+    x = (torch.rand(n, 3, device=DEV) * 2 - 1) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
+    target = torch.rand(n, 3, device=DEV)
+    assert m.offset_in_dim == 48 and m.weight_net.num_layers == 2
+
+    def loss_of(pred, w, o):
+        return torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w.float(), params) + m.offset_loss(o.float(), params) \
+            + m.palet_loss(params)
+    with torch.autocast("cuda", dtype=torch.float16):
+        pred, w_hat, o_hat = m.forward_train(x, d)
+        loss = loss_of(pred, w_hat, o_hat)
+    assert pred.shape == (n, 3) and w_hat.shape == (n, 8) and o_hat.shape == (n, 3)
+    (loss * 128.0).backward()
+    got = {k: (v.grad / 128.0).clone() for k, v in (("table", m.encoder.embeddings), ("wn", m.weight_net.weights),
+                                                     ("on", m.offset_net.weights), ("pal", m.color_palette))}
+    m.zero_grad()
+    rp, rw, ro = reference_forward(m, x, d)
+    assert np.abs(N(pred) - N(rp)).max() < 1e-2 and np.abs(N(w_hat) - N(rw)).max() < 1e-2 and np.abs(N(o_hat) - N(ro)).max() < 1e-2
+    rloss = loss_of(rp, rw, ro)
+    assert loss.item() == pytest.approx(rloss.item(), rel=2e-2)
+    rloss.backward()
+    for k, p in (("wn", m.weight_net.weights), ("on", m.offset_net.weights), ("pal", m.color_palette)):
+        ref = N(p.grad)
+        assert np.abs(N(got[k]) - ref).max() < 0.08 * np.abs(ref).max() + 1e-6, k
+    gt, rt = N(got["table"]), N(m.encoder.embeddings.grad)
+    assert np.linalg.norm(gt - rt) < 0.1 * np.linalg.norm(rt)
+
+
+def test_laenerf_inference_active_palettes_and_no_dirs():
+    m, params = make_model(P=6)
+    m.eval()
+    x = (torch.rand(500, 3, device=DEV) * 2 - 1) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(500, 3, device=DEV), dim=-1)
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        full = m(x, d)
+        m.set_active_palets([True, False, True, True, False, True])
+        part, w, o = m.forward_train(x, d)
+        assert w.shape == (500, 4) and m.get_color_palette().shape == (4, 3)
+        rp, rw, ro = reference_forward(m, x, d)
+        assert np.abs(N(part) - N(rp)).max() < 1e-2 and np.abs(N(w) - N(rw)).max() < 1e-2
+        gw = m.get_weights(x)
+        assert np.abs(N(gw) - N(w)).max() < 2e-3
+        assert np.abs(N(m.get_offsets(x, d)).astype(np.float32) - np.arctanh(np.clip(N(ro), -0.999, 0.999))).max() < 5e-2
+        m.distill_color_palettes([x, x * 0.5], n=4, thresh=1e-6)      # switched-off bases have mean weight 0
+        assert int(m.active_palets.sum()) == 4 and m._active_mask == 0b101101
+        with pytest.raises(ValueError):
+            m.set_active_palets([False] * 6)
+    assert full.shape == (500, 3)
+    m2, _ = make_model(dir_encoding=None)
+    assert m2.offset_in_dim == 32
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        p2 = m2(x)
+        rp2 = reference_forward(m2, x, None)[0]
+    assert np.abs(N(p2) - N(rp2)).max() < 1e-2
