@@ -109,13 +109,11 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
     float gp_pal[PAL_MAX][3];
 #pragma unroll
     for (int k = 0; k < PAL_MAX; k++) { gp_pal[k][0] = 0.f; gp_pal[k][1] = 0.f; gp_pal[k][2] = 0.f; }
-    uint32_t na_block = 0;
     if (i < M) {
         const Row16 wl = load_row16(w_logits + (size_t)i * 16), ol = load_row16(o_raw + (size_t)i * 16);
         float w[PAL_MAX];
         uint32_t na;
         softmax_active(wl, P, mask, w, na);
-        na_block = na;
         half_t o[3], pre[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) o[c] = (half_t)tanhf((float)ol.v[c]);
@@ -147,18 +145,21 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
         *reinterpret_cast<uint4*>(g_ol + (size_t)i * 16) = *reinterpret_cast<const uint4*>(&out_o.v[0]);
         *reinterpret_cast<uint4*>(g_ol + (size_t)i * 16 + 8) = *reinterpret_cast<const uint4*>(&out_o.v[8]);
     }
-    (void)na_block;
-    // palette gradient: wave reduce -> LDS -> one partial row per workgroup
+    // palette gradient: wave reduce (active rows only; the count is uniform) -> LDS -> one partial row per workgroup
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t na_u = (uint32_t)__popc(mask & ((P >= 32 ? 0u : (1u << P)) - 1u));
 #pragma unroll
-    for (int k = 0; k < PAL_MAX; k++)
+    for (int k = 0; k < PAL_MAX; k++) {
+        if ((uint32_t)k < na_u) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float v = gp_pal[k][c];
+            for (int c = 0; c < 3; c++) {
+                float v = gp_pal[k][c];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == 0) red[wv][k * 3 + c] = v;
-        }
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                if (lane == 0) red[wv][k * 3 + c] = v;
+            }
+        } else if (lane == 0) { red[wv][k * 3] = 0.f; red[wv][k * 3 + 1] = 0.f; red[wv][k * 3 + 2] = 0.f; }
+    }
     __syncthreads();
     if (threadIdx.x < PAL_MAX * 3) {
         float t = 0.0f;
@@ -168,13 +169,16 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
     }
 }
 
-// fixed-order sum of the slabs; scatter the compact active rows back to the [P,3] parameter gradient (inactive rows 0)
+// fixed-order sum of the slabs (one workgroup per (compact row j, channel c): lanes stride over the partials, then a
+// butterfly -- the same order every run); scatter the compact active rows back to the [P,3] parameter gradient
 __global__ __launch_bounds__(64) void k_palette_grad_reduce(const float* __restrict__ slab, uint32_t n_blocks, uint32_t P, uint32_t mask,
                                                             float* __restrict__ g_palette) {
-    const uint32_t e = threadIdx.x;                      // (compact row j, channel c)
-    if (e >= PAL_MAX * 3) return;
+    const uint32_t e = blockIdx.x;                       // (compact row j, channel c)
     float t = 0.0f;
-    for (uint32_t b = 0; b < n_blocks; b++) t += slab[(size_t)b * (PAL_MAX * 3) + e];
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 64) t += slab[(size_t)b * (PAL_MAX * 3) + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+    if (threadIdx.x != 0) return;
     const uint32_t j = e / 3, c = e % 3;
     uint32_t seen = 0;
     for (uint32_t k = 0; k < P; k++) {
@@ -217,7 +221,7 @@ int lae_palette_backward(const void* w_logits, const void* o_raw, const float* p
     const uint32_t nb = lae::cdiv(M, PAL_BLOCK);
     k_palette_bwd<<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M, (const half_t*)g_pred, g_w,
                                            (const half_t*)g_o, (half_t*)g_w_logits, (half_t*)g_o_raw, (float*)scratch);
-    k_palette_grad_reduce<<<1, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
+    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
     return lae::check_launch("palette_backward");
 }
 
