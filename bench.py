@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
+    p.add_argument("--no-pipeline", action="store_true",
+                   help="one graph per step; default: the march of step k+1 (no weight dependence) is its own graph, replayed on a "
+                        "side stream beside the shading / backward / optimizer graph of step k")
     p.add_argument("--torch-loss", action="store_true", help="A/B: torch mse_loss + scale() instead of laenerf_amd.losses.mse_loss_scaled")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="A/B: torch.optim.Adam(fused) + torch.amp.GradScaler instead of laenerf_amd.optim.FusedAdam")
@@ -287,6 +290,7 @@ def main():
     # One graph per resident ray batch (the batches already live in HBM, so a replay reads them in place); the graphs
     # share one memory pool because they never run concurrently.
     graph = None
+    pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer
     if not args.no_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -296,6 +300,7 @@ def main():
                 step_body(*batches[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+    if not args.no_graph and not pipelined:
         graphs, n_graph_samples = [], []
         for b in range(n_batches):
             zero_grad()
@@ -310,6 +315,56 @@ def main():
             return n_graph_samples[i % n_batches]
         for i in range(5):
             step(i)
+    if pipelined:
+        # The march reads rays and the occupancy bitfield only (no network weight), so the march of step k+1 is captured
+        # as its own graph and replayed on a side stream while the main stream runs shading, backward and the optimizer
+        # of step k.  The counting half of the hash-grid backward (positions only) rides along in that graph.  Same kernels and the same work per step; the two graph families use separate memory pools because
+        # they run concurrently, and every march graph keeps its own output buffers (read by its shading graph).
+        main = torch.cuda.current_stream()
+        g_march, g_rest, marched, n_graph_samples = [], [], [], []
+        for b in range(n_batches):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g_march[0].pool() if g_march else None):
+                marched.append(r.march_train(batches[b][0], batches[b][1], perturb=True, max_steps=1024, plan_backward=True))
+            g_march.append(g)
+        for b in range(n_batches):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g_rest[0].pool() if g_rest else None):
+                with torch.autocast("cuda", dtype=torch.float16):
+                    res = r.shade_train(marched[b], bg_color=1)
+                    loss = mse_loss_scaled(res["image"], batches[b][2], scaler) if fused_loss else \
+                        scaler.scale(torch.nn.functional.mse_loss(res["image"], batches[b][2]))
+                loss.backward()
+                opt.step()
+                n_graph_samples.append(res["n_samples"])
+            g_rest.append(g)
+        graph = g_rest[0]
+        ev_march = [torch.cuda.Event() for _ in range(n_batches)]
+        ev_rest = [torch.cuda.Event() for _ in range(n_batches)]
+        state = {"primed": -1}
+
+        def launch_march(b):
+            with torch.cuda.stream(side):
+                g_march[b].replay()
+                ev_march[b].record(side)
+
+        def step(i):                                        # noqa: F811
+            b, nxt = i % n_batches, (i + 1) % n_batches
+            if state["primed"] != b:                        # first step after a break in the sequence: march in line
+                side.wait_stream(main)
+                launch_march(b)
+            main.wait_event(ev_march[b])
+            side.wait_event(ev_rest[(b - 1) % n_batches]) if i > 0 else None   # stay at most one step ahead
+            launch_march(nxt)
+            state["primed"] = nxt
+            g_rest[b].replay()
+            ev_rest[b].record(main)
+            return n_graph_samples[b]
+        for b in range(n_batches):
+            ev_rest[b].record(main)
+        for i in range(n_warm - 5, n_warm):                 # ends with the march of the first timed step in flight
+            step(i)
+        torch.cuda.synchronize()
     backend.enable_kernel_timing(not graph)
 
     def sync_all():
@@ -368,6 +423,7 @@ def main():
                        "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
                        "optimizer_in_timed_region": not args.no_optimizer,
                        "hip_graph_replay": bool(graph),
+                       "march_pipelined_on_side_stream": bool(pipelined),
                        "parallelism": f"{world} independent ray-batch replicas (no data-path collective)"},
             "roofline": {"kernel": "k_grid_fwd (hash-grid encode forward, fp16 table)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -261,6 +261,20 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
                                 void* stream);
 
+/* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- counting sort bookkeeping: per
+ * (level, table partition) item counts, their scans -- depends on the sample positions only, so a caller can run it as
+ * soon as the positions exist (e.g. right after the march, on another stream beside the forward pass) and hand the
+ * result to the second half, which needs the gradients.  plan: lae_grid_backward_plan_bytes(B, L) bytes of device
+ * memory, read-only for `_planned`.  grad is level-major [L, B, 2] (the layout of lae_grid_encode_backward). */
+LAE_API uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L);
+LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                  float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                  float in_shift, float in_scale, void* plan, void* stream);
+LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
+                                     uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
+                                     int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
+                                     const void* plan, void* stream);
+
 /* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
  * 1 = always the generic kernel (one global atomic per corner, what the reference does). */
 LAE_API int lae_grid_set_backward_mode(int mode);

@@ -46,6 +46,9 @@ SIGNATURES = {
     "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, f32, f32, vp],
     "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp],
     "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp],
+    "lae_grid_backward_plan_bytes": [u32, u32],
+    "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
+    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
     "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
@@ -77,6 +80,7 @@ SIGNATURES = {
 _RESTYPES = {
     "lae_march_rays_train_scratch_bytes": u64,
     "lae_compact_scratch_bytes": u64,
+    "lae_grid_backward_plan_bytes": u64,
     "lae_palette_backward_scratch_bytes": u64,
     "lae_render_frame_workspace_bytes": u64,
     "lae_version": ctypes.c_char_p,

@@ -273,13 +273,32 @@ class _GridEncoder:
             check(lib.lae_grid_encode_forward(*args, stream()), "grid_encode_forward")
 
     @staticmethod
+    def grid_backward_plan(inputs, offsets, B, D, C, L, S, H, gridtype, align_corners, interp, half, in_map=(0.0, 1.0)):
+        """first half of the binned grid backward (positions only) -> plan tensor for grid_encode_backward(plan=...)"""
+        need_cuda(inputs, offsets); need_contig(inputs, offsets)
+        lib = _lib.load()
+        plan = torch.empty(int(lib.lae_grid_backward_plan_bytes(B, L)), dtype=torch.uint8, device=inputs.device)
+        check(lib.lae_grid_encode_backward_plan(ptr(inputs), ptr(offsets), B, D, C, L, float(S), H, gridtype, int(bool(align_corners)),
+                                                interp, 1 if half else 0, float(in_map[0]), float(in_map[1]), ptr(plan), stream()),
+              "grid_backward_plan")
+        return plan
+
+    @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                             gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0)):
-        ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs)
+                             gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0), plan=None):
+        """plan (MI355X extension): result of grid_backward_plan for the same inputs -- skips the count pass and scans"""
+        ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs, plan)
         need_cuda(*ts); need_contig(*ts)
         if grad.dtype != grad_embeddings.dtype:
             raise RuntimeError("grid_encode_backward: grad and grad_embeddings dtypes differ")
         lib = _lib.load()
+        if plan is not None:
+            if blc or dy_dx is not None:
+                raise RuntimeError("grid_encode_backward: a plan needs level-major gradients and no input gradient")
+            check(lib.lae_grid_encode_backward_planned(ptr(grad), ptr(inputs), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
+                                                       gridtype, int(bool(align_corners)), interp, _dtype_code(grad), float(in_map[0]),
+                                                       float(in_map[1]), ptr(plan), stream()), "grid_encode_backward")
+            return
         args = (ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad))
         if blc:

@@ -442,12 +442,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin(
     for (int s_ = 0; s_ < BIN_SPT; s_++)
 #pragma unroll
         for (int d = 0; d < 3; d++) xs[s_][d] = (xs[s_][d] + sc.in_shift) * sc.in_scale;
-    const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
+    if constexpr (FILL) {                               // the COUNT pass depends on the positions only (it can run before
+        const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;   // the gradients exist: lae_grid_encode_backward_plan)
 #pragma unroll
-    for (int s_ = 0; s_ < BIN_SPT; s_++) {
-        const uint32_t b = min(b0 + s_, B - 1);
-        if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
-        else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
+        for (int s_ = 0; s_ < BIN_SPT; s_++) {
+            const uint32_t b = min(b0 + s_, B - 1);
+            if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
+            else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
+        }
+    } else {
+#pragma unroll
+        for (int s_ = 0; s_ < BIN_SPT; s_++) { g0[s_] = 0.f; g1[s_] = 0.f; }
     }
 
     // emit one finished cell: `mode` 0 = count/rank (returns ranks through rk[]), 1 = write items
@@ -901,30 +906,44 @@ static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t
     return &cache.back().v;
 }
 
+// The binned backward in two halves.  PLAN (count pass + scans) reads the sample positions only and fills
+// {bucket totals | bucket offsets | per-block exclusive counts}; EXEC (fill + accumulate) needs the gradients.  A caller
+// may run PLAN early -- e.g. right after the march, beside the forward pass (lae_grid_encode_backward_plan) -- the default
+// entry points run both back to back in the library workspace.
+static inline size_t bin_tab_bytes(uint32_t L) { return (((size_t)2 * L * BK_MAX * 4 + 255) / 256) * 256; }
+static inline size_t bin_plan_bytes(uint32_t B, uint32_t L) {
+    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
+    return bin_tab_bytes(L) + (((size_t)nb * L * BK_MAX * 4 + 255) / 256) * 256;
+}
+struct BinPlan { uint32_t* counts; uint32_t* offs; uint32_t* block_counts; };
+static inline BinPlan bin_plan_at(void* buf, uint32_t L) {
+    uint8_t* p = reinterpret_cast<uint8_t*>(buf);
+    BinPlan bp;
+    bp.counts = reinterpret_cast<uint32_t*>(p);
+    bp.offs = bp.counts + (size_t)L * BK_MAX;
+    bp.block_counts = reinterpret_cast<uint32_t*>(p + bin_tab_bytes(L));
+    return bp;
+}
+
 template <typename T>
-static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L,
-                           const BwdArgs& a) {
-    const T* g = (const T*)gT;
-    T* ge = (T*)gemb;
-    // count -> scans -> fill -> accumulate.  Worst case 8 items per (sample, level).
+static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t L, const BwdArgs& a, const BinPlan& bp) {
     const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
     const size_t n_tab = (size_t)L * BK_MAX;
-    const size_t tab_bytes = ((2 * n_tab * 4 + 255) / 256) * 256;
-    const size_t blk_bytes = (((size_t)nb * n_tab * 4 + 255) / 256) * 256;
-    const size_t q_bytes = (size_t)B * 8 * L * sizeof(HItem<T>);
-    uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, tab_bytes + blk_bytes + q_bytes));
-    if (!ws) return LAE_ELAUNCH;
-    uint32_t* counts = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* offs = counts + n_tab;
-    uint32_t* block_counts = reinterpret_cast<uint32_t*>(ws + tab_bytes);
-    HItem<T>* queue = reinterpret_cast<HItem<T>*>(ws + tab_bytes + blk_bytes);
-    k_bin<T, false><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
-                                                        block_counts, offs, queue);
-    k_bin_scan_blocks<<<lae::cdiv(n_tab, 4), 256, 0, a.stream>>>(block_counts, counts, L, nb);
-    k_bin_scan<<<1, 1024, 0, a.stream>>>(counts, offs, (uint32_t)n_tab);
+    k_bin<T, false><<<nb * L, BIN_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
+                                                        bp.block_counts, bp.offs, nullptr);
+    k_bin_scan_blocks<<<lae::cdiv(n_tab, 4), 256, 0, a.stream>>>(bp.block_counts, bp.counts, L, nb);
+    k_bin_scan<<<1, 1024, 0, a.stream>>>(bp.counts, bp.offs, (uint32_t)n_tab);
+}
+
+template <typename T>
+static int bwd_exec(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L, const BwdArgs& a,
+                    const BinPlan& bp, HItem<T>* queue) {
+    const T* g = (const T*)gT;
+    T* ge = (T*)gemb;
+    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
     k_bin<T, true><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
-                                                       block_counts, offs, queue);
-    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, counts, offs, queue);
+                                                       bp.block_counts, bp.offs, queue);
+    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, bp.counts, bp.offs, queue);
     // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel; skipped when the host copy of
     // the level sizes shows that no level needs it
     bool need_generic = true;
@@ -946,16 +965,42 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     return LAE_OK;
 }
 
+// queue of the fill / accumulate passes: worst case 8 items per (sample, level); library workspace
+template <typename T>
+static HItem<T>* bin_queue(uint32_t B, uint32_t L, size_t extra_bytes, uint8_t** base_out) {
+    const size_t q_bytes = (size_t)B * 8 * L * sizeof(HItem<T>);
+    uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, extra_bytes + q_bytes));
+    if (base_out) *base_out = ws;
+    return ws ? reinterpret_cast<HItem<T>*>(ws + extra_bytes) : nullptr;
+}
+
+template <typename T>
+static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L,
+                           const BwdArgs& a, const void* plan = nullptr) {
+    if (plan) {                                            // counts / offsets were prepared by lae_grid_encode_backward_plan
+        HItem<T>* queue = bin_queue<T>(B, L, 0, nullptr);
+        if (!queue) return LAE_ELAUNCH;
+        return bwd_exec<T>(gT, inputs, offsets, gemb, B, L, a, bin_plan_at(const_cast<void*>(plan), L), queue);
+    }
+    uint8_t* ws = nullptr;
+    HItem<T>* queue = bin_queue<T>(B, L, bin_plan_bytes(B, L), &ws);
+    if (!queue) return LAE_ELAUNCH;
+    const BinPlan bp = bin_plan_at(ws, L);
+    bwd_plan<T>(inputs, offsets, B, L, a, bp);
+    return bwd_exec<T>(gT, inputs, offsets, gemb, B, L, a, bp, queue);
+}
+
 // 0 = binned LDS pipeline where available (default), 1 = always the generic global-atomic kernel
 static int g_force_atomic_bwd = 0;
 
 static int grid_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                          const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
-                         int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f) {
+                         int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f, const void* plan = nullptr) {
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
+    if (plan && !(D == 3 && C == 2 && L <= 32 && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
     BwdArgs a;
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
@@ -978,8 +1023,8 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
             else k_grad_transpose<float><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const float*)grad, (float*)ws, B, L);
             gT = ws;
         }
-        rc = (dtype == LAE_F16) ? launch_bwd_fast<half_t>(gT, inputs, offsets, grad_embeddings, B, L, a)
-                                : launch_bwd_fast<float>(gT, inputs, offsets, grad_embeddings, B, L, a);
+        rc = (dtype == LAE_F16) ? launch_bwd_fast<half_t>(gT, inputs, offsets, grad_embeddings, B, L, a, plan)
+                                : launch_bwd_fast<float>(gT, inputs, offsets, grad_embeddings, B, L, a, plan);
         if (rc) return rc;
         rc = LAE_OK;
     } else if (dtype == LAE_F32) rc = dispatch_bwd_d<float>(a, D, C);
@@ -1076,6 +1121,35 @@ int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
                                 void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale);
+}
+
+uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L) { return bin_plan_bytes(B, L); }
+
+int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                  uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float in_shift,
+                                  float in_scale, void* plan, void* stream) {
+    if (B == 0) return LAE_OK;
+    if (!inputs || !offsets || !plan) return LAE_ENULL;
+    if (D != 3 || C != 2 || L > 32 || gridtype > 1 || interp > 1 || (dtype != LAE_F32 && dtype != LAE_F16)) return LAE_EINVAL;
+    BwdArgs a;
+    a.grad = nullptr; a.inputs = inputs; a.offsets = offsets; a.gemb = nullptr; a.B = B; a.L = L;
+    int rc = fill_scales(a.sc, L, S, H);
+    if (rc) return rc;
+    a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
+    a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
+    a.gs_b = C; a.gs_l = (uint64_t)B * C;
+    a.stream = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == LAE_F16) bwd_plan<half_t>(inputs, offsets, B, L, a, bin_plan_at(plan, L));
+    else bwd_plan<float>(inputs, offsets, B, L, a, bin_plan_at(plan, L));
+    return lae::check_launch("grid_encode_backward_plan");
+}
+
+int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                                     uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                     uint32_t interp, int dtype, float in_shift, float in_scale, const void* plan, void* stream) {
+    if (!plan) return LAE_ENULL;
+    return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
+                         interp, dtype, false, stream, in_shift, in_scale, plan);
 }
 
 int lae_grid_set_backward_mode(int mode) {

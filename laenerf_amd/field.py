@@ -18,7 +18,7 @@ from .ffmlp.head import COLOR_NET_PARAMS, SIGMA_NET_PARAMS
 class _nerf_field(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, x, dirs, embeddings, sigma_weights, color_weights, enc, sigma_shadow, color_shadow, bound, density_scale):
+    def forward(ctx, x, dirs, embeddings, sigma_weights, color_weights, enc, sigma_shadow, color_shadow, bound, density_scale, plan=None):
         M = x.shape[0]
         L = enc.num_levels
         x = x.float().contiguous()
@@ -40,6 +40,7 @@ class _nerf_field(Function):
         _mlp.nerf_head_forward(feats, dirs, ws, wc, M, density_scale, h, sigmas, rgbs, level_major=True)
         ctx.save_for_backward(x, dirs, table, ws, wc, feats, h, rgbs)
         ctx.enc, ctx.shadows, ctx.in_map, ctx.geom = enc, shadows, in_map, (M, L, S, H)
+        ctx.plan = plan
         ctx.density_scale = density_scale
         ctx.wdtypes = (sigma_weights.dtype, color_weights.dtype)
         return sigmas, rgbs
@@ -62,10 +63,10 @@ class _nerf_field(Function):
                                 gws, gwc, accumulate=ctx.shadows is not None, level_major=True)
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
-                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map)
+                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, plan=ctx.plan)
         return (None, None, None if enc.shadow is not None else grad_table,
                 None if ctx.shadows is not None else gws.to(ctx.wdtypes[0]),
-                None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None)
+                None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None, None)
 
 
 def field_supported(enc, sigma_net, color_net):
@@ -73,9 +74,21 @@ def field_supported(enc, sigma_net, color_net):
             and sigma_net.weights.numel() == SIGMA_NET_PARAMS and color_net.weights.numel() == COLOR_NET_PARAMS)
 
 
-def nerf_field(x, dirs, enc, sigma_net, color_net, bound=1, density_scale=1.0):
-    """x [M,3] in [-bound, bound], dirs [M,3] unit -> sigmas [M] fp32, rgbs [M,3] fp32 (fp16 table and MLPs; M % 16 == 0)"""
+def nerf_field(x, dirs, enc, sigma_net, color_net, bound=1, density_scale=1.0, plan=None):
+    """x [M,3] in [-bound, bound], dirs [M,3] unit -> sigmas [M] fp32, rgbs [M,3] fp32 (fp16 table and MLPs; M % 16 == 0).
+    plan: `field_backward_plan(x, enc, bound)` computed earlier (positions only) -- the table-gradient pass then skips
+    its counting half."""
     if x.shape[0] % 16 != 0:
         raise RuntimeError("nerf_field: the number of samples must be a multiple of 16")
     return _nerf_field.apply(x, dirs, enc.embeddings, sigma_net.weights, color_net.weights, enc, sigma_net.shadow,
-                             color_net.shadow, float(bound), float(density_scale))
+                             color_net.shadow, float(bound), float(density_scale), plan)
+
+
+@torch.no_grad()
+def field_backward_plan(x, enc, bound=1):
+    """counting half of the hash-grid backward for the samples x [M,3] (fp16 table path): depends on the positions
+    only, so it can be launched right after the march, on another stream, beside the forward pass"""
+    x = x.float().contiguous()
+    in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+    return _grid.grid_backward_plan(x, enc.offsets, x.shape[0], 3, 2, enc.num_levels, np.log2(enc.per_level_scale), enc.base_resolution,
+                                    enc.gridtype_id, enc.align_corners, enc.interp_id, True, in_map)

@@ -11,7 +11,7 @@ import torch.nn as nn
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .ffmlp import FFMLP, nerf_density, nerf_head
-from .field import field_supported, nerf_field
+from .field import field_backward_plan, field_supported, nerf_field
 
 
 class NeRFNetwork(nn.Module):
@@ -39,12 +39,22 @@ class NeRFNetwork(nn.Module):
                            and geo_feat_dim == 15 and getattr(self.encoder_dir, "degree", 0) == 4)
         self.fused_field = self.fused_head and encoding == "hashgrid" and field_supported(self.encoder, self.sigma_net, self.color_net)
 
-    def forward(self, x, d):
+    def _field_ok(self, x, d):
+        return (self.fused_field and self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and torch.is_autocast_enabled("cuda")
+                and not x.requires_grad and not d.requires_grad)
+
+    def plan_backward(self, x):
+        """MI355X-native: the position-only half of the table-gradient pass for the samples x (None when the fused field
+        op does not apply); hand the result to forward(x, d, plan=...)"""
+        if not (self.fused_field and self.fused_head and x.is_cuda and x.shape[0] % 16 == 0):
+            return None
+        return field_backward_plan(x.view(-1, 3), self.encoder, self.bound)
+
+    def forward(self, x, d, plan=None):
         """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N] fp32, rgb [N,3]   (network_ff.py:51-81)"""
-        if (self.fused_field and self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and torch.is_autocast_enabled("cuda")
-                and not x.requires_grad and not d.requires_grad):
+        if self._field_ok(x, d):
             # encoder + head as one op: features stay level-major between the grid and MLP kernels (field.py)
-            return nerf_field(x.view(-1, 3), d, self.encoder, self.sigma_net, self.color_net, self.bound)
+            return nerf_field(x.view(-1, 3), d, self.encoder, self.sigma_net, self.color_net, self.bound, plan=plan)
         x = self.encoder(x, bound=self.bound)
         if self.fused_head and x.is_cuda and x.shape[0] % 16 == 0 and x.dtype == torch.half and not d.requires_grad:
             return nerf_head(x, d, self.sigma_net.weights, self.color_net.weights, 1.0, self.sigma_net.shadow, self.color_net.shadow)

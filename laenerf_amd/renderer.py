@@ -192,10 +192,13 @@ class NeRFRenderer(nn.Module):
         marched = self.march_train(rays_o, rays_d, perturb, force_all_rays, dt_gamma, max_steps, dens_grid)
         return self.shade_train(marched, bg_color, T_thresh)
 
-    def march_train(self, rays_o, rays_d, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, dens_grid=None):
+    def march_train(self, rays_o, rays_d, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, dens_grid=None,
+                    plan_backward=False):
         """first half of the training render: ray/box intersection and the occupancy march (renderer.py:285-311).  It
-        reads no network weight.  (Measured: overlapping it with the previous step's optimizer update as a forked
-        branch of the captured graph did not help on this stack, 0.600 vs 0.580 ms/step, so bench.py stays sequential.)"""
+        reads no network weight, so it can run for step k+1 while step k is still in its backward (bench.py replays it
+        as its own graph on a side stream: 0.575 -> 0.530 ms/step; a forked branch inside ONE captured graph did not
+        overlap on this stack).  plan_backward=True additionally runs the position-only half of the hash-grid
+        backward (counting pass + scans) here and returns the plan as a 7th element for shade_train."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         grid = self.density_bitfield if dens_grid is None else dens_grid
@@ -206,12 +209,15 @@ class NeRFRenderer(nn.Module):
         xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, grid, self.cascade,
                                                                 self.grid_size, nears, fars, counter, self.mean_count,
                                                                 perturb, 128, force_all_rays, dt_gamma, max_steps)
+        if plan_backward and hasattr(self.model, "plan_backward"):
+            return xyzs, dirs, deltas, rays, nears, fars, self.model.plan_backward(xyzs)
         return xyzs, dirs, deltas, rays, nears, fars
 
     def shade_train(self, marched, bg_color=1, T_thresh=1e-4):
         """second half: network on the samples, compositing, background blend, depth normalisation (renderer.py:313-334)"""
-        xyzs, dirs, deltas, rays, nears, fars = marched
-        sigmas, rgbs = self.model(xyzs, dirs)
+        xyzs, dirs, deltas, rays, nears, fars = marched[:6]
+        plan = marched[6] if len(marched) > 6 else None
+        sigmas, rgbs = self.model(xyzs, dirs, plan=plan) if plan is not None else self.model(xyzs, dirs)
         if self.density_scale != 1:
             sigmas = self.density_scale * sigmas
         if self.fused_post_ops:      # composite + bg blend + depth normalisation in one kernel, gradients without zero fills

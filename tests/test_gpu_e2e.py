@@ -144,3 +144,38 @@ def test_full_size_properties(O):
     g = torch.randn_like(y)
     y.backward(g)
     assert enc.embeddings.grad.double().sum().item() == pytest.approx(g.double().sum().item(), rel=1e-3, abs=1e-2)
+
+
+def test_planned_grid_backward_equals_default():
+    """march_train(plan_backward=True): the counting half of the table-gradient pass runs with the march (positions only);
+    gradients must be identical to the default back-to-back pipeline (full-size table: every hashed level has >= 16
+    partitions, so each table slice has one writer and its fp16 sums are exact, hence order independent)"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(3)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=19).to(DEV)
+    net.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    r = NeRFRenderer(net, bound=1).to(DEV)
+    r.density_bitfield = T(S.pack_bits_np(S.sphere_density_grid(), 10.0))
+    o, d = S.lego_like_rays(1024, seed=4)
+    o, d = T(o), T(d)
+    net.train()
+    grads = []
+    for plan in (False, True):
+        net.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            marched = r.march_train(o, d, perturb=False, plan_backward=plan)
+            assert len(marched) == (7 if plan else 6)
+            res = r.shade_train(marched, bg_color=1)
+            loss = ((res["image"] - 0.3) ** 2).mean() * 1024.0
+        loss.backward()
+        grads.append([p.grad.clone() for p in (net.encoder.embeddings, net.sigma_net.weights, net.color_net.weights)])
+    assert grads[0][0].abs().sum().item() > 0
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        assert torch.equal(a, b)                                            # MLP weights: fixed-order reductions
+    lo = int(net.encoder.offsets[4].item())                                  # levels 4.. have >= 16 partitions: one writer per slice
+    ta, tb = grads[0][0], grads[1][0]
+    assert torch.equal(ta[lo:], tb[lo:])
+    # coarser levels merge their sub-buckets with fp16 atomics (order dependent at the last bit, with or without a plan)
+    assert (ta[:lo] - tb[:lo]).abs().max().item() <= 2e-3 * ta[:lo].abs().max().item()
