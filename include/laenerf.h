@@ -348,6 +348,14 @@ LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_r
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
                            void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream);
 
+/* ---- freqencoder (freqencoder/src/freqencoder.h:6-10; bindings.cpp:5-8) ----
+ * outputs [B, C], C = D + 2*D*deg: the input, then per frequency f < deg the D sines and D cosines of x * 2^f.
+ * backward: grad [B, C], outputs (saved forward result) -> grad_inputs [B, D] (overwritten). fp32 only. */
+LAE_API int lae_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
+                            void* stream);
+LAE_API int lae_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                             float* grad_inputs, void* stream);
+
 /* ---- LAENeRF palette recomposition (editing/style_encoder.py:135-158 forward_train) ----
  * w_logits, o_raw: the [M,16] fp16 outputs of the weight net (first P columns) and offset net (first 3 columns);
  * palette [P,3] fp32 (device); active_mask bit k = palette base k takes part (style_encoder.py `active_palets`).

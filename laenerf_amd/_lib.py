@@ -53,6 +53,8 @@ SIGNATURES = {
     "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
     "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
     "lae_sh_encode_backward": [vp, vp, u32, u32, u32, vp, vp, vp],
+    "lae_freq_encode_forward": [vp, u32, u32, u32, u32, vp, vp],
+    "lae_freq_encode_backward": [vp, vp, u32, u32, u32, u32, vp, vp],
     "lae_ffmlp_forward": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],

@@ -340,6 +340,21 @@ class _SHEncoder:
 
 
 # --------------------------------------------------------------------------- _ffmlp
+class _FreqEncoder:
+    """freqencoder/src/bindings.cpp:5-8"""
+
+    @staticmethod
+    def freq_encode_forward(inputs, B, D, deg, C, outputs):
+        need_cuda(inputs, outputs); need_contig(inputs, outputs); _need_f32(inputs, outputs)     # freqencoder.cu:98-104
+        check(_lib.load().lae_freq_encode_forward(ptr(inputs), B, D, deg, C, ptr(outputs), stream()), "freq_encode_forward")
+
+    @staticmethod
+    def freq_encode_backward(grad, outputs, B, D, deg, C, grad_inputs):
+        need_cuda(grad, outputs, grad_inputs); need_contig(grad, outputs, grad_inputs); _need_f32(grad, outputs, grad_inputs)
+        check(_lib.load().lae_freq_encode_backward(ptr(grad), ptr(outputs), B, D, deg, C, ptr(grad_inputs), stream()),
+              "freq_encode_backward")
+
+
 class _FFMLP:
     @staticmethod
     def _half(*ts):
@@ -500,6 +515,7 @@ raymarching_backend = _RayMarching
 gridencoder_backend = _GridEncoder
 shencoder_backend = _SHEncoder
 ffmlp_backend = _FFMLP
+freqencoder_backend = _FreqEncoder
 
 
 def _as_module(name, cls):
@@ -517,5 +533,5 @@ def install_as_reference_backends():
     editing/*) runs on it unmodified."""
     _lib.load()
     for name, cls in (("_raymarching", _RayMarching), ("_gridencoder", _GridEncoder), ("_shencoder", _SHEncoder),
-                      ("_ffmlp", _FFMLP)):
+                      ("_ffmlp", _FFMLP), ("_freqencoder", _FreqEncoder)):
         sys.modules[name] = _as_module(name, cls)

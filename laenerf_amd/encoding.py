@@ -1,4 +1,5 @@
-"""get_encoder (reference encoding.py:45-82) restricted to the encoders on the hot path."""
+"""get_encoder (reference encoding.py:45-82) on the HIP encoders."""
+from .freqencoder import FreqEncoder
 from .gridencoder import GridEncoder
 from .shencoder import SHEncoder
 
@@ -7,7 +8,9 @@ def get_encoder(encoding, input_dim=3, multires=6, degree=4, num_levels=16, leve
                 log2_hashmap_size=19, desired_resolution=2048, align_corners=False, **kwargs):
     if encoding == "None":
         return (lambda x, **kw: x), input_dim
-    if encoding == "sphere_harmonics":
+    if encoding == "frequency":
+        encoder = FreqEncoder(input_dim=input_dim, degree=multires)           # encoding.py:59-62
+    elif encoding == "sphere_harmonics":
         encoder = SHEncoder(input_dim=input_dim, degree=degree)
     elif encoding in ("hashgrid", "tiledgrid"):
         encoder = GridEncoder(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim,
@@ -15,7 +18,7 @@ def get_encoder(encoding, input_dim=3, multires=6, degree=4, num_levels=16, leve
                               desired_resolution=desired_resolution,
                               gridtype="hash" if encoding == "hashgrid" else "tiled", align_corners=align_corners)
     else:
-        # 'frequency' (freqencoder) and 'ash' are out of scope for the hot path
+        # 'ash' is out of scope for the hot path
         raise NotImplementedError(f"encoding {encoding!r} is not part of the MI355X hot path "
-                                  "[None, sphere_harmonics, hashgrid, tiledgrid]")
+                                  "[None, frequency, sphere_harmonics, hashgrid, tiledgrid]")
     return encoder, encoder.output_dim

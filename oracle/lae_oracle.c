@@ -759,6 +759,43 @@ ORC_API void orc_sh_encode_backward(const float* grad, uint32_t B, uint32_t D, u
 }
 
 /* =====================================================================
+ * freqencoder (K18 / K19; reachable through get_encoder('frequency'), encoding.py:59-62)
+ * ===================================================================== */
+
+/* freqencoder.cu:30-58 (kernel_freq): outputs [B, C], C = D + 2*D*deg; column c < D copies the input, otherwise
+ * col = c / D - 1, d = c % D: sin(x_d * 2^(col/2) + (col % 2) * pi/2).  The reference uses the fast __sinf. */
+ORC_API void orc_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs) {
+    const float HALF_PI = 3.141592653589793f / 2;
+    (void)deg;
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t c = 0; c < C; c++) {
+            const float* in = inputs + (size_t)b * D;
+            float* out = outputs + (size_t)b * C + c;
+            if (c < D) { *out = in[c]; continue; }
+            const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+            const float phase = (float)(col % 2) * HALF_PI;
+            *out = sinf(scalbnf(in[d], (int)freq) + phase);
+        }
+}
+
+/* freqencoder.cu:63-94 (kernel_freq_backward): d/dx of sin is the stored cos column, of cos minus the stored sin */
+ORC_API void orc_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                                      float* grad_inputs) {
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t d = 0; d < D; d++) {
+            const float* g = grad + (size_t)b * C;
+            const float* o = outputs + (size_t)b * C;
+            float r = g[d];
+            g += D; o += D;
+            for (uint32_t f = 0; f < deg; f++) {
+                r += scalbnf(1.0f, (int)f) * (g[d] * o[D + d] - g[D + d] * o[d]);
+                g += 2 * D; o += 2 * D;
+            }
+            grad_inputs[(size_t)b * D + d] = r;
+        }
+}
+
+/* =====================================================================
  * ffmlp: bias-free MLP, fp16 storage, fp32 accumulate.
  * Layout (ffmlp/src/ffmlp.cu:631-634, 377-383): weights = W0[hidden,in] |
  * W1..W_{n-1}[hidden,hidden] | Wout[16,hidden], each [out,in] row-major;

@@ -272,6 +272,25 @@ def sh_encode_backward(grad, dy_dx, degree, D=3):
     return g_in
 
 
+# ------------------------------------------------------------------ freqencoder
+def freq_encode_forward(inputs, degree):
+    """freqencoder/freq.py:15-33: [B, D] -> [B, D + 2*D*degree]"""
+    inputs = _f32(inputs)
+    B, D = inputs.shape
+    C = D + 2 * D * degree
+    out = np.empty((B, C), np.float32)
+    lib().orc_freq_encode_forward(_p(inputs), u32(B), u32(D), u32(degree), u32(C), _p(out))
+    return out
+
+
+def freq_encode_backward(grad, outputs, D, degree):
+    grad, outputs = _f32(grad), _f32(outputs)
+    B, C = grad.shape
+    g_in = np.zeros((B, D), np.float32)
+    lib().orc_freq_encode_backward(_p(grad), _p(outputs), u32(B), u32(D), u32(degree), u32(C), _p(g_in))
+    return g_in
+
+
 # ------------------------------------------------------------------ ffmlp
 def ffmlp_num_params(input_dim, hidden_dim, num_layers, padded_output_dim=16):
     return hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + padded_output_dim)

@@ -184,3 +184,30 @@ def test_sh_all_degrees(O, degree):
         g = rng.standard_normal(ref.shape).astype(np.float32)
         y.backward(T(g))
         assert np.allclose(N(di.grad), O.sh_encode_backward(g, ref_dd, degree), rtol=1e-4, atol=1e-4 * (1 + np.abs(ref_dd).max()))
+
+
+@pytest.mark.parametrize("D,deg", [(3, 6), (3, 10), (2, 4), (5, 1)])
+def test_freq_encoder(O, D, deg):
+    """K18/K19 (freqencoder.cu:30-94) through the C ABI vs the oracle; the kernels use the fast sine like the reference"""
+    from laenerf_amd.encoding import get_encoder
+    from laenerf_amd.freqencoder import FreqEncoder, freq_encode
+    rng = np.random.default_rng(D * 100 + deg)
+    for B in (1, 255, 4097):
+        x = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+        ref = O.freq_encode_forward(x, deg)
+        xi = T(x).requires_grad_()
+        y = freq_encode(xi, deg, D + 2 * D * deg)
+        assert y.shape == ref.shape
+        assert np.array_equal(N(y)[:, :D], x)
+        assert np.abs(N(y) - ref).max() < 2e-6 * 2 ** deg + 2e-6                # fast-sine error grows with the argument
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        y.backward(T(g))
+        rg = O.freq_encode_backward(g, N(y), D, deg)                             # same saved outputs -> same arithmetic
+        assert np.allclose(N(xi.grad), rg, rtol=1e-5, atol=1e-5 * (1 + np.abs(rg).max()))
+    enc, dim = get_encoder("frequency", input_dim=D, multires=deg)
+    assert isinstance(enc, FreqEncoder) and dim == D + 2 * D * deg
+    with torch.autocast("cuda", dtype=torch.float16):                           # forced to fp32 like the reference (freq.py:17)
+        out = enc(T(x).half().reshape(-1, 1, D))
+    assert out.dtype == torch.float32 and out.shape == (x.shape[0], 1, dim)
+    with pytest.raises(RuntimeError):
+        freq_encode(torch.zeros(4, D), deg, D + 2 * D * deg)                     # CPU tensor: no fallback
