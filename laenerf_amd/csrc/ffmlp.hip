@@ -414,11 +414,18 @@ __device__ __forceinline__ void layer64(const half_t* Wl, int ld, const h4 (&in)
         acc[mt] = mfma_ksteps<KT>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g); },
                                   in, f4{0, 0, 0, 0});
 }
+// ReLU + fp16 rounding of a 64-wide layer.  round(max(x, 0)) == max(round(x), 0), so the maximum is taken on the packed
+// halves (v_cvt_pk_f16_f32 + v_pk_max_f16: 2 values per instruction; fmaxf on the floats costs a canonicalising
+// v_max_f32 plus the real one per value -- 160 of this kernel's ~700 VALU instructions per tile)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void relu4(const f4 (&acc)[4], h4 (&out)[4]) {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) out[mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
+    for (int mt = 0; mt < 4; mt++) {
+        h2 lo = {(half_t)acc[mt][0], (half_t)acc[mt][1]}, hi = {(half_t)acc[mt][2], (half_t)acc[mt][3]};
+        lo = __builtin_elementwise_max(lo, h2{(half_t)0.0f, (half_t)0.0f});
+        hi = __builtin_elementwise_max(hi, h2{(half_t)0.0f, (half_t)0.0f});
+        out[mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    }
 }
 __device__ __forceinline__ f4 out16(const half_t* Wl, int ld, const h4 (&in)[4], int c, int g) {
     return mfma_ksteps<4>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + c * ld + kt * 16 + 4 * g); }, in, f4{0, 0, 0, 0});
@@ -426,9 +433,13 @@ __device__ __forceinline__ f4 out16(const half_t* Wl, int ld, const h4 (&in)[4],
 
 // colour-net input fragments of a tile: k-step 0 = SH components 4g..4g+3 of the row's direction,
 // k-step 1 = features 16 + 4g + j = h[1 + 4g + j] (h = fp16 sigma-net output in C/D layout), feature 31 = 0
+__device__ __forceinline__ void color_inputs(float dx, float dy, float dz, const h4& hq, int g, h4 (&cin)[2]);
 __device__ __forceinline__ void color_inputs(const float* __restrict__ dirs, size_t row, const h4& hq, int g, h4 (&cin)[2]) {
+    color_inputs(dirs[3 * row], dirs[3 * row + 1], dirs[3 * row + 2], hq, g, cin);
+}
+__device__ __forceinline__ void color_inputs(float dx, float dy, float dz, const h4& hq, int g, h4 (&cin)[2]) {
     float o[16], gx[1], gy[1], gz[1];
-    sh_eval<4, false>(dirs[3 * row], dirs[3 * row + 1], dirs[3 * row + 2], o, gx, gy, gz);
+    sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float v = g == 0 ? o[j] : g == 1 ? o[4 + j] : g == 2 ? o[8 + j] : o[12 + j];
@@ -1036,10 +1047,22 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    // software pipeline: the inputs of the wave's NEXT tile are requested before the current tile's MFMA chain (two
+    // waves per SIMD do not hide a global-load latency per tile on their own; measured neutral on the 248 k-sample step,
+    // the kernel is VALU-bound: ~700 VALU instructions per 36 MFMAs per tile)
+    h4 xf_n[2] = {};
+    float d_n[3] = {0.f, 0.f, 0.f};
+    auto request = [&](uint32_t t) {
+        const size_t r = (size_t)t * 16 + c;
+        load_enc_frags(enc, r, (size_t)lm_rows, g, level_major, xf_n);
+        if constexpr (COLOR) { d_n[0] = dirs[3 * r]; d_n[1] = dirs[3 * r + 1]; d_n[2] = dirs[3 * r + 2]; }
+    };
+    if (wave0 < n_tiles) request(wave0);
     for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
         const size_t row = (size_t)tile * 16 + c;
-        h4 xf[2];
-        load_enc_frags(enc, row, (size_t)lm_rows, g, level_major, xf);
+        h4 xf[2] = {xf_n[0], xf_n[1]};
+        const float dx = d_n[0], dy = d_n[1], dz = d_n[2];
+        if (tile + nwaves < n_tiles) request(tile + nwaves);
         f4 acc[4];
         h4 a0[4], a1[4];
         layer64<2>(lds + C::S0, C::LDX, xf, c, g, acc); relu4(acc, a0);
@@ -1052,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
         if (g == 0) sigmas[row] = density_scale * expf((float)hq[0]);                    // trunc_exp forward (activation.py:9)
         if constexpr (!COLOR) continue;
         h4 cin[2];
-        color_inputs(dirs, row, hq, g, cin);
+        color_inputs(dx, dy, dz, hq, g, cin);
         layer64<2>(lds + C::C0, C::LDX, cin, c, g, acc); relu4(acc, a0);
         layer64<4>(lds + C::C1, C::LDH, a0, c, g, acc); relu4(acc, a1);
         layer64<4>(lds + C::C2, C::LDH, a1, c, g, acc); relu4(acc, a0);

@@ -92,7 +92,8 @@ def test_frame_loop_row_budget():
         b = r.render_eval(o, d, bg_color=1, frame_loop=True, want_stats=True, row_budget=4 * 6000)
         c = r.render_eval(o, d, bg_color=1, frame_loop=True, want_stats=True, row_budget=3)      # below N: clamped to N
     assert b["stats"]["iterations"] < a["stats"]["iterations"]
-    assert c["stats"] == a["stats"] and np.array_equal(N(c["image"]), N(a["image"]))
+    assert all(c["stats"][k] == a["stats"][k] for k in ("iterations", "rows"))      # launched iterations depend on host timing
+    assert np.array_equal(N(c["image"]), N(a["image"]))
     assert np.abs(N(a["image"]) - N(b["image"])).max() < 1e-5
     assert np.abs(N(a["weights_sum"]) - N(b["weights_sum"])).max() < 1e-5
     hit = N(a["weights_sum"]) > 0
