@@ -148,6 +148,27 @@ def eval_frame(net, r, dev, H=800, W=800):
             "note": "800x800 inference render, T_thresh 1e-4, device-resident loop (lookahead marcher on a side stream)"}
 
 
+def grid_update(dev):
+    """occupancy-grid maintenance (update_extra_state, renderer.py:555-649; every 16 train steps, nerf/utils.py:1465) on a
+    separate model of the same architecture: full sweeps (first 16 calls: 128^3 cells) and partial sweeps afterwards"""
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(3)
+    net = NeRFNetwork(bound=1).to(dev)
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    r = NeRFRenderer(net, bound=1, density_thresh=10).to(dev)
+    ts = []
+    for it in range(24):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.autocast("cuda", dtype=torch.float16):
+            r.update_extra_state()
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    full, part = sorted(ts[2:16])[7], sorted(ts[17:])[3]
+    return {"full_sweep_ms": round(full, 3), "partial_sweep_ms": round(part, 3), "every_steps": 16,
+            "amortised_us_per_step": round(part / 16 * 1e3, 1),
+            "note": "not inside `value`: the reference runs it between train steps (nerf/utils.py:1465)"}
+
+
 def style_step(dev, P=100000, steps=30):
     """configs[4]: one optimisation step of LAENeRF's palette network (train_LAENeRF_step, nerf/utils.py:980-1043, point-wise
     losses) on P region-masked points: hash-grid encode -> weight / offset MLPs -> palette recomposition -> MSE + weight +
@@ -237,8 +258,6 @@ def main():
         from laenerf_amd.optim import FusedAdam
         opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     fused_loss = not args.torch_loss and not args.torch_optimizer
-    if fused_loss:
-        from laenerf_amd.losses import mse_loss_scaled
     n_batches = 16
     batches = []
     for b in range(n_batches):
@@ -249,10 +268,11 @@ def main():
 
     def step_body(o, d, gt):
         with torch.autocast("cuda", dtype=torch.float16):
-            res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
-            if fused_loss:                                  # criterion + GradScaler.scale in one kernel (losses.py)
-                loss = mse_loss_scaled(res["image"], gt, scaler)
+            if fused_loss:                                  # criterion + GradScaler.scale inside the compositing op
+                res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024, gt=gt, scaler=scaler)
+                loss = res["loss"]
             else:
+                res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
                 loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], gt))
         loss.backward()
         if not args.no_optimizer:
@@ -331,9 +351,12 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=g_rest[0].pool() if g_rest else None):
                 with torch.autocast("cuda", dtype=torch.float16):
-                    res = r.shade_train(marched[b], bg_color=1)
-                    loss = mse_loss_scaled(res["image"], batches[b][2], scaler) if fused_loss else \
-                        scaler.scale(torch.nn.functional.mse_loss(res["image"], batches[b][2]))
+                    if fused_loss:
+                        res = r.shade_train(marched[b], bg_color=1, gt=batches[b][2], scaler=scaler)
+                        loss = res["loss"]
+                    else:
+                        res = r.shade_train(marched[b], bg_color=1)
+                        loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], batches[b][2]))
                 loss.backward()
                 opt.step()
                 n_graph_samples.append(res["n_samples"])
@@ -437,6 +460,7 @@ def main():
             out["eval_frame"] = eval_frame(net, r, dev)        # the "ms/frame" half of BASELINE.json's metric (not `value`)
         if world == 1 and not args.no_style:
             out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
+            out["grid_update"] = grid_update(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
         print(json.dumps(out), flush=True)

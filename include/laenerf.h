@@ -136,6 +136,15 @@ LAE_API int lae_composite_rays_train_backward_blend(const float* grad_weights_su
                                             const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                             float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
                                             const uint32_t* rows_end, float* grad_sigmas, float* grad_rgbs, void* stream);
+/* same, for a criterion fused in front of it: grad_weights_sum may be NULL (zero) and every incoming gradient is
+ * multiplied by the device scalar *grad_scale when grad_scale != NULL (the upstream d(loss), so no elementwise
+ * multiplication / zero-fill kernels are needed between the loss and this call). */
+LAE_API int lae_composite_rays_train_backward_blend_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                               const float* rgbs, const float* deltas, const int32_t* rays,
+                                               const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                               float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
+                                               const uint32_t* rows_end, const float* grad_scale, float* grad_sigmas,
+                                               float* grad_rgbs, void* stream);
 
 /* raymarching.cu:929-936 */
 LAE_API int lae_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,

@@ -143,15 +143,16 @@ class _RayMarching:
 
     @staticmethod
     def composite_rays_train_backward_blend(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M,
-                                            N, T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs):
+                                            N, T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs, grad_scale=None):
+        """grad_scale (MI355X extension): device scalar multiplied into the incoming gradients; grad_weights_sum may be None"""
         ts = (grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_sigmas,
-              grad_rgbs)
+              grad_rgbs, grad_scale)
         need_cuda(*ts); need_contig(*ts)
-        _need_f32(grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, bg_rays, grad_sigmas, grad_rgbs)
-        check(_lib.load().lae_composite_rays_train_backward_blend(
+        _need_f32(grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, bg_rays, grad_sigmas, grad_rgbs, grad_scale)
+        check(_lib.load().lae_composite_rays_train_backward_blend_ex(
             ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(weights_sum),
-            ptr(image), M, N, T_thresh, ptr(bg_rays), bg[0], bg[1], bg[2], ptr(rows_end), ptr(grad_sigmas), ptr(grad_rgbs),
-            stream()), "composite_rays_train_backward_blend")
+            ptr(image), M, N, T_thresh, ptr(bg_rays), bg[0], bg[1], bg[2], ptr(rows_end), ptr(grad_scale), ptr(grad_sigmas),
+            ptr(grad_rgbs), stream()), "composite_rays_train_backward_blend")
 
     @staticmethod
     def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,

@@ -15,6 +15,7 @@
 // chain through all layers in registers: no LDS, no shuffles.  Accumulation is
 // fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
 #include <algorithm>
+#include <stdlib.h>
 #include "lae_common.h"
 
 namespace {
@@ -1167,6 +1168,12 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
 }  // namespace
 
 // frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], live rows = *n_rows_dev
+static uint32_t head_blocks_per_cu() {
+    static int v = 0;
+    if (v == 0) { const char* e = getenv("LAE_HEAD_BLOCKS_PER_CU"); v = e ? atoi(e) : 2; if (v < 1 || v > 8) v = 2; }
+    return (uint32_t)v;
+}
+
 int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
                                  uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
                                  float* rgbs, hipStream_t stream) {
@@ -1180,7 +1187,7 @@ int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void*
         attr_set = true;
     }
     const uint32_t n_tiles = M_cap / 16, launch_tiles = lae::cdiv(std::min(M_launch, M_cap), 16);
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(launch_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(launch_tiles, 4), (uint32_t)lae::num_cus() * head_blocks_per_cu()));
     k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, stream>>>((const half_t*)enc, dirs, (const half_t*)sigma_weights,
                                                             (const half_t*)color_weights, n_tiles, density_scale, nullptr, sigmas,
                                                             rgbs, 1, n_rows_dev, M_cap);
@@ -1261,7 +1268,7 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
         attr_set = true;
     }
     const uint32_t n_tiles = M / 16;
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * head_blocks_per_cu()));
     k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
         (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
         (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M);

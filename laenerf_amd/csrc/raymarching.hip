@@ -525,7 +525,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
 // (b) EVERY row of grad_sigmas / grad_rgbs in [0, M) is written (zeros for samples after the early stop and for the
 // rows [rows_end, M) no ray owns), so the caller allocates them uninitialised.  Needs the contiguous ray-id-order
 // layout lae_march_rays_train produces.
-struct Dense { const float* bg_rays; float bg[3]; const uint32_t* rows_end; };
+struct Dense { const float* bg_rays; float bg[3]; const uint32_t* rows_end; const float* grad_scale; };   // grad_scale: device scalar or NULL
 
 template <bool DENSE>
 __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
@@ -544,9 +544,13 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
     const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
     if (num_steps == 0 || offset + num_steps > M) return;                   // :624
-    float gws = grad_ws[index];
-    const float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
+    float gws = grad_ws ? grad_ws[index] : 0.0f;
+    float g0 = grad_image[3 * (size_t)index], g1 = grad_image[3 * (size_t)index + 1], g2 = grad_image[3 * (size_t)index + 2];
     if constexpr (DENSE) {
+        if (dn.grad_scale) {                               // fused criterion: upstream d(loss) arrives as a device scalar
+            const float gs = dn.grad_scale[0];
+            g0 *= gs; g1 *= gs; g2 *= gs; gws *= gs;
+        }
         const float* bg = dn.bg_rays ? dn.bg_rays + 3 * (size_t)index : dn.bg;
         gws = gws - ((g0 * bg[0] + g1 * bg[1]) + g2 * bg[2]);
     }
@@ -1158,19 +1162,30 @@ int lae_composite_rays_train_forward_blend(const float* sigmas, const float* rgb
     return lae::check_launch("composite_rays_train_forward_blend");
 }
 
+int lae_composite_rays_train_backward_blend_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                               const float* rgbs, const float* deltas, const int32_t* rays,
+                                               const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                               float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
+                                               const uint32_t* rows_end, const float* grad_scale, float* grad_sigmas,
+                                               float* grad_rgbs, void* stream) {
+    if (N == 0 || M == 0) return LAE_OK;
+    if (!grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs || !rows_end)
+        return LAE_ENULL;                                   // grad_weights_sum may be NULL (= zero)
+    const Dense dn{bg_rays, {bg_r, bg_g, bg_b}, rows_end, grad_scale};
+    k_composite_train_bwd<true><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
+        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, dn);
+    return lae::check_launch("composite_rays_train_backward_blend");
+}
+
 int lae_composite_rays_train_backward_blend(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
                                             const float* rgbs, const float* deltas, const int32_t* rays,
                                             const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                             float T_thresh, const float* bg_rays, float bg_r, float bg_g, float bg_b,
                                             const uint32_t* rows_end, float* grad_sigmas, float* grad_rgbs, void* stream) {
     if (N == 0 || M == 0) return LAE_OK;
-    if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image ||
-        !grad_sigmas || !grad_rgbs || !rows_end)
-        return LAE_ENULL;
-    const Dense dn{bg_rays, {bg_r, bg_g, bg_b}, rows_end};
-    k_composite_train_bwd<true><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(
-        grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, dn);
-    return lae::check_launch("composite_rays_train_backward_blend");
+    if (!grad_weights_sum) return LAE_ENULL;
+    return lae_composite_rays_train_backward_blend_ex(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                      T_thresh, bg_rays, bg_r, bg_g, bg_b, rows_end, nullptr, grad_sigmas, grad_rgbs, stream);
 }
 
 int lae_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,

@@ -14,7 +14,7 @@ from ..backend import raymarching_backend as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
-           "compact_rays_alive", "render_frame", "composite_rays_train_blend", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
+           "compact_rays_alive", "render_frame", "composite_rays_train_blend", "composite_rays_train_blend_mse", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
 
 
 def _gpu(t):
@@ -218,15 +218,10 @@ class _composite_rays_train_blend(Function):
         return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None
 
 
-def composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars, bg_color=1, T_thresh=1e-4):
-    """-> weights_sum [N], depth normalised to [0,1] [N], image blended over bg_color [N,3]
-    bg_color: number, 3 numbers / tensor of 3, or a per-ray [N,3] tensor (renderer.py:313-321)"""
-    rows_end = getattr(rays, "rows_end", None)
-    if rows_end is None:
-        raise RuntimeError("composite_rays_train_blend: `rays` must be the tensor returned by laenerf_amd march_rays_train")
+def _bg_args(bg_color, device):
     bg_rays, bg = None, (0.0, 0.0, 0.0)
     if torch.is_tensor(bg_color) and bg_color.numel() > 3:
-        bg_rays = bg_color.to(sigmas.device, torch.float32).reshape(-1, 3).contiguous()
+        bg_rays = bg_color.to(device, torch.float32).reshape(-1, 3).contiguous()
     elif torch.is_tensor(bg_color):
         v = [float(x) for x in bg_color.reshape(-1).tolist()]
         bg = tuple(v * 3 if len(v) == 1 else v)
@@ -234,7 +229,76 @@ def composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars, bg_color
         bg = (float(bg_color),) * 3
     else:
         bg = tuple(float(x) for x in bg_color)
+    return bg_rays, bg
+
+
+def composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars, bg_color=1, T_thresh=1e-4):
+    """-> weights_sum [N], depth normalised to [0,1] [N], image blended over bg_color [N,3]
+    bg_color: number, 3 numbers / tensor of 3, or a per-ray [N,3] tensor (renderer.py:313-321)"""
+    rows_end = getattr(rays, "rows_end", None)
+    if rows_end is None:
+        raise RuntimeError("composite_rays_train_blend: `rays` must be the tensor returned by laenerf_amd march_rays_train")
+    bg_rays, bg = _bg_args(bg_color, sigmas.device)
     return _composite_rays_train_blend.apply(sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh)
+
+
+class _composite_rays_train_blend_mse(Function):
+    """composite_rays_train_blend + the trainer's criterion and loss scaling (`MSELoss(pred_rgb, gt).mean()` then
+    `scaler.scale(loss)`, nerf/utils.py train_step) as ONE autograd node: forward = compositing kernel + the fused MSE
+    kernel (loss, scaled loss, d(scaled loss)/d(pred)); backward = the compositing backward kernel alone, which takes the
+    upstream gradient as a device scalar.  Between the loss and the sample gradients torch otherwise runs a ones-fill, an
+    elementwise multiplication, a zero-fill for the unused weights_sum gradient and two copies (~25 us per step)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh, target, scale):
+        from .. import _lib
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        dev, dt = sigmas.device, sigmas.dtype
+        weights_sum, depth, image = (torch.empty(N, dtype=dt, device=dev), torch.empty(N, dtype=dt, device=dev),
+                                     torch.empty(N, 3, dtype=dt, device=dev))
+        depth_out, image_out = torch.empty(N, dtype=dt, device=dev), torch.empty(N, 3, dtype=dt, device=dev)
+        _backend.composite_rays_train_forward_blend(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears.contiguous(),
+                                                    fars.contiguous(), bg_rays, bg, weights_sum, depth, image, depth_out, image_out)
+        target = target.float().contiguous()
+        if target.shape != image_out.shape:
+            raise RuntimeError("composite_rays_train_blend_mse: target must be [N,3]")
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        grad_image = torch.empty_like(image_out)
+        _lib.check(_lib.load().lae_mse_loss_forward(image_out.data_ptr(), target.data_ptr(), image_out.numel(), _lib.ptr(scale),
+                                                    out.data_ptr(), grad_image.data_ptr(), _lib.stream()), "mse_loss_forward")
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image)
+        ctx.dims = [M, N, T_thresh, bg]
+        ctx.mark_non_differentiable(weights_sum, depth_out, image_out, out)
+        return out[0], weights_sum, depth_out, image_out, out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_loss, *_):
+        sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image = ctx.saved_tensors
+        M, N, T_thresh, bg = ctx.dims
+        grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
+        _backend.composite_rays_train_backward_blend(None, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                     T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs,
+                                                     grad_scale=grad_loss.float().reshape(1).contiguous())
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None
+
+
+def composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, target, bg_color=1, T_thresh=1e-4, scaler=None):
+    """-> (loss, weights_sum, depth, image): loss = MSE(image, target) times the loss scale of `scaler` (a FusedAdam, a
+    1-element fp32 cuda tensor, or None); `loss.unscaled` holds the plain MSE.  Only `loss` carries a gradient."""
+    rows_end = getattr(rays, "rows_end", None)
+    if rows_end is None:
+        raise RuntimeError("composite_rays_train_blend_mse: `rays` must be the tensor returned by laenerf_amd march_rays_train")
+    bg_rays, bg = _bg_args(bg_color, sigmas.device)
+    scale = None
+    if scaler is not None:
+        scale = scaler if torch.is_tensor(scaler) else (scaler._scale_view[:1] if scaler.use_scaler else None)
+    loss, weights_sum, depth, image, both = _composite_rays_train_blend_mse.apply(sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg,
+                                                                                  rows_end, T_thresh, target, scale)
+    loss.unscaled = both[1]
+    return loss, weights_sum, depth, image
 
 
 def _infer_buffers(n_alive, n_step, align, dt, dev):

@@ -188,9 +188,9 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ training render (renderer.py:285-334)
     def render_train(self, rays_o, rays_d, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024,
-                     T_thresh=1e-4, dens_grid=None):
+                     T_thresh=1e-4, dens_grid=None, gt=None, scaler=None):
         marched = self.march_train(rays_o, rays_d, perturb, force_all_rays, dt_gamma, max_steps, dens_grid)
-        return self.shade_train(marched, bg_color, T_thresh)
+        return self.shade_train(marched, bg_color, T_thresh, gt, scaler)
 
     def march_train(self, rays_o, rays_d, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, dens_grid=None,
                     plan_backward=False):
@@ -213,21 +213,30 @@ class NeRFRenderer(nn.Module):
             return xyzs, dirs, deltas, rays, nears, fars, self.model.plan_backward(xyzs)
         return xyzs, dirs, deltas, rays, nears, fars
 
-    def shade_train(self, marched, bg_color=1, T_thresh=1e-4):
-        """second half: network on the samples, compositing, background blend, depth normalisation (renderer.py:313-334)"""
+    def shade_train(self, marched, bg_color=1, T_thresh=1e-4, gt=None, scaler=None):
+        """second half: network on the samples, compositing, background blend, depth normalisation (renderer.py:313-334).
+        gt [N,3] (optional, MI355X-native): also evaluate the trainer's criterion MSE(image, gt) (scaled by `scaler`'s
+        loss scale) inside the compositing op -> result["loss"]; call loss.backward() on it."""
         xyzs, dirs, deltas, rays, nears, fars = marched[:6]
         plan = marched[6] if len(marched) > 6 else None
         sigmas, rgbs = self.model(xyzs, dirs, plan=plan) if plan is not None else self.model(xyzs, dirs)
         if self.density_scale != 1:
             sigmas = self.density_scale * sigmas
-        if self.fused_post_ops:      # composite + bg blend + depth normalisation in one kernel, gradients without zero fills
+        loss = None
+        if self.fused_post_ops and gt is not None:
+            loss, weights_sum, depth, image = raymarching.composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars,
+                                                                                        gt, bg_color, T_thresh, scaler)
+        elif self.fused_post_ops:    # composite + bg blend + depth normalisation in one kernel, gradients without zero fills
             weights_sum, depth, image = raymarching.composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars,
                                                                                bg_color, T_thresh)
         else:                        # operator-by-operator, as renderer.py:318-325
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        return {"image": image, "depth": depth, "weights_sum": weights_sum, "nears": nears, "n_samples": xyzs.shape[0]}
+        res = {"image": image, "depth": depth, "weights_sum": weights_sum, "nears": nears, "n_samples": xyzs.shape[0]}
+        if loss is not None:
+            res["loss"] = loss
+        return res
 
     # ------------------------------------------------------------------ inference render (renderer.py:335-387)
     def _frame_loop_ok(self, rays_o):

@@ -179,3 +179,42 @@ def test_planned_grid_backward_equals_default():
     assert torch.equal(ta[lo:], tb[lo:])
     # coarser levels merge their sub-buckets with fp16 atomics (order dependent at the last bit, with or without a plan)
     assert (ta[:lo] - tb[:lo]).abs().max().item() <= 2e-3 * ta[:lo].abs().max().item()
+
+
+def test_fused_criterion_equals_separate_loss():
+    """shade_train(gt=...): MSE + loss scale inside the compositing node == composite_rays_train_blend followed by
+    mse_loss_scaled (same kernels, gradient scale applied inside the compositing backward instead of a torch multiply)"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.losses import mse_loss_scaled
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(5)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=19).to(DEV)
+    net.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    r = NeRFRenderer(net, bound=1).to(DEV)
+    r.density_bitfield = T(S.pack_bits_np(S.sphere_density_grid(), 10.0))
+    o, d = S.lego_like_rays(1000, seed=6)
+    o, d = T(o), T(d)
+    gt = torch.rand(1000, 3, device=DEV)
+    scale = torch.tensor([512.0], device=DEV)
+    net.train()
+    out = []
+    for fused in (False, True):
+        net.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            if fused:
+                res = r.render_train(o, d, bg_color=1, perturb=False, gt=gt, scaler=scale)
+                loss = res["loss"]
+            else:
+                res = r.render_train(o, d, bg_color=1, perturb=False)
+                loss = mse_loss_scaled(res["image"], gt, scale)
+        (loss * 2.0).backward()                               # upstream gradient != 1 on purpose
+        out.append((loss.detach().clone(), loss.unscaled.clone(), res["image"].detach().clone(),
+                    [p.grad.clone() for p in (net.sigma_net.weights, net.color_net.weights, net.encoder.embeddings)]))
+    (l0, u0, i0, g0), (l1, u1, i1, g1) = out
+    assert torch.equal(l0, l1) and torch.equal(u0, u1) and torch.equal(i0, i1)
+    assert l0.item() == pytest.approx(512.0 * u0.item(), rel=1e-6)
+    assert torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1])
+    lo = int(net.encoder.offsets[4].item())
+    assert torch.equal(g0[2][lo:], g1[2][lo:])
+    assert (g0[2][:lo] - g1[2][:lo]).abs().max().item() <= 2e-3 * g0[2][:lo].abs().max().item()
