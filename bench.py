@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--no-style", action="store_true", help="skip the LAENeRF palette-network step timing (extra field style_step)")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
+    p.add_argument("--workload", choices=["train", "frame1080"], default="train",
+                   help="train (default): the BASELINE configs[1] train step.  frame1080: configs[3]-style whole-frame render, "
+                        "1920x1080 rays sharded over the ranks in 128-ray tiles, one all-gather (RCCL) per frame; a step is a frame")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
     p.add_argument("--no-pipeline", action="store_true",
                    help="one graph per step; default: the march of step k+1 (no weight dependence) is its own graph, replayed on a "
@@ -148,6 +151,59 @@ def eval_frame(net, r, dev, H=800, W=800):
             "note": "800x800 inference render, T_thresh 1e-4, device-resident loop (lookahead marcher on a side stream)"}
 
 
+def frame_workload(args, world, rank, dev, backend_name):
+    """configs[3]: full-frame inference render, rays sharded across the ranks (laenerf_amd/dist.py), one all-gather of the
+    [n/W, 5] fp32 block per frame.  Every rank holds the same (random-init, synthetic-occupancy) model; a step = a frame."""
+    import torch.distributed as dist
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.dist import render_frame_sharded
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(1234)                                   # identical replicas
+    net = NeRFNetwork(bound=1).to(dev).eval()
+    r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev).eval()
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    H, W = 1080, 1920
+    o, d = S.frame_rays(H, W, focal=1111.1 * H / 800)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+
+    def render(ro, rd):
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            return r.render_eval(ro, rd, bg_color=1, max_steps=1024)
+
+    def frame():
+        return render_frame_sharded(render, o, d, rank, world)
+    for _ in range(max(args.warmup, 2)):
+        res = frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        print(json.dumps({
+            "metric": "Mrays/s, 1920x1080 whole-frame inference render", "value": round(H * W * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
+            "config": {"workload": "configs[3]-style: 1920x1080 rays of one view, L=16 T=2^19 hash grid + 2x64 / 3x64 ffmlp, cascade 1, "
+                                   "analytic occupancy, device-resident inference loop per rank",
+                       "rays_per_frame": H * W, "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
+                       "parallelism": f"rays in 128-ray tiles dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def grid_update(dev):
     """occupancy-grid maintenance (update_extra_state, renderer.py:555-649; every 16 train steps, nerf/utils.py:1465) on a
     separate model of the same architecture: full sweeps (first 16 calls: 128^3 cells) and partial sweeps afterwards"""
@@ -244,6 +300,11 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
+
+    if args.workload == "frame1080":
+        if args.steps == 200 and args.warmup == 40:            # the train defaults are too long for whole frames
+            args.steps, args.warmup = 20, 3
+        return frame_workload(args, world, rank, dev, backend_name)
 
     torch.manual_seed(1234 + rank)
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64

@@ -28,8 +28,13 @@ def gather_frame(local_block, n_rays, rank, world_size, tile=TILE, group=None):
     if world_size == 1:
         gathered = [local_block]
     else:
+        dev = local_block.device
+        if local_block.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
+            local_block = local_block.cpu()
         gathered = [torch.empty_like(local_block) for _ in range(world_size)]
         dist.all_gather(gathered, local_block, group=group)
+        gathered = [g.to(dev) for g in gathered]
+        local_block = local_block.to(dev)
     out = torch.zeros(n_rays, local_block.shape[1], dtype=local_block.dtype, device=local_block.device)
     for r in range(world_size):
         idx = shard_indices(n_rays, r, world_size, tile).to(local_block.device)
