@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--workload", choices=["train", "frame1080"], default="train",
                    help="train (default): the BASELINE configs[1] train step.  frame1080: configs[3]-style whole-frame render, "
                         "1920x1080 rays sharded over the ranks in 128-ray tiles, one all-gather (RCCL) per frame; a step is a frame")
+    p.add_argument("--dp", action="store_true",
+                   help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
+                        "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
     p.add_argument("--no-pipeline", action="store_true",
                    help="one graph per step; default: the march of step k+1 (no weight dependence) is its own graph, replayed on a "
@@ -336,13 +339,19 @@ def main():
                 res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
                 loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], gt))
         loss.backward()
-        if not args.no_optimizer:
+        if not args.no_optimizer and not args.dp:
             if args.torch_optimizer:
                 scaler.step(opt)
                 scaler.update()
             else:
                 opt.step()
         return res["n_samples"]
+
+    def dp_tail():                                          # --dp: outside the captured graph (a collective + 3 launches)
+        if world > 1:
+            from laenerf_amd.dist import allreduce_gradients
+            allreduce_gradients(opt, world)
+        opt.step()
 
     def zero_grad():
         if args.torch_optimizer:
@@ -353,7 +362,10 @@ def main():
     def step(i):
         o, d, gt = batches[i % n_batches]
         zero_grad()
-        return step_body(o, d, gt)
+        n = step_body(o, d, gt)
+        if args.dp:
+            dp_tail()
+        return n
 
     # warm-up: the first 16 steps run in the reference's "mean_count <= 0" mode (sized by a D2H read), then the
     # running mean is refreshed every 16 steps exactly like update_extra_state does (renderer.py:644-647)
@@ -371,7 +383,9 @@ def main():
     # One graph per resident ray batch (the batches already live in HBM, so a replay reads them in place); the graphs
     # share one memory pool because they never run concurrently.
     graph = None
-    pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer
+    if args.dp and (args.torch_optimizer or args.no_optimizer):
+        raise SystemExit("--dp needs the FusedAdam path")
+    pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer and not args.dp
     if not args.no_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -393,6 +407,8 @@ def main():
 
         def step(i):                                        # noqa: F811  (replaces the eager step)
             graphs[i % n_batches].replay()
+            if args.dp:
+                dp_tail()
             return n_graph_samples[i % n_batches]
         for i in range(5):
             step(i)
@@ -508,7 +524,8 @@ def main():
                        "optimizer_in_timed_region": not args.no_optimizer,
                        "hip_graph_replay": bool(graph),
                        "march_pipelined_on_side_stream": bool(pipelined),
-                       "parallelism": f"{world} independent ray-batch replicas (no data-path collective)"},
+                       "parallelism": (f"{world} data-parallel ranks, one flat gradient all-reduce per dtype per step" if args.dp else
+                                       f"{world} independent ray-batch replicas (no data-path collective)")},
             "roofline": {"kernel": "k_grid_fwd (hash-grid encode forward, fp16 table)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

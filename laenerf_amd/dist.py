@@ -52,3 +52,59 @@ def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None
     block = torch.cat([res["image"].float(), res["depth"].float()[:, None], res["weights_sum"].float()[:, None]], dim=1)
     full = gather_frame(block, n, rank, world_size, group=group)
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data-parallel training.  No configuration of the north star exchanges gradients (training is
+# replicas-only there); this is the optional DP mode: every rank marches / shades its own ray batch, the gradients are
+# averaged, every rank applies the same Adam step.  The payload is dominated by the hash table's gradient (12.2 M
+# parameters = 24.5 MB in the fp16 accumulator FusedAdam owns), so it goes out as ONE flat all-reduce per dtype: on
+# 8 MI355X, RCCL runs a ring/tree over the xGMI links (7 x ~153 GB/s per GPU): 2 * 7/8 * 24.5 MB / link rate ~ 0.3 ms,
+# i.e. comparable to the 0.5 ms step itself -- which is why the default bench mode keeps independent replicas.
+def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20):
+    """in place: every tensor becomes the mean over the ranks.  Tensors are packed by dtype into flat buckets of at most
+    `bucket_bytes` (one all-reduce each); fp16 payloads are reduced in fp16 (sum of W values scaled by 1/W first, so the
+    reduction cannot overflow where the local gradients did not)."""
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    if world_size == 1:
+        return tensors
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), ts in by_dtype.items():
+        bucket, size = [], 0
+        buckets = []
+        for t in ts:
+            nbytes = t.numel() * t.element_size()
+            if bucket and size + nbytes > bucket_bytes:
+                buckets.append(bucket); bucket, size = [], 0
+            bucket.append(t); size += nbytes
+        if bucket:
+            buckets.append(bucket)
+        for b in buckets:
+            flat = torch.cat([t.reshape(-1) for t in b]) if len(b) > 1 else b[0].reshape(-1)
+            flat.mul_(1.0 / world_size)
+            rehearsal = flat.is_cuda and dist.get_backend(group) == "gloo"        # CPU rehearsal of the RCCL path
+            buf = flat.cpu() if rehearsal else flat
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            if rehearsal:
+                flat.copy_(buf)
+            if len(b) > 1:
+                off = 0
+                for t in b:
+                    t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+    return tensors
+
+
+def allreduce_gradients(optimizer, world_size=None, group=None):
+    """average the gradients a `laenerf_amd.optim.FusedAdam` is about to consume (fp16 accumulators of the tables it owns,
+    fp32 `.grad` of the rest) over the ranks; call between `loss.backward()` and `optimizer.step()`"""
+    grads = []
+    for p, _, _, shadow, _ in optimizer.items:
+        if shadow is not None:
+            if p.grad is not None:                           # folded into the accumulator, like FusedAdam._grad does
+                shadow.grad_half.add_(p.grad.to(torch.half)); p.grad = None
+            grads.append(shadow.grad_half)
+        elif p.grad is not None:
+            grads.append(p.grad)
+    return allreduce_mean_(grads, world_size, group)

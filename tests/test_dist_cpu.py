@@ -47,3 +47,40 @@ def test_shard_indices_partition():
         assert len({shard_indices(n, r, w).numel() for r in range(w)}) == 1      # equal shard sizes (all-gather)
         real = all_idx[all_idx >= 0]
         assert real.numel() == n and torch.equal(torch.sort(real).values, torch.arange(n))
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from laenerf_amd.dist import allreduce_mean_
+    g = torch.Generator().manual_seed(100 + rank)
+    ts = [torch.randn(1000, 2, generator=g).half(), torch.randn(7168, generator=g).half(), torch.randn(11264, generator=g).half(),
+          torch.randn(8, 3, generator=g), torch.randn(5, generator=g)]
+    every = [[torch.randn(1000, 2, generator=torch.Generator().manual_seed(100 + r)).half()] for r in range(world)]
+    mine = [t.clone() for t in ts]
+    allreduce_mean_(ts, bucket_bytes=20000)                   # small buckets: the fp16 tensors split into two all-reduces
+    ok = True
+    # reference: mean over ranks of the first tensor, computed locally from the same seeds
+    ref0 = sum(e[0].float() / world for e in every)
+    ok &= bool(torch.allclose(ts[0].float(), ref0, atol=2e-3))
+    ok &= all(t.dtype == m.dtype and t.shape == m.shape for t, m in zip(ts, mine))
+    # every rank must end with identical tensors: compare through a second all-reduce of the difference to rank 0's copy
+    for t in ts:
+        ref = t.clone(); dist.broadcast(ref, src=0)
+        ok &= bool(torch.equal(ref, t))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_allreduce_gloo():
+    world = 2
+    port = 29500 + (os.getpid() + 777) % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0] and ret[1]
