@@ -1,21 +1,28 @@
-"""trunc_exp (reference activation.py:5-17): exp forward in fp32, gradient exp(clamp(x, -15, 15))."""
+"""`trunc_exp`, the density activation of the NeRF networks (reference activation.py:5-17).
+
+Forward: exp in fp32 whatever the autocast state.  Backward: the incoming gradient times exp of the input clamped to
+[-15, 15], so one exploding logit cannot turn the whole step into inf.  (The fused NeRF head applies the same rule inside
+its kernels, csrc/ffmlp.hip; this autograd function serves the operator-by-operator path.)
+"""
 import torch
-from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+_CLAMP = 15.0
 
-class _trunc_exp(Function):
+
+class TruncExp(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+    def forward(ctx, logits):
+        ctx.save_for_backward(logits)
+        return logits.exp()
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return g * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, grad_out):
+        logits, = ctx.saved_tensors
+        return grad_out * logits.clamp(min=-_CLAMP, max=_CLAMP).exp()
 
 
-trunc_exp = _trunc_exp.apply
+def trunc_exp(x):
+    return TruncExp.apply(x)

@@ -63,28 +63,42 @@ def convert_activation(act):
 
 
 class FFMLP(nn.Module):
-    """ffmlp.py:99-168: bias-free MLP, `weights` is one flat fp32 parameter laid out
-    W0[hidden,in] | W1..[hidden,hidden] | Wout[16,hidden]."""
+    """The reference's fully fused MLP module (ffmlp.py:99-168) on the MFMA kernels.
+
+    `weights`: ONE flat fp32 parameter, layers back to back, each stored [out, in] row-major:
+    W0 [hidden, input_dim] | (num_layers - 1) x W [hidden, hidden] | W_out [16, hidden] (output rows beyond output_dim are
+    padding).  No biases.  Same constructor constraints as the reference (AssertionError when violated)."""
+
+    HIDDEN_CHOICES = (16, 32, 64, 128, 256)
 
     def __init__(self, input_dim, output_dim, hidden_dim, num_layers, activation="relu"):
         super().__init__()
-        self.input_dim = input_dim
-        self.output_dim = output_dim
-        self.hidden_dim = hidden_dim
-        self.num_layers = num_layers
+        assert hidden_dim in self.HIDDEN_CHOICES, f"FFMLP: hidden_dim {hidden_dim} not in {self.HIDDEN_CHOICES}"
+        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP: input_dim {input_dim} is not a positive multiple of 16"
+        assert output_dim <= 16, f"FFMLP: output_dim {output_dim} exceeds the 16-wide output tile"
+        assert num_layers >= 2, f"FFMLP: num_layers {num_layers} < 2 (at least three matrix products)"
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.hidden_dim, self.num_layers = hidden_dim, num_layers
         self.activation = convert_activation(activation)
         self.output_activation = convert_activation("none")
         self.tensorcore_width = 16
-        assert hidden_dim in [16, 32, 64, 128, 256], f"FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got {hidden_dim}"
-        assert input_dim > 0 and input_dim % 16 == 0, f"FFMLP input_dim should be 16 * m (m  > 0), but got {input_dim}"
-        assert output_dim <= 16, f"FFMLP current only supports output dim <= 16, but got {output_dim}"
-        assert num_layers >= 2, f"FFMLP num_layers should be larger than 2 (3 matmuls), but got {num_layers}"
-        self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
-        self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
+        self.padded_output_dim = 16 * math.ceil(output_dim / 16)
+        self.num_parameters = hidden_dim * (input_dim + (num_layers - 1) * hidden_dim + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
         self.shadow = None                                      # fp16 weights + gradient buffer once a FusedAdam owns them
         self.reset_parameters()
-        _backend.allocate_splitk(self.num_layers + 1)
+        _backend.allocate_splitk(num_layers + 1)                # accepted for interface parity (ffmlp.py:126)
+
+    def extra_repr(self):
+        return (f"input_dim={self.input_dim}, output_dim={self.output_dim}, hidden_dim={self.hidden_dim}, "
+                f"num_layers={self.num_layers}, activation={self.activation}")
+
+    def reset_parameters(self):
+        """U(-sqrt(3/hidden), +sqrt(3/hidden)) from generator seed 42, like the reference (ffmlp.py:141-144)"""
+        torch.manual_seed(42)
+        bound = math.sqrt(3.0 / self.hidden_dim)
+        with torch.no_grad():
+            self.weights.uniform_(-bound, bound)
 
     def attach_shadow(self):
         from ..gridencoder.grid import TableShadow
@@ -96,26 +110,16 @@ class FFMLP(nn.Module):
     def cleanup(self):
         _backend.free_splitk()
 
-    def __repr__(self):
-        return (f"FFMLP: input_dim={self.input_dim} output_dim={self.output_dim} hidden_dim={self.hidden_dim} "
-                f"num_layers={self.num_layers} activation={self.activation}")
-
-    def reset_parameters(self):
-        torch.manual_seed(42)                                   # ffmlp.py:141-144
-        std = math.sqrt(3 / self.hidden_dim)
-        self.weights.data.uniform_(-std, std)
-
     def forward(self, inputs):
-        B, C = inputs.shape
-        # The reference always pads to the next multiple of 128, +128 rows when already aligned (ffmlp.py:157-159),
-        # because its kernel owns 128-row tiles.  The MFMA kernel owns 16-row tiles, so an aligned batch needs no
-        # padded copy; the rows returned to the caller are identical either way.
-        pad = (16 - B % 16) % 16
-        if pad > 0:
-            inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
-        outputs = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim,
-                                self.num_layers, self.activation, self.output_activation, not self.training,
-                                inputs.requires_grad)
-        if B != outputs.shape[0] or self.padded_output_dim != self.output_dim:
-            outputs = outputs[:B, :self.output_dim]
-        return outputs
+        """[B, input_dim] -> [B, output_dim].  The reference pads B to the next multiple of 128 (a further 128 rows when
+        it already is one, ffmlp.py:157-159) because its kernel owns 128-row tiles; the MFMA kernel owns 16-row tiles,
+        so only a ragged tail is padded.  The rows handed back are the same."""
+        rows = inputs.shape[0]
+        tail = -rows % 16
+        if tail:
+            inputs = torch.cat([inputs, inputs.new_zeros(tail, inputs.shape[1])], dim=0)
+        out = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                            self.activation, self.output_activation, not self.training, inputs.requires_grad)
+        if tail or self.padded_output_dim != self.output_dim:
+            out = out[:rows, :self.output_dim]
+        return out

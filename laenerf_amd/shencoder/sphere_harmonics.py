@@ -1,60 +1,63 @@
-"""Host-side mirror of the reference's `shencoder/sphere_harmonics.py` on the HIP backend."""
+"""Real spherical-harmonics direction encoding on the HIP backend -- the operator interface of the reference's
+`shencoder/sphere_harmonics.py` (`sh_encode(inputs, degree, calc_grad_inputs)`, `SHEncoder(input_dim, degree)`).
+
+[B,3] unit directions -> [B, degree^2] basis values in the reference's fixed order (shencoder.cu:50-120), fp32.
+`calc_grad_inputs` additionally stores d(basis)/d(direction) for the backward (never needed for ray directions).
+"""
 import torch
-import torch.nn as nn
-from torch.autograd import Function
+from torch import nn
 from torch.amp import custom_bwd, custom_fwd
 
 from ..backend import shencoder_backend as _backend
 
 
-class _sh_encoder(Function):
-    """sphere_harmonics.py:14-56"""
-
+class SHEncodeFn(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, inputs, degree, calc_grad_inputs=False):
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        output_dim = degree ** 2
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        dy_dx = torch.empty(B, input_dim * output_dim, dtype=inputs.dtype, device=inputs.device) if calc_grad_inputs else None
-        _backend.sh_encode_forward(inputs, outputs, B, input_dim, degree, dy_dx)
-        ctx.save_for_backward(inputs, dy_dx)
-        ctx.dims = [B, input_dim, degree]
-        return outputs
+    def forward(ctx, dirs, degree, want_input_grad=False):
+        dirs = dirs.contiguous()
+        n, dim = dirs.shape
+        width = degree * degree
+        basis = dirs.new_empty(n, width)
+        jac = dirs.new_empty(n, dim * width) if want_input_grad else None
+        _backend.sh_encode_forward(dirs, basis, n, dim, degree, jac)
+        ctx.save_for_backward(dirs, jac)
+        ctx.shape = (n, dim, degree)
+        return basis
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, grad):
-        inputs, dy_dx = ctx.saved_tensors
-        if dy_dx is None:
+    def backward(ctx, grad_basis):
+        dirs, jac = ctx.saved_tensors
+        if jac is None:                                  # forward was asked not to keep the Jacobian
             return None, None, None
-        B, input_dim, degree = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.sh_encode_backward(grad.contiguous(), inputs, B, input_dim, degree, dy_dx, grad_inputs)
-        return grad_inputs, None, None
+        n, dim, degree = ctx.shape
+        grad_dirs = torch.zeros_like(dirs)               # the kernel accumulates (shencoder.cu:358-382)
+        _backend.sh_encode_backward(grad_basis.contiguous(), dirs, n, dim, degree, jac, grad_dirs)
+        return grad_dirs, None, None
 
 
-sh_encode = _sh_encoder.apply
+def sh_encode(inputs, degree, calc_grad_inputs=False):
+    return SHEncodeFn.apply(inputs, degree, calc_grad_inputs)
 
 
 class SHEncoder(nn.Module):
-    """sphere_harmonics.py:61-86"""
+    """sphere_harmonics.py:61-86: degree 1..8, three input dimensions; `forward(inputs, size=1)` divides by `size` first"""
 
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = degree ** 2
-        assert self.input_dim == 3, "SH encoder only support input dim == 3"
-        assert 0 < self.degree <= 8, "SH encoder only supports degree in [1, 8]"
+        if input_dim != 3:
+            raise AssertionError("SH encoder only support input dim == 3")
+        if not 0 < degree <= 8:
+            raise AssertionError("SH encoder only supports degree in [1, 8]")
+        self.input_dim, self.degree = input_dim, degree
+        self.output_dim = degree * degree
 
-    def __repr__(self):
-        return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
+    def extra_repr(self):
+        return f"input_dim={self.input_dim}, degree={self.degree}"
 
     def forward(self, inputs, size=1):
-        inputs = inputs / size
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = sh_encode(inputs, self.degree, inputs.requires_grad)
-        return outputs.reshape(prefix_shape + [self.output_dim])
+        scaled = inputs / size
+        lead = scaled.shape[:-1]
+        flat = scaled.reshape(-1, self.input_dim)
+        return sh_encode(flat, self.degree, flat.requires_grad).reshape(*lead, self.output_dim)
