@@ -86,7 +86,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_fwd(
     uint32_t out_act, half_t* __restrict__ fwd_buf, half_t* __restrict__ out, uint32_t B, uint32_t n_groups) {
     constexpr int MT = WIDTH / 16;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (MLP_BLOCK / 64);
+    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * (MLP_BLOCK / 64);
     for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
         const size_t row0 = (size_t)grp * 16 * NT;
         f4 acc[MT][NT];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_bwd(
     uint32_t n_groups) {
     constexpr int MT = WIDTH / 16;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (MLP_BLOCK / 64);
+    const uint32_t wave0 = blockIdx.x * (MLP_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * (MLP_BLOCK / 64);
     const half_t* Wout = W + (size_t)WIDTH * in_dim + (size_t)WIDTH * WIDTH * n_hidden;
     for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
         const size_t row0 = (size_t)grp * 16 * NT;
@@ -296,7 +296,8 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
     const uint32_t mt0 = job.mb * 4, nt0 = job.nb * 4;
     const uint32_t mt_n = min(4u, OUT / 16 - mt0), nt_n = min(4u, IN / 16 - nt0);
 
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: per-wave branches stay uniform
     f4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -530,7 +531,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int KT0 = C::KT0;
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     half_t* Wl = lds;                                          // weight image
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: per-wave branches stay uniform
     half_t* T = lds + C::W_HALVES + w * C::WAVE_HALVES;        // this wave's tiles
     // transposed-read lane address inside a [16 x ld] tile: group g reads rows 4g..4g+3, lane i=4q+p supplies row q, cols 4p..
     const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -789,7 +791,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_bwd_coop(
     extern __shared__ __attribute__((aligned(16))) half_t lds[];
     half_t* Wl = lds;
     half_t* Xs = lds + C::X_OFF; half_t* Hs = lds + C::H_OFF; half_t* Ds = lds + C::D_OFF; half_t* Gs = lds + C::G_OFF;
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    // wave index as a SCALAR: the per-wave branches below (`w < 4`, `t < 4 * KT0`) must be uniform branches.  As a vector
+    // value they compile to EXEC-masked regions; with IN = 48 (the only shape where waves 4-7 skip a dW0 tile) one 16-row
+    // tile of dX / dW came out wrong in ~25 % of the launches (tests/test_gpu_ffmlp.py [1152-48-64-2]).
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     const int r0 = 16 * w;                                   // this wave's rows inside the shared tiles
 
@@ -1047,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * 4;   // scalar tile loop
     // software pipeline: the inputs of the wave's NEXT tile are requested before the current tile's MFMA chain (two
     // waves per SIMD do not hide a global-load latency per tile on their own; measured neutral on the 248 k-sample step,
     // the kernel is VALU-bound: ~700 VALU instructions per 36 MFMAs per tile)

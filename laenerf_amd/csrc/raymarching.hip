@@ -260,7 +260,7 @@ __global__ __launch_bounds__(MARCH_BLOCK) void k_march_train_wave(
     uint32_t max_steps, uint32_t N, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, uint32_t* __restrict__ counts, const uint32_t* __restrict__ prefix,
     float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays, MarchRecs recs) {
-    const uint32_t n = blockIdx.x * MARCH_WAVES + (threadIdx.x >> 6);
+    const uint32_t n = blockIdx.x * MARCH_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // one ray per wave: scalar
     if (n >= N) return;                                   // whole wave
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
     const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
     float* __restrict__ depth, float* __restrict__ image, Blend bl) {
-    const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
+    const uint32_t n = blockIdx.x * COMP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // one ray per wave: scalar
     if (n >= N) return;
     const int lane = threadIdx.x & 63;
     const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
     const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     const float* __restrict__ weights_sum, const float* __restrict__ image, uint32_t M, uint32_t N, float T_thresh,
     float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, Dense dn) {
-    const uint32_t n = blockIdx.x * COMP_WAVES + (threadIdx.x >> 6);
+    const uint32_t n = blockIdx.x * COMP_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // one ray per wave: scalar
     if (n >= N) return;
     const int lane = threadIdx.x & 63;
     if constexpr (DENSE) {

@@ -54,7 +54,7 @@ def test_ffmlp_forward_backward(O, IN, H, NL, B):
             gw2 = torch.empty_like(gw)
             F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), None if fused else half_from_bits(ref_fb),
                              B, IN, 16, H, NL, 0, 6, False, None if fused else bb, gi, gw2)
-            assert torch.equal(gw, gw2)
+            assert torch.equal(gw, gw2), mode
     finally:
         F.ffmlp_set_mode(0)
 
