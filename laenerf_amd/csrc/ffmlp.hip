@@ -1095,6 +1095,61 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     }
 }
 
+// FFMLP forward for the common shape (64 wide, ReLU, linear output, 32 / 48 / 64 inputs, 1 or 2 hidden GEMMs) with the
+// weights staged in LDS once per workgroup, like k_nerf_head_fwd: the generic k_mlp_fwd re-reads every weight fragment
+// from global memory for every 32-row group (41 us per 100 k rows for the LAENeRF nets against ~10 us here).
+template <int KT0, int NH>
+struct Fwd64Cfg {
+    static constexpr int IN = 16 * KT0, LDX = IN + 8, LDH = 72;
+    static constexpr int W0 = 0, WH = W0 + 64 * LDX, WO = WH + NH * 64 * LDH, LDS_HALVES = WO + 16 * LDH;
+};
+template <int KT0, int NH>
+__global__ __launch_bounds__(256) void k_mlp_fwd64(const half_t* __restrict__ in, const half_t* __restrict__ W, uint32_t n_tiles,
+                                                   half_t* __restrict__ fwd_buf, half_t* __restrict__ out) {
+    using C = Fwd64Cfg<KT0, NH>;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    stage_rows(lds + C::W0, C::LDX, W, 64, C::IN);
+#pragma unroll
+    for (int l = 0; l < NH; l++) stage_rows(lds + C::WH + l * 64 * C::LDH, C::LDH, W + 64 * C::IN + (size_t)l * 4096, 64, 64);
+    stage_rows(lds + C::WO, C::LDH, W + 64 * C::IN + (size_t)NH * 4096, 16, 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * 4;
+    const size_t B = (size_t)n_tiles * 16;
+    for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
+        const size_t row = (size_t)tile * 16 + c;
+        h4 xf[KT0];
+#pragma unroll
+        for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(in + row * C::IN + kt * 16 + 4 * g);
+        f4 acc[4];
+        h4 a[4], b[4];
+        layer64<KT0>(lds + C::W0, C::LDX, xf, c, g, acc); relu4(acc, a);
+        if (fwd_buf) store_tiles<4>(fwd_buf, row, 64, g, a);
+#pragma unroll
+        for (int l = 0; l < NH; l++) {
+            layer64<4>(lds + C::WH + l * 64 * C::LDH, C::LDH, a, c, g, acc); relu4(acc, b);
+            if (fwd_buf) store_tiles<4>(fwd_buf + (size_t)(l + 1) * B * 64, row, 64, g, b);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) a[mt] = b[mt];
+        }
+        const f4 o = out16(lds + C::WO, C::LDH, a, c, g);
+        h4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = (half_t)o[r];
+        *reinterpret_cast<h4*>(out + row * 16 + 4 * g) = v;
+    }
+}
+
+template <int KT0, int NH>
+int launch_fwd64(const half_t* in, const half_t* W, uint32_t B, half_t* fwd_buf, half_t* out, hipStream_t s) {
+    using C = Fwd64Cfg<KT0, NH>;
+    const size_t lds_bytes = (size_t)C::LDS_HALVES * 2;
+    const uint32_t n_tiles = B / 16;
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
+    k_mlp_fwd64<KT0, NH><<<blocks, 256, lds_bytes, s>>>(in, W, n_tiles, fwd_buf, out);
+    return LAE_OK;
+}
+
 // 0 = fused backward where available (default), 1 = always the buffer-faithful three-kernel path
 int g_ffmlp_mode = 0;
 
@@ -1132,6 +1187,13 @@ int forward_any(const void* inputs, const void* weights, uint32_t B, uint32_t in
     half_t* fb = (half_t*)fwd_buf; half_t* out = (half_t*)outputs;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const uint32_t nh = num_layers - 1;
+    if (hidden == 64 && act == LAE_ACT_RELU && out_act == 6 && (nh == 1 || nh == 2) && (in_dim == 32 || in_dim == 48 || in_dim == 64) &&
+        g_ffmlp_mode != 1) {                                  // weights in LDS (< 48 KiB: no attribute needed)
+        if (in_dim == 32) nh == 1 ? launch_fwd64<2, 1>(in, W, B, fb, out, s) : launch_fwd64<2, 2>(in, W, B, fb, out, s);
+        else if (in_dim == 48) nh == 1 ? launch_fwd64<3, 1>(in, W, B, fb, out, s) : launch_fwd64<3, 2>(in, W, B, fb, out, s);
+        else nh == 1 ? launch_fwd64<4, 1>(in, W, B, fb, out, s) : launch_fwd64<4, 2>(in, W, B, fb, out, s);
+        return lae::check_launch("ffmlp_forward");
+    }
     switch (hidden) {
         case 16: forward_w<16>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
         case 32: forward_w<32>(in, W, B, in_dim, nh, act, out_act, fb, out, s); break;
