@@ -249,10 +249,10 @@ def style_step(dev, P=100000, steps=30):
 
     def body():
         with torch.autocast("cuda", dtype=torch.float16):
-            pred, w, o = m.forward_train(x, d)
-            loss = torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params) \
-                + m.palet_loss(params)
-        opt.scale(loss).backward()
+            # recomposition + MSE + weight + offset losses as one node (palette.hip); the palette-only term stays in torch
+            loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt)
+            loss = loss + opt.scale(m.palet_loss(params))
+        loss.backward()
         opt.step()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

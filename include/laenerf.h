@@ -380,6 +380,21 @@ LAE_API int lae_palette_backward(const void* w_logits, const void* o_raw, const 
                          uint32_t M, const void* g_pred, const float* g_w, const void* g_o, void* g_w_logits, void* g_o_raw,
                          float* g_palette, void* scratch, void* stream);
 
+/* The point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996; style_encoder.py:183-205) fused behind the
+ * recomposition: loss = MSE(pred, target) + w_uniform * max_j sum_i w_hat[i,j] + w_non_uniform * sum_i (1 - max_j w_hat[i,j])
+ * + c_offset * sum o_hat^2.  forward: fin[8] (device) = {loss * scale, loss, mse, uniform, non_uniform, offset terms,
+ * arg-max column, scale}; scale: device scalar or NULL (1).  backward: gradients of (upstream * fin[0]) with respect to the
+ * two MLP outputs and the palette in ONE kernel (no per-point gradient tensors); upstream: device scalar.
+ * scratch: max(lae_style_loss_scratch_bytes(M), lae_palette_backward_scratch_bytes(M)). */
+LAE_API uint64_t lae_style_loss_scratch_bytes(uint32_t M);
+LAE_API int lae_style_loss_forward(const void* pred, const float* target, const float* w_hat, const void* o_hat, uint32_t M,
+                           uint32_t n_active, float w_uniform, float w_non_uniform, float c_offset, const float* scale,
+                           float* fin, void* scratch, void* stream);
+LAE_API int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask,
+                            uint32_t M, const float* target, const float* fin, const float* upstream, float w_uniform,
+                            float w_non_uniform, float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette,
+                            void* scratch, void* stream);
+
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
  *   (renderer.py:580-592).  coords NULL: c = (j / H^2, (j / H) % H, j % H) (full sweep, n <= H^3); else coords [n,3] int32.

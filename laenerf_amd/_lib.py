@@ -68,6 +68,9 @@ SIGNATURES = {
     "lae_palette_forward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp],
     "lae_palette_backward_scratch_bytes": [u32],
     "lae_palette_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_style_loss_scratch_bytes": [u32],
+    "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp],
+    "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],
@@ -85,6 +88,7 @@ _RESTYPES = {
     "lae_compact_scratch_bytes": u64,
     "lae_grid_backward_plan_bytes": u64,
     "lae_palette_backward_scratch_bytes": u64,
+    "lae_style_loss_scratch_bytes": u64,
     "lae_render_frame_workspace_bytes": u64,
     "lae_version": ctypes.c_char_p,
     "lae_last_error": ctypes.c_char_p,

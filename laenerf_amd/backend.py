@@ -504,6 +504,26 @@ class _Style:
                                        ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws), stream()), "palette_backward")
 
 
+    @staticmethod
+    def style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin):
+        ts = (pred, target, w_hat, o_hat, scale, fin)
+        need_cuda(*ts); need_contig(*ts)
+        lib = _lib.load()
+        ws = _workspace(pred.device, lib.lae_style_loss_scratch_bytes(M))
+        check(lib.lae_style_loss_forward(ptr(pred), ptr(target), ptr(w_hat), ptr(o_hat), M, n_active, float(lw[0]), float(lw[1]), float(lw[2]),
+                                         ptr(scale), ptr(fin), ptr(ws), stream()), "style_loss_forward")
+
+    @staticmethod
+    def style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, upstream, lw, g_w_logits, g_o_raw, g_palette):
+        ts = (w_logits, o_raw, palette, target, fin, upstream, g_w_logits, g_o_raw, g_palette)
+        need_cuda(*ts); need_contig(*ts)
+        lib = _lib.load()
+        ws = _workspace(w_logits.device, max(lib.lae_palette_backward_scratch_bytes(M), lib.lae_style_loss_scratch_bytes(M)))
+        check(lib.lae_style_loss_backward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(target), ptr(fin), ptr(upstream),
+                                          float(lw[0]), float(lw[1]), float(lw[2]), ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws),
+                                          stream()), "style_loss_backward")
+
+
 style_backend = _Style
 
 for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):

@@ -96,13 +96,24 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_fwd(const half_t* __restr
     }
 }
 
-// g_pred / g_o: fp16 [M,3] or NULL; g_w: fp32 [M, n_active] or NULL.  Writes g_wl, g_ol [M,16] fp16 (zeros in padded /
-// inactive columns) and this workgroup's palette-gradient partial into slab[blockIdx][PAL_MAX*3].
+// Point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996) fused behind the recomposition:
+//   loss = MSE(pred, target) + w_uniform * max_j sum_i w_ij + w_non_uniform * sum_i (1 - max_j w_ij) + c_offset * sum o^2
+// (style_encoder.py:183-205).  `fin` is the result block of k_style_loss_final (totals, arg-max column, loss scale).
+struct StyleLossW { float w_uniform, w_non_uniform, c_offset; };
+struct LossSrc { const float* target; const float* fin; const float* upstream; StyleLossW lw; };
+constexpr int SL_COLS = 3 + PAL_MAX;             // partial sums per workgroup: squared error, o^2, 1 - max w, column sums
+constexpr int FIN_LOSS_SCALED = 0, FIN_LOSS = 1, FIN_MSE = 2, FIN_UNIFORM = 3, FIN_NON_UNIFORM = 4, FIN_OFFSET = 5, FIN_JMAX = 6,
+              FIN_SCALE = 7;
+
+// g_pred / g_o: fp16 [M,3] or NULL; g_w: fp32 [M, n_active] or NULL (LOSS: derived from the fused criterion instead).
+// Writes g_wl, g_ol [M,16] fp16 (zeros in padded / inactive columns) and this workgroup's palette-gradient partial into
+// slab[blockIdx][PAL_MAX*3].
+template <bool LOSS>
 __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restrict__ w_logits, const half_t* __restrict__ o_raw,
                                                            const float* __restrict__ palette, uint32_t P, uint32_t mask, uint32_t M,
                                                            const half_t* __restrict__ g_pred, const float* __restrict__ g_w,
                                                            const half_t* __restrict__ g_o, half_t* __restrict__ g_wl,
-                                                           half_t* __restrict__ g_ol, float* __restrict__ slab) {
+                                                           half_t* __restrict__ g_ol, float* __restrict__ slab, LossSrc ls) {
     __shared__ float red[PAL_BLOCK / 64][PAL_MAX * 3];
     const uint32_t i = blockIdx.x * PAL_BLOCK + threadIdx.x;
     const Palette pal = load_palette(palette, P, mask);
@@ -119,15 +130,32 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
         for (int c = 0; c < 3; c++) o[c] = (half_t)tanhf((float)ol.v[c]);
         recompose(w, na, pal, o, pre);
         float gpc[3], got[3];
+        float gmul = 0.0f;                                   // LOSS: upstream d(loss) x loss scale
+        uint32_t jmax_col = 0, jmax_row = 0;
+        if constexpr (LOSS) {
+            gmul = ls.upstream[0] * ls.fin[FIN_SCALE];
+            jmax_col = (uint32_t)ls.fin[FIN_JMAX];
+            for (uint32_t j = 1; j < na; j++) if (w[j] > w[jmax_row]) jmax_row = j;                     // first maximum, like torch.max
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float p = (float)pre[c];
-            gpc[c] = (g_pred && p >= 0.0f && p <= 1.0f) ? (float)g_pred[(size_t)i * 3 + c] : 0.0f;     // clamp backward (inclusive)
-            got[c] = gpc[c] + (g_o ? (float)g_o[(size_t)i * 3 + c] : 0.0f);
+            const bool pass = p >= 0.0f && p <= 1.0f;                                                   // clamp backward (inclusive)
+            if constexpr (LOSS) {
+                const float pc = fminf(fmaxf(p, 0.0f), 1.0f);
+                gpc[c] = pass ? gmul * 2.0f * (pc - ls.target[(size_t)i * 3 + c]) / (3.0f * (float)M) : 0.0f;
+                got[c] = gpc[c] + gmul * 2.0f * ls.lw.c_offset * (float)o[c];
+            } else {
+                gpc[c] = (g_pred && pass) ? (float)g_pred[(size_t)i * 3 + c] : 0.0f;
+                got[c] = gpc[c] + (g_o ? (float)g_o[(size_t)i * 3 + c] : 0.0f);
+            }
         }
         float gw[PAL_MAX], dot = 0.0f;
         for (uint32_t j = 0; j < na; j++) {
-            gw[j] = (g_w ? g_w[(size_t)i * na + j] : 0.0f) + gpc[0] * pal.c[j][0] + gpc[1] * pal.c[j][1] + gpc[2] * pal.c[j][2];
+            float gin;
+            if constexpr (LOSS) gin = gmul * ((j == jmax_col ? ls.lw.w_uniform : 0.0f) - (j == jmax_row ? ls.lw.w_non_uniform : 0.0f));
+            else gin = g_w ? g_w[(size_t)i * na + j] : 0.0f;
+            gw[j] = gin + gpc[0] * pal.c[j][0] + gpc[1] * pal.c[j][1] + gpc[2] * pal.c[j][2];
             dot = fmaf(w[j], gw[j], dot);
             gp_pal[j][0] = w[j] * gpc[0]; gp_pal[j][1] = w[j] * gpc[1]; gp_pal[j][2] = w[j] * gpc[2];
         }
@@ -187,6 +215,69 @@ __global__ __launch_bounds__(64) void k_palette_grad_reduce(const float* __restr
     }
 }
 
+// forward of the fused criterion: per-workgroup partial sums (fixed order inside the wave / workgroup)
+__global__ __launch_bounds__(PAL_BLOCK) void k_style_loss_partial(const half_t* __restrict__ pred, const float* __restrict__ target,
+                                                                  const float* __restrict__ w_hat, const half_t* __restrict__ o_hat,
+                                                                  uint32_t M, uint32_t na, float* __restrict__ slab) {
+    __shared__ float red[PAL_BLOCK / 64][SL_COLS];
+    const uint32_t i = blockIdx.x * PAL_BLOCK + threadIdx.x;
+    float v[SL_COLS];
+#pragma unroll
+    for (int k = 0; k < SL_COLS; k++) v[k] = 0.0f;
+    if (i < M) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (float)pred[(size_t)i * 3 + c] - target[(size_t)i * 3 + c];
+            const float o = (float)o_hat[(size_t)i * 3 + c];
+            v[0] = fmaf(d, d, v[0]); v[1] = fmaf(o, o, v[1]);
+        }
+        float mx = -1.0f;
+#pragma unroll
+        for (int j = 0; j < PAL_MAX; j++)
+            if ((uint32_t)j < na) { const float w = w_hat[(size_t)i * na + j]; v[3 + j] = w; mx = fmaxf(mx, w); }
+        v[2] = 1.0f - mx;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < SL_COLS; k++) {
+        float t = v[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0) red[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < SL_COLS) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < PAL_BLOCK / 64; q++) t += red[q][threadIdx.x];
+        slab[(size_t)blockIdx.x * SL_COLS + threadIdx.x] = t;
+    }
+}
+
+// one workgroup: fixed-order totals of the partials, the loss terms, the arg-max column of the uniform term
+__global__ __launch_bounds__(1024) void k_style_loss_final(const float* __restrict__ slab, uint32_t n_blocks, uint32_t M, uint32_t na,
+                                                           StyleLossW lw, const float* __restrict__ scale, float* __restrict__ fin) {
+    __shared__ float tot[SL_COLS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int col = wave; col < SL_COLS; col += 16) {         // a wave per column: lanes stride over the partials, then a butterfly
+        float t = 0.0f;
+        for (uint32_t b = lane; b < n_blocks; b += 64) t += slab[(size_t)b * SL_COLS + col];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0) tot[col] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uint32_t jmax = 0;
+    for (uint32_t j = 1; j < na; j++) if (tot[3 + j] > tot[3 + jmax]) jmax = j;
+    const float s = scale ? scale[0] : 1.0f;
+    const float mse = tot[0] / (3.0f * (float)M), uni = lw.w_uniform * tot[3 + jmax], non = lw.w_non_uniform * tot[2],
+                off = lw.c_offset * tot[1];
+    const float loss = ((mse + uni) + non) + off;
+    fin[FIN_LOSS_SCALED] = loss * s; fin[FIN_LOSS] = loss; fin[FIN_MSE] = mse; fin[FIN_UNIFORM] = uni; fin[FIN_NON_UNIFORM] = non;
+    fin[FIN_OFFSET] = off; fin[FIN_JMAX] = (float)jmax; fin[FIN_SCALE] = s;
+}
+
 int check_palette(uint32_t P, uint32_t mask) {
     if (P == 0 || P > PAL_MAX) return LAE_EINVAL;
     return (mask & ((1u << P) - 1u)) ? LAE_OK : LAE_EINVAL;        // at least one active base
@@ -219,10 +310,42 @@ int lae_palette_backward(const void* w_logits, const void* o_raw, const float* p
     const int rc = check_palette(P, active_mask);
     if (rc) return rc;
     const uint32_t nb = lae::cdiv(M, PAL_BLOCK);
-    k_palette_bwd<<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M, (const half_t*)g_pred, g_w,
-                                           (const half_t*)g_o, (half_t*)g_w_logits, (half_t*)g_o_raw, (float*)scratch);
+    k_palette_bwd<false><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M,
+                                                  (const half_t*)g_pred, g_w, (const half_t*)g_o, (half_t*)g_w_logits, (half_t*)g_o_raw,
+                                                  (float*)scratch, LossSrc{});
     k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
     return lae::check_launch("palette_backward");
+}
+
+uint64_t lae_style_loss_scratch_bytes(uint32_t M) { return (uint64_t)lae::cdiv(M, PAL_BLOCK) * SL_COLS * sizeof(float) + 256; }
+
+int lae_style_loss_forward(const void* pred, const float* target, const float* w_hat, const void* o_hat, uint32_t M, uint32_t n_active,
+                           float w_uniform, float w_non_uniform, float c_offset, const float* scale, float* fin, void* scratch,
+                           void* stream) {
+    if (!pred || !target || !w_hat || !o_hat || !fin || !scratch) return LAE_ENULL;
+    if (M == 0 || n_active == 0 || n_active > PAL_MAX) return LAE_EINVAL;
+    hipStream_t s = STREAM(stream);
+    const uint32_t nb = lae::cdiv(M, PAL_BLOCK);
+    k_style_loss_partial<<<nb, PAL_BLOCK, 0, s>>>((const half_t*)pred, target, w_hat, (const half_t*)o_hat, M, n_active, (float*)scratch);
+    k_style_loss_final<<<1, 1024, 0, s>>>((const float*)scratch, nb, M, n_active, StyleLossW{w_uniform, w_non_uniform, c_offset},
+                                                  scale, fin);
+    return lae::check_launch("style_loss_forward");
+}
+
+int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask, uint32_t M,
+                            const float* target, const float* fin, const float* upstream, float w_uniform, float w_non_uniform,
+                            float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch, void* stream) {
+    if (!w_logits || !o_raw || !palette || !target || !fin || !upstream || !g_w_logits || !g_o_raw || !g_palette || !scratch) return LAE_ENULL;
+    if (M == 0) return LAE_EINVAL;
+    const int rc = check_palette(P, active_mask);
+    if (rc) return rc;
+    hipStream_t s = STREAM(stream);
+    const uint32_t nb = lae::cdiv(M, PAL_BLOCK);
+    const LossSrc ls{target, fin, upstream, StyleLossW{w_uniform, w_non_uniform, c_offset}};
+    k_palette_bwd<true><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M, nullptr, nullptr,
+                                                 nullptr, (half_t*)g_w_logits, (half_t*)g_o_raw, (float*)scratch, ls);
+    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
+    return lae::check_launch("style_loss_backward");
 }
 
 }  // extern "C"

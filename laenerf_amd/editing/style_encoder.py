@@ -54,6 +54,44 @@ class _palette_recompose(Function):
         return g_wl, g_ol, g_pal, None
 
 
+class _palette_point_loss(Function):
+    """recomposition + the point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996) as ONE autograd node:
+    forward = recomposition kernel + two reduction kernels, backward = one kernel that derives the per-point gradients of
+    MSE / weight / offset terms on the fly (csrc/palette.hip k_palette_bwd<LOSS>).  The torch formulation costs ~40
+    reduce / elementwise launches per step around [P, <= 16] tensors."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, w_logits, o_raw, palette, active_mask, target, lw, scale):
+        M = w_logits.shape[0]
+        w_logits, o_raw = w_logits.half().contiguous(), o_raw.half().contiguous()
+        palette, target = palette.float().contiguous(), target.float().contiguous()
+        P = palette.shape[0]
+        n_active = bin(active_mask & ((1 << P) - 1)).count("1")
+        dev = w_logits.device
+        pred = torch.empty(M, 3, dtype=torch.half, device=dev)
+        w_hat = torch.empty(M, n_active, dtype=torch.float32, device=dev)
+        o_hat = torch.empty(M, 3, dtype=torch.half, device=dev)
+        _backend.palette_forward(w_logits, o_raw, palette, P, active_mask, M, pred, w_hat, o_hat)
+        fin = torch.empty(8, dtype=torch.float32, device=dev)
+        _backend.style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin)
+        ctx.save_for_backward(w_logits, o_raw, palette, target, fin)
+        ctx.meta = (P, active_mask, M, lw)
+        ctx.mark_non_differentiable(pred, w_hat, o_hat, fin)
+        return fin[0], pred, w_hat, o_hat, fin
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_loss, *_):
+        w_logits, o_raw, palette, target, fin = ctx.saved_tensors
+        P, active_mask, M, lw = ctx.meta
+        g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)
+        g_pal = torch.empty_like(palette)
+        _backend.style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, g_loss.float().reshape(1).contiguous(), lw,
+                                     g_wl, g_ol, g_pal)
+        return g_wl, g_ol, g_pal, None, None, None, None
+
+
 def palette_recompose(w_logits, o_raw, palette, active_mask):
     """w_logits, o_raw [M,16] (the padded FFMLP outputs), palette [P,3], active_mask int (bit k = base k active)
     -> pred [M,3] fp16, w_hat [M, n_active] fp32, o_hat [M,3] fp16   (style_encoder.py:148-158)"""
@@ -127,6 +165,24 @@ class LAENeRF(nn.Module):
     def forward(self, x, d=None):
         """style_encoder.py:111-133"""
         return self.forward_train(x, d)[0]
+
+    def forward_train_loss(self, x, d, target, params, scaler=None):
+        """MI355X-native: forward_train + the point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996) in one node:
+        loss = MSE(pred, target) + weights_loss(w_hat) + offset_loss(o_hat), multiplied by `scaler`'s loss scale (a FusedAdam,
+        a 1-element fp32 cuda tensor, or None).  `palet_loss(params)` (palette only) is left to the caller.
+        -> (loss, pred [M,3], w_hat, o_hat); loss.terms = [scaled loss, loss, mse, uniform, non-uniform, offset, ...]"""
+        if self.dir_encoding is not None:
+            assert d is not None
+        w_logits, o_raw, M = self._logits(x, d)
+        if w_logits.shape[0] != M:
+            raise RuntimeError("forward_train_loss: the number of points must be a multiple of 16")
+        scale = None
+        if scaler is not None:
+            scale = scaler if torch.is_tensor(scaler) else (scaler._scale_view[:1] if scaler.use_scaler else None)
+        lw = (float(params.weight_loss_uniform), float(params.weight_loss_non_uniform), float(params.offset_loss))
+        loss, pred, w_hat, o_hat, fin = _palette_point_loss.apply(w_logits, o_raw, self.color_palette, self._active_mask, target, lw, scale)
+        loss.terms = fin
+        return loss, pred, w_hat, o_hat
 
     def get_weights(self, x):
         """style_encoder.py:93-96"""

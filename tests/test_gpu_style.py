@@ -158,3 +158,35 @@ def test_laenerf_inference_active_palettes_and_no_dirs():
         p2 = m2(x)
         rp2 = reference_forward(m2, x, None)[0]
     assert np.abs(N(p2) - N(rp2)).max() < 1e-2
+
+
+@pytest.mark.parametrize("n,mask", [(4096, 0xFF), (1008, 0b10110101)])
+def test_fused_point_losses_equal_the_torch_formulation(n, mask):
+    """forward_train_loss == forward_train followed by MSE + weights_loss + offset_loss in torch (value and gradients)"""
+    m, params = make_model()
+    m.set_active_palets([(mask >> k) & 1 == 1 for k in range(8)])
+    m.train()
+    torch.manual_seed(2)
+    x = (torch.rand(n, 3, device=DEV) * 2 - 1) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
+    target = torch.rand(n, 3, device=DEV)
+    scale = torch.tensor([256.0], device=DEV)
+    res = []
+    for fused in (False, True):
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            if fused:
+                loss, pred, w, o = m.forward_train_loss(x, d, target, params, scale)
+            else:
+                pred, w, o = m.forward_train(x, d)
+                loss = (torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params)) * scale
+        (loss * 0.5).backward()
+        res.append((loss.detach().float().clone(), pred.detach().clone(), [p.grad.clone() for p in (m.color_palette, m.weight_net.weights,
+                                                                                                     m.offset_net.weights, m.encoder.embeddings)]))
+    (l0, p0, g0), (l1, p1, g1) = res
+    assert torch.equal(p0, p1)
+    assert l1.item() == pytest.approx(l0.item(), rel=2e-4)
+    terms = res[1][0]
+    for a, b, name in zip(g0, g1, ("palette", "weight_net", "offset_net", "table")):
+        a, b = N(a), N(b)
+        assert np.abs(a - b).max() <= 0.02 * np.abs(a).max() + 1e-6, name      # fp16 rounding of dL/dlogits in both paths
