@@ -139,7 +139,7 @@ def eval_frame(net, r, dev, H=800, W=800):
         for it in range(6):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-                res = r.render_eval(o, d, bg_color=1, max_steps=1024, **kw)
+                res = r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(H, W), **kw)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         return sorted(times[1:])[2], res

@@ -194,3 +194,16 @@ def test_frame_loop_refuses_capture_and_cpu():
             with torch.cuda.graph(gph):
                 r.render_eval(o, d, frame_loop=True)
     torch.cuda.synchronize()
+
+
+def test_tiled_ray_order_returns_the_same_image():
+    from laenerf_amd import synthetic as S
+    net, r = make(bound=1, seed=6)
+    o, d = S.frame_rays(64, 96)
+    o, d = T(o), T(d)
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = r.render_eval(o, d, bg_color=1)
+        b = r.render_eval(o, d, bg_color=1, image_hw=(64, 96))            # rendered in 8x4 pixel tiles, returned in scanline order
+        c = r.render_eval(o, d, bg_color=1, image_hw=(64, 96), tile_hw=(16, 16), frame_loop=False)
+    for k in ("image", "weights_sum"):
+        assert np.array_equal(N(a[k]), N(b[k])) and np.array_equal(N(a[k]), N(c[k])), k
