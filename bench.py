@@ -96,7 +96,7 @@ def cpu_baseline(n_rays_hint, n_threads):
         O.grid_encode_backward(genc, (xyzs + 1) / 2, (int(offsets[-1]), 2), offsets, pls, 16, f16=True, grad_blc=True)
         return int(counter[0])
 
-    o, d = S.lego_like_rays(4096, seed=0)
+    o, d = S.lego_like_rays(4096, seed=0, n_views=1)
     noises = np.random.default_rng(1).random(4096).astype(np.float32)
     # calibrate on 64 rays, then size the sample for ~15 s of wall time on n_threads threads: whole 4096-ray steps
     # (different ray batches) when one step is too short for the box
@@ -110,7 +110,7 @@ def cpu_baseline(n_rays_hint, n_threads):
     n_steps = max(1, (n_rays + 4095) // 4096)
     work = []
     for k in range(n_steps):
-        ok_, dk_ = (o, d) if k == 0 else S.lego_like_rays(4096, seed=k)
+        ok_, dk_ = (o, d) if k == 0 else S.lego_like_rays(4096, seed=k, n_views=1)
         n_k = min(4096, n_rays - 4096 * k)
         for c in np.array_split(np.arange(n_k), max(1, min(n_threads, n_k // 16))):
             work.append((ok_[c], dk_[c], noises[c]))
@@ -325,7 +325,9 @@ def main():
     n_batches = 16
     batches = []
     for b in range(n_batches):
-        o, d = S.lego_like_rays(args.rays, seed=1000 * rank + b)
+        # one training view per step, random pixels of it: what the reference's loader does (DataLoader batch_size = 1,
+        # nerf/provider.py:349; get_rays draws randint(0, H*W) pixel indices of that pose, nerf/utils.py:108)
+        o, d = S.lego_like_rays(args.rays, seed=1000 * rank + b, n_views=1)
         batches.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev),
                         torch.rand(args.rays, 3, device=dev)))
     net.train()
@@ -517,7 +519,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
-            "config": {"workload": "configs[1]: lego-like 800x800 pinhole rays, 4096 rays/batch, L=16 T=2^19 F=2 hash grid "
+            "config": {"workload": "configs[1]: lego-like 800x800 pinhole rays, 4096 random pixels of one view per step, L=16 T=2^19 F=2 hash grid "
                                    "+ 2x64 / 3x64 ffmlp, cascade 1, analytic occupancy (13% occupied), "
                                    "steady-state train step incl. backward + Adam",
                        "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
