@@ -38,6 +38,7 @@ class _palette_recompose(Function):
         _backend.palette_forward(w_logits, o_raw, palette, P, active_mask, M, pred, w_hat, o_hat)
         ctx.save_for_backward(w_logits, o_raw, palette)
         ctx.meta = (P, active_mask, M)
+        ctx.set_materialize_grads(False)                 # unused outputs arrive as None in backward (the kernel takes NULL)
         return pred, w_hat, o_hat
 
     @staticmethod
@@ -78,11 +79,14 @@ class _palette_point_loss(Function):
         ctx.save_for_backward(w_logits, o_raw, palette, target, fin)
         ctx.meta = (P, active_mask, M, lw)
         ctx.mark_non_differentiable(pred, w_hat, o_hat, fin)
+        ctx.set_materialize_grads(False)                 # no zero-filled gradients for the auxiliary outputs
         return fin[0], pred, w_hat, o_hat, fin
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, g_loss, *_):
+        if g_loss is None:
+            return (None,) * 7
         w_logits, o_raw, palette, target, fin = ctx.saved_tensors
         P, active_mask, M, lw = ctx.meta
         g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)

@@ -27,10 +27,13 @@ class _mse_scaled(Function):
                                                     out.data_ptr(), grad.data_ptr(), _lib.stream()), "mse_loss_forward")
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
         return out[0], out
 
     @staticmethod
     def backward(ctx, grad_out, _):
+        if grad_out is None:
+            return None, None, None
         (grad,) = ctx.saved_tensors
         return grad * grad_out, None, None
 

@@ -271,11 +271,14 @@ class _composite_rays_train_blend_mse(Function):
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image)
         ctx.dims = [M, N, T_thresh, bg]
         ctx.mark_non_differentiable(weights_sum, depth_out, image_out, out)
+        ctx.set_materialize_grads(False)                 # no zero-filled gradients for the four auxiliary outputs (4 fill launches)
         return out[0], weights_sum, depth_out, image_out, out
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad_loss, *_):
+        if grad_loss is None:
+            return (None,) * 12
         sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image = ctx.saved_tensors
         M, N, T_thresh, bg = ctx.dims
         grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
