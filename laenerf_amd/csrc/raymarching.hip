@@ -766,11 +766,12 @@ template <bool EDIT>
 __device__ __forceinline__ uint32_t frame_lookahead_coop(const Ray& r, const MarchCfg& cfg, const uint8_t* __restrict__ grid,
                                                          const uint8_t* __restrict__ edit_grid, float t_base, float far,
                                                          uint32_t remaining, float* __restrict__ out_t, uint8_t* __restrict__ out_e,
-                                                         int lane) {
+                                                         int lane, float& t_end) {
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t emitted = 0;
     bool pending = false;
     float pending_tt = 0.f;
+    t_end = t_base;                                        // the serial walker's t when it stops (wave-uniform)
     while (t_base < far && emitted < remaining) {
         const float t = candidate_t(cfg, t_base, lane);
         const float t_next = t + step_of(cfg, t);
@@ -815,8 +816,13 @@ __device__ __forceinline__ uint32_t frame_lookahead_coop(const Ray& r, const Mar
             if (EDIT) out_e[slot] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
         }
         emitted += cnt;
-        if (done || valid_mask != ~0ull) break;
+        if (emit && emitted >= remaining) {                // sample budget reached: the walker stands right after its last sample
+            t_end = __shfl(t_next, 63 - __builtin_clzll(emit), 64);
+            break;
+        }
+        if (done || valid_mask != ~0ull) { t_end = far; break; }   // the ray left [near, far): nothing further to find
         t_base = __shfl(t_next, 63, 64);
+        t_end = t_base;
     }
     return emitted;
 }
@@ -840,6 +846,7 @@ template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     int phase, const FrameCtrl* __restrict__ ctrl, uint32_t N, uint32_t max_n_step, const int32_t* __restrict__ alive,
     float* __restrict__ tc, float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt,
+    float* __restrict__ la_tend,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises) {
     const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
@@ -854,6 +861,9 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         if (phase >= 0 && la_cnt[index] < n_consumed) has_ray = false;          // the ray ends in this iteration
     }
     if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
+    float* out_t = la_t + (size_t)index * FRAME_LA;
+    uint8_t* out_e = EDIT ? la_e + (size_t)index * FRAME_LA : nullptr;
+    uint32_t step = 0;
     if (has_ray) {
         r = load_ray(rays_o, rays_d, index);
         far = fars[index];
@@ -862,17 +872,26 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         else {
             float last = phase == 0 ? perturbed_start(cfg, t, noises, n) : t;   // iteration 0 lists rays in identity order
             for (uint32_t j = 0; j < n_consumed; j++) {
-                const float tj = la_t[(size_t)index * FRAME_LA + j];
+                const float tj = out_t[j];
                 const float tn = tj + step_of(cfg, tj);
                 t += tn - last;                            // composite: t += deltas[1], deltas[1] = t_next - last_t
                 last = tn;
             }
             tc[index] = t;
+            // The samples recorded beyond the consumed ones are exactly what a walk restarted at t would find, provided the
+            // compositing kernel's running t equals the walker's own t after the last consumed sample (it does unless the
+            // float subtraction / addition pair above rounded: then everything is walked again from t, like the reference).
+            if (n_consumed > 0 && t == last) {
+                const uint32_t keep = la_cnt[index] - n_consumed;
+                for (uint32_t j = 0; j < keep; j++) {
+                    out_t[j] = out_t[j + n_consumed];
+                    if (EDIT) out_e[j] = out_e[j + n_consumed];
+                }
+                step = keep;
+                t = la_tend[index];
+            }
         }
     }
-    float* out_t = la_t + (size_t)index * FRAME_LA;
-    uint8_t* out_e = EDIT ? la_e + (size_t)index * FRAME_LA : nullptr;
-    uint32_t step = 0;
     for (;;) {
         uint32_t visits = 0;                               // lane phase: the reference's walk
         while (has_ray && t < far && step < max_n_step && visits < FRAME_LANE_VISITS) {
@@ -898,14 +917,15 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             rl.rdx = bcast(r.rdx, L); rl.rdy = bcast(r.rdy, L); rl.rdz = bcast(r.rdz, L);
             const uint32_t step_l = (uint32_t)__builtin_amdgcn_readlane((int)step, L);
             const uint32_t index_l = (uint32_t)__builtin_amdgcn_readlane((int)index, L);
+            float t_end;
             const uint32_t got = frame_lookahead_coop<EDIT>(rl, cfg, grid, edit_grid, bcast(t, L), bcast(far, L), max_n_step - step_l,
                                                             la_t + (size_t)index_l * FRAME_LA + step_l,
-                                                            EDIT ? la_e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane);
-            if (lane == L) step += got;
+                                                            EDIT ? la_e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane, t_end);
+            if (lane == L) { step += got; t = t_end; }
         }
         break;
     }
-    if (has_ray) la_cnt[index] = step;
+    if (has_ray) { la_cnt[index] = step; la_tend[index] = t; }
 }
 
 // march_rays (raymarching.cu:700-805 / :811-926) as a replay of the recorded sample times; see the section comment
@@ -1291,7 +1311,7 @@ uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_b
     const uint64_t cap = frame_cap(frame_budget(N, row_budget));
     return 256 /*ctrl x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*segment counts x2*/ + al256(4ull * N) /*alive*/ +
            2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + 4 * al256(4ull * N) /*rays_t, tc, nears, fars*/ +
-           al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + al256(4ull * N) /*lookahead times, edit flags, counts*/ +
+           al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 2 * al256(4ull * N) /*lookahead times, edit flags, counts, end t*/ +
            2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
            al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ + al256(4 * cap) /*sigmas*/ + al256(12 * cap) /*rgbs*/;
 }
@@ -1376,6 +1396,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     float* la_t = reinterpret_cast<float*>(take(4ull * FRAME_LA * N));
     uint8_t* la_e = take((uint64_t)FRAME_LA * N);
     uint32_t* la_cnt = reinterpret_cast<uint32_t*>(take(4ull * N));
+    float* la_tend = reinterpret_cast<float*>(take(4ull * N));
     float* xyzs = reinterpret_cast<float*>(take(12 * cap));
     float* dirs = reinterpret_cast<float*>(take(12 * cap));
     float* deltas = reinterpret_cast<float*>(take(8 * cap));
@@ -1389,10 +1410,10 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     auto lookahead = [&](int phase, const FrameCtrl* c, uint32_t n_bound, hipStream_t q) {
         const uint32_t blocks = lae::cdiv(n_bound, FRAME_BLOCK);
         if (edit_grid)
-            k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, rays_o, rays_d, fars,
+            k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, la_tend, rays_o, rays_d, fars,
                                                                  cfg, grid, edit_grid, noises);
         else
-            k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, rays_o, rays_d,
+            k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, la_tend, rays_o, rays_d,
                                                                   fars, cfg, grid, nullptr, noises);
     };
     k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
