@@ -207,3 +207,25 @@ def test_tiled_ray_order_returns_the_same_image():
         c = r.render_eval(o, d, bg_color=1, image_hw=(64, 96), tile_hw=(16, 16), frame_loop=False)
     for k in ("image", "weights_sum"):
         assert np.array_equal(N(a[k]), N(b[k])) and np.array_equal(N(a[k]), N(c[k])), k
+
+
+def test_render_frame_argument_errors():
+    """lae_render_frame through the stub: bad arguments raise, nothing falls back"""
+    from laenerf_amd import raymarching as rm
+    net, r = make(bound=1)
+    o, d = rays(64, seed=2)
+    enc = net.encoder
+    table = enc.embeddings.detach().half()
+    ws, wc = net.sigma_net.weights.detach().half(), net.color_net.weights.detach().half()
+    args = (o, d, r.aabb_infer, 0.2, r.density_bitfield, 1, 1, 128, table, enc.offsets, enc.per_level_scale, 16, ws, wc)
+    res = rm.render_frame(*args, bg_color=1)                                   # sanity: the direct call works
+    assert res["image"].shape == (64, 3)
+    with pytest.raises(RuntimeError):
+        rm.render_frame(*args, max_n_step=9)                                   # more steps per iteration than the lookahead records
+    with pytest.raises(RuntimeError):
+        rm.render_frame(*args, max_steps=0)
+    with pytest.raises(RuntimeError):
+        rm.render_frame(o, d, r.aabb_infer, 0.2, r.density_bitfield, 1, 1, 128, enc.embeddings.detach(), enc.offsets,
+                        enc.per_level_scale, 16, ws, wc)                       # fp32 table
+    with pytest.raises(RuntimeError):
+        rm.render_frame(*args[:4], r.density_bitfield.cpu(), *args[5:])        # bitfield on the CPU: no fallback

@@ -190,3 +190,29 @@ def test_fused_point_losses_equal_the_torch_formulation(n, mask):
     for a, b, name in zip(g0, g1, ("palette", "weight_net", "offset_net", "table")):
         a, b = N(a), N(b)
         assert np.abs(a - b).max() <= 0.02 * np.abs(a).max() + 1e-6, name      # fp16 rounding of dL/dlogits in both paths
+
+
+def test_palette_and_loss_argument_errors():
+    """error behaviour of the C ABI through the Python stub: invalid arguments raise RuntimeError (no silent fallback)"""
+    from laenerf_amd.backend import style_backend as B
+    from laenerf_amd.editing import palette_recompose
+    wl = torch.zeros(32, 16, device=DEV, dtype=torch.half)
+    pal = torch.rand(8, 3, device=DEV)
+    with pytest.raises(RuntimeError):
+        palette_recompose(wl, wl, pal, 0)                                   # no active palette base
+    with pytest.raises(RuntimeError):
+        palette_recompose(wl, wl, torch.rand(17, 3, device=DEV), 0x1FFFF)  # more bases than the 16-wide MLP output
+    with pytest.raises(RuntimeError):
+        palette_recompose(wl.cpu(), wl.cpu(), pal.cpu(), 0xFF)              # CPU tensors: no fallback
+    pred = torch.zeros(32, 3, device=DEV, dtype=torch.half)
+    w = torch.zeros(32, 8, device=DEV)
+    fin = torch.zeros(8, device=DEV)
+    with pytest.raises(RuntimeError):
+        B.style_loss_forward(pred, torch.zeros(32, 3, device=DEV), w, pred, 32, 0, (1, 1, 1), None, fin)     # n_active = 0
+    # empty batch: forward is a no-op, backward zeroes the palette gradient
+    e = torch.zeros(0, 16, device=DEV, dtype=torch.half, requires_grad=True)
+    p2 = pal.clone().requires_grad_(True)
+    a, b, c = palette_recompose(e, e, p2, 0xFF)
+    assert a.shape == (0, 3) and b.shape == (0, 8)
+    (a.float().sum() + b.sum() + c.float().sum()).backward()
+    assert torch.equal(p2.grad, torch.zeros_like(p2))
