@@ -395,6 +395,18 @@ LAE_API int lae_style_loss_backward(const void* w_logits, const void* o_raw, con
                             float w_non_uniform, float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette,
                             void* scratch, void* stream);
 
+/* ---- edit-grid region growing (editing/editgrid.py:274-340 EditGrid.grow_region_queue; Python + collections.deque
+ * in the reference) ----
+ * grid: the selection bitfield [C*H^3/8] (Morton order, like density_bitfield), modified in place; density_grid [C, H^3];
+ * queue: device array of `capacity` entries x | y << 8 | z << 16 | level << 24; state (device uint32[4]): head, tail
+ * (indices into queue; the caller seeds entries [head, tail)), on return also [2] = cells popped, [3] = 1 if the queue
+ * would have overflowed (growth stopped early).  Pops at most grow_iterations cells in batches of max_batch (32 in the
+ * reference) with the reference's FIFO order, acceptance rule (density >= thresh and not yet selected), neighbour order
+ * and level rule; byte writes follow the CPU-tensor semantics of the reference's indexed assignment (last one wins). */
+LAE_API int lae_grow_region(uint8_t* grid, const float* density_grid, uint32_t C, uint32_t H, float density_thresh,
+                    uint32_t* queue, uint32_t capacity, uint32_t* state, uint32_t grow_iterations, uint32_t max_batch,
+                    void* stream);
+
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
  *   (renderer.py:580-592).  coords NULL: c = (j / H^2, (j / H) % H, j % H) (full sweep, n <= H^3); else coords [n,3] int32.

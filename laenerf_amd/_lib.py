@@ -71,6 +71,7 @@ SIGNATURES = {
     "lae_style_loss_scratch_bytes": [u32],
     "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp],
     "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
+    "lae_grow_region": [vp, vp, u32, u32, f32, vp, u32, vp, u32, u32, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],

@@ -354,3 +354,42 @@ def mark_untrained_grid(grid, poses, intrinsics, bound, min_near=0.2, filter_clo
     lib().orc_mark_untrained_grid(_p(poses), u32(poses.shape[0]), f32c(fx), f32c(fy), f32c(cx), f32c(cy), u32(g.shape[0]),
                                   u32(H), f32c(bound), f32c(min_near), ctypes.c_int(int(filter_close_point)), _p(g), _p(margin))
     return g, margin
+
+
+# ------------------------------------------------------------------ edit-grid region growing (editing/editgrid.py)
+def grow_region_queue(grid, density_grid, density_thresh, queue, grow_iterations=5000, H=128, max_n=32):
+    """EditGrid.grow_region_queue (editing/editgrid.py:274-340) restated on numpy arrays.
+
+    grid: uint8 [C*H^3/8] selection bitfield (a modified copy is returned); density_grid: float32 [C, H^3] (Morton order);
+    queue: sequence of (x, y, z, level).  Returns (grid, remaining queue as a list, cells popped).
+    The indexed byte assignment of set_edit_bitfield_at (:35-38) has CPU-tensor semantics here: every right-hand side
+    is read before any write and, for duplicate byte indices inside one batch, the last element wins."""
+    from collections import deque
+    grid = np.array(grid, dtype=np.uint8, copy=True)
+    density_grid = _f32(density_grid)
+    V = H ** 3
+    q = deque((int(x), int(y), int(z), int(l)) for x, y, z, l in queue)
+    offs = ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (0, 1, 0), (1, 0, 0))                 # :314-321
+    ctr = 0
+    while ctr < grow_iterations and q:
+        num = min(max_n, len(q), grow_iterations - ctr)                                         # :289
+        batch = [q.popleft() for _ in range(num)]
+        coords = np.array([b[:3] for b in batch], np.int32)
+        lvl = np.array([b[3] for b in batch], np.int64)
+        pos = morton3D(coords).astype(np.int64) % V                                             # :299-301
+        byte = pos // 8 + (V * lvl) // 8
+        bit = pos % 8
+        dens = density_grid[lvl, pos]
+        old = grid[byte]
+        cond = (dens >= density_thresh) & (((old >> bit) & 1) == 0)                             # :303-308
+        if cond.any():
+            new = (old & ~(1 << bit).astype(np.uint8)) | (1 << bit).astype(np.uint8)            # :35-38, value = 1
+            for i in np.nonzero(cond)[0]:                                                       # in order: the last write to a byte stays
+                grid[byte[i]] = new[i]
+            for i in np.nonzero(cond)[0]:
+                for o in offs:
+                    c = coords[i] + np.array(o, np.int32)
+                    if (c >= 0).all() and (c < H).all():                                        # :327-329
+                        q.append((int(c[0]), int(c[1]), int(c[2]), int(lvl[0])))                # :323 level of the batch's first cell
+        ctr += num
+    return grid, list(q), ctr

@@ -377,7 +377,53 @@ def gen_ops():
     save("ops_wrappers", **out)
 
 
+# ---------------------------------------------------------------- K. EditGrid region growing (editing/editgrid.py:80-136, 274-340)
+def gen_editgrid():
+    """the reference's EditGrid.new_from_points + grow_region_queue executed here on CPU tensors (its `_edit_grid`
+    extension is not used by these two methods and is stubbed; morton3D comes from the oracle backend)"""
+    from types import SimpleNamespace
+    sys.modules.setdefault("_edit_grid", types.ModuleType("_edit_grid"))
+    from editing.editgrid import EditGrid
+    H, V = 128, 128 ** 3
+    cases = {}
+    for tag, cascade, bound, seeds, iters in (("c1", 1, 1.0, [[0.02, -0.03, 0.05]], 1500),
+                                              ("c2", 2, 2.0, [[0.4, 0.1, -0.2], [-1.3, 0.2, 0.4]], 900)):
+        rng = np.random.default_rng(len(tag) + cascade)
+        # density: a few blobs per cascade, in Morton order like density_grid
+        c = np.stack(np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+        from oracle import oracle as O
+        midx = O.morton3D(c)
+        dens = np.zeros((cascade, V), np.float32)
+        for cas in range(cascade):
+            b = min(2.0 ** cas, bound)
+            xyz = (2 * (c + 0.5) / H - 1) * b
+            field = np.zeros(V, np.float32)
+            for centre, rad in (((0.0, 0.0, 0.0), 0.18), ((0.4, 0.1, -0.2), 0.15), ((-1.3, 0.2, 0.4), 0.3)):
+                field = np.maximum(field, np.where(np.linalg.norm(xyz - np.array(centre), axis=1) < rad, 15.0 + rng.random(V).astype(np.float32) * 10, 0))
+            dens[cas, midx] = field
+        trainer = SimpleNamespace(model=SimpleNamespace(density_bitfield=torch.zeros(cascade * V // 8, dtype=torch.uint8), cascade=cascade))
+        eg = EditGrid()
+        pts = torch.tensor(seeds, dtype=torch.float32)
+        eg.new_from_points(pts, trainer=trainer, bound=bound)
+        grid0 = eg.grid.numpy().copy()
+        q0 = np.array([[int(v) for v in cc.tolist()] + [int(l)] for cc, l in eg.growing_queue], np.int32)
+        eg.grow_region_queue(torch.from_numpy(dens), 12.0, grow_iterations=iters)
+        q1 = np.array([[int(v) for v in cc.tolist()] + [int(l)] for cc, l in eg.growing_queue], np.int32).reshape(-1, 4)
+        nz = np.nonzero(dens.reshape(-1))[0]
+        cases.update({f"{tag}_pts": np.array(seeds, np.float32), f"{tag}_cascade": cascade, f"{tag}_bound": bound, f"{tag}_iters": iters,
+                      f"{tag}_dens_idx": nz.astype(np.int32), f"{tag}_dens_val": dens.reshape(-1)[nz],
+                      f"{tag}_grid0": np.nonzero(np.unpackbits(grid0, bitorder="little"))[0].astype(np.int32),
+                      f"{tag}_queue0": q0, f"{tag}_grid1": np.nonzero(np.unpackbits(eg.grid.numpy(), bitorder="little"))[0].astype(np.int32),
+                      f"{tag}_queue1": q1})
+        print(tag, "selected", cases[f"{tag}_grid1"].size, "queue", q0.shape[0], "->", q1.shape[0])
+    save("editgrid", **cases)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "editgrid":
+        gen_editgrid()
+        sys.exit(0)
+    gen_editgrid()
     gen_grid_offsets()
     gen_ffmlp_init()
     gen_mlp_chain()

@@ -196,3 +196,28 @@ def test_sample_pdf_matches_reference():
     g = golden("run_upsample")
     s = sample_pdf(torch.from_numpy(g["pdf_bins"]), torch.from_numpy(g["pdf_weights"]), 16, det=True).numpy()
     assert np.allclose(s, g["pdf_samples"], rtol=0, atol=1e-6)
+
+
+def _editgrid_case(g, tag):
+    V = 128 ** 3
+    cascade = int(g[f"{tag}_cascade"])
+    dens = np.zeros(cascade * V, np.float32)
+    dens[g[f"{tag}_dens_idx"]] = g[f"{tag}_dens_val"]
+
+    def bits(idx):
+        b = np.zeros(cascade * V, np.uint8); b[idx] = 1
+        return np.packbits(b, bitorder="little")
+    return dens.reshape(cascade, V), bits(g[f"{tag}_grid0"]), bits(g[f"{tag}_grid1"])
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_grow_region_queue_matches_reference_python(O, tag):
+    """oracle restatement of EditGrid.grow_region_queue vs the reference's own method run on CPU tensors
+    (tests/golden/make_golden.py gen_editgrid): selection bitfield and remaining FIFO contents, exactly"""
+    g = golden("editgrid")
+    dens, grid0, grid1 = _editgrid_case(g, tag)
+    grid, rest, popped = O.grow_region_queue(grid0, dens, 12.0, g[f"{tag}_queue0"], grow_iterations=int(g[f"{tag}_iters"]))
+    assert popped == int(g[f"{tag}_iters"])
+    assert np.array_equal(grid, grid1)
+    assert np.array_equal(np.array(rest, np.int32).reshape(-1, 4), g[f"{tag}_queue1"])
+    assert np.unpackbits(grid1).sum() > np.unpackbits(grid0).sum()
