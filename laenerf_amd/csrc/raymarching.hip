@@ -1324,6 +1324,8 @@ struct FrameHost {                                        // process-wide helper
     static constexpr int NEV = 16;
     hipEvent_t ev_emit[NEV] = {}, ev_look[NEV] = {};
     uint64_t frame_counter = 0;
+    hipStream_t last_stream = nullptr;                    // stream of the previous frame (its tail may still be queued)
+    bool have_last = false;
     bool ok = false;
     bool init() {
         if (ok) return true;
@@ -1376,6 +1378,10 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     if (!g_frame.init()) { lae::set_last_error_str("render_frame: could not create the pinned mirror / side stream / events"); return LAE_ELAUNCH; }
     FrameMirror* mirror_h = g_frame.mirror_h;
     FrameMirror* mirror_d = g_frame.mirror_d;
+    // One mirror / side stream / event ring per process (one process per GPU): frames on the SAME stream are ordered by the
+    // stream itself; a frame on another stream first waits for the previous frame's queued tail.
+    if (g_frame.have_last && g_frame.last_stream != s) (void)hipStreamSynchronize(g_frame.last_stream);
+    g_frame.last_stream = s; g_frame.have_last = true;
     const uint64_t frame_id = ++g_frame.frame_counter;
     const bool overlap = g_frame_overlap != 0;
     hipStream_t ls = overlap ? g_frame.side : s;           // stream of the lookahead marcher

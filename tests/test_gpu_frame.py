@@ -229,3 +229,20 @@ def test_render_frame_argument_errors():
                         enc.per_level_scale, 16, ws, wc)                       # fp32 table
     with pytest.raises(RuntimeError):
         rm.render_frame(*args[:4], r.density_bitfield.cpu(), *args[5:])        # bitfield on the CPU: no fallback
+
+
+def test_frames_on_two_streams():
+    """frames issued from different torch streams share the library's mirror / side stream: the second waits for the first"""
+    net, r = make(bound=1, seed=8)
+    o, d = rays(3000, seed=4)
+    with torch.autocast("cuda", dtype=torch.float16):
+        ref = r.render_eval(o, d, bg_color=1)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for st in (s1, s2, s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(r.render_eval(o, d, bg_color=1))
+        torch.cuda.synchronize()
+    for res in outs:
+        assert np.array_equal(N(res["image"]), N(ref["image"]))
