@@ -972,7 +972,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     c.pad = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *cur = c;
-        mirror->n_alive = c.n_alive; mirror->done = c.done; mirror->total_rows = c.total_rows; mirror->iters = c.iter;
+        mirror->total_rows = c.total_rows; mirror->iters = c.iter; mirror->n_alive = c.n_alive; mirror->done = c.done;   // done last
         __threadfence_system();
         mirror->tag = frame_id;
         for (uint32_t row = c.n_rows; row < ((c.n_rows + 15u) & ~15u); row++) {     // pad rows of the last 16-row MLP tile
@@ -1441,7 +1441,9 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t iters = mirror_h->iters, na = mirror_h->n_alive, dn = mirror_h->done;
         if (iters > seen_iter) seen_iter = iters;
         if (na < bound_alive) bound_alive = na;
-        if (dn) done = true;
+        // the four mirror words are separate stores: n_alive == 0 may be visible before its done flag (the device sets
+        // n_alive to 0 only together with done), and a zero bound would size the next launches to zero workgroups
+        if (dn || na == 0) done = true;
     };
     for (; it <= max_steps && !done; it++) {
         poll();
@@ -1513,8 +1515,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     if (stats_out) {
         // the loop ends either on `done` (mirror holds the final state) or after max_steps + 1 launched iterations
         const auto t0 = std::chrono::steady_clock::now();
-        while (!done) {
-            poll();
+        while (!(mirror_h->tag == frame_id && mirror_h->done)) {     // the done flag is the last word the device writes
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
         }
         stats_out[0] = mirror_h->iters; stats_out[1] = mirror_h->total_rows; stats_out[2] = it;

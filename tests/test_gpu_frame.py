@@ -246,3 +246,23 @@ def test_frames_on_two_streams():
         torch.cuda.synchronize()
     for res in outs:
         assert np.array_equal(N(res["image"]), N(ref["image"]))
+
+
+@pytest.mark.parametrize("kind", ["opaque", "empty"])
+def test_frame_loop_ends_when_every_ray_dies_at_once(kind):
+    """all rays terminate in the first iteration (opaque field) or never find a sample (empty bitfield): n_alive drops to 0
+    in one step. The host must treat an observed n_alive == 0 as the end of the frame even if the done flag of the same
+    mirror update is not visible yet (regression: a zero-workgroup launch, 'invalid configuration argument')"""
+    net, r = make(bound=2, seed=2, table_amp=0.5)
+    if kind == "opaque":
+        net.sigma_net.weights.data.abs_().mul_(8.0)                          # huge densities everywhere
+    else:
+        r.density_bitfield = torch.zeros_like(r.density_bitfield)
+    for n in (64, 300, 2048):
+        o, d = rays(n, seed=n, bound=2)
+        with torch.autocast("cuda", dtype=torch.float16):
+            a = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=False)
+            for rep in range(40):                                            # the race is a matter of timing: many short frames
+                b = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=True, want_stats=(rep % 2 == 0))
+                assert np.array_equal(N(a["image"]), N(b["image"]))
+                assert np.array_equal(N(a["weights_sum"]), N(b["weights_sum"]))

@@ -11,14 +11,17 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def test_student_fits_teacher_scene():
+@pytest.mark.parametrize("bound", [1, 2])
+def test_student_fits_teacher_scene(bound):
+    """bound 2 = two cascades (BASELINE configs[2]-style scenes); its teacher field (a random hash table seen at twice the
+    extent) is fitted with the smaller learning rate: at 1e-2 the student stays at ~15 dB within 200 steps"""
     import fit_scene
     lines = []
-    psnr = fit_scene.fit(steps=200, log=lines.append)
+    psnr = fit_scene.fit(steps=200, log=lines.append, bound=bound, lr=1e-2 if bound == 1 else 2e-3)
     first = float(lines[0].split("loss")[1].split()[0])
     last = float(lines[-2].split("loss")[1].split()[0])
     assert last < 0.05 * first, lines                       # the loss falls by more than an order of magnitude
-    assert psnr > 35.0, lines                                # held-out rays (400 steps reach ~50 dB)
+    assert psnr > (35.0 if bound == 1 else 30.0), lines       # held-out rays (bound 1: 400 steps reach ~50 dB; bound 2: 34.7 dB)
     assert "skipped by the scaler: 0" in lines[-1]
     occ = [float(l.split("occupied")[1]) for l in lines[:-1]]
     assert occ[-1] < occ[0]                                  # the student's occupancy grid culls empty space as it learns
