@@ -73,6 +73,16 @@ LAE_API const char* lae_last_error(void);
 LAE_API int lae_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
                            uint32_t N, float min_near, float* nears, float* fars, void* stream);
 
+/* nerf/utils.py:61-153  get_rays(poses, intrinsics, H, W, N, ...): MI355X-native -- the ray generation of the data loader
+ * (meshgrid + gather + stack + normalise + matmul, ~15 torch launches) as one kernel.  poses [B,4,4] cam2world, row-major;
+ * inds [B,N] int64 flat pixel indices h*W+w with batch stride `inds_batch_stride` elements (0: one index row shared by all
+ * poses, the reference's `inds.expand([B, N])`), or NULL for every pixel in order (then N must equal H*W).  perturb != 0
+ * subtracts (off_x, off_y) from the pixel centre (`perturb_ray_dirs`, :133-136).  rays_o, rays_d [B,N,3].  aabb != NULL
+ * additionally writes the near_far_from_aabb interval (raymarching.cu:91-145) of every ray to nears, fars [B,N]. */
+LAE_API int lae_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                 const int64_t* inds, uint64_t inds_batch_stride, uint32_t N, int perturb, float off_x, float off_y,
+                 float* rays_o, float* rays_d, const float* aabb, float min_near, float* nears, float* fars, void* stream);
+
 /* raymarching.cu:201-209  sph_from_ray(rays_o, rays_d, radius, N, coords[N,2]) */
 LAE_API int lae_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N,
                      float* coords, void* stream);

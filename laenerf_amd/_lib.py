@@ -21,6 +21,7 @@ u32, u64, f32, i32, vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctype
 SIGNATURES = {
     "lae_near_far_from_aabb": [vp, vp, vp, u32, f32, vp, vp, vp],
     "lae_sph_from_ray": [vp, vp, f32, u32, vp, vp],
+    "lae_get_rays": [vp, u32, f32, f32, f32, f32, u32, u32, vp, u64, u32, i32, f32, f32, vp, vp, vp, f32, vp, vp, vp],
     "lae_morton3D": [vp, u32, vp, vp],
     "lae_morton3D_invert": [vp, u32, vp, vp],
     "lae_packbits": [vp, u32, f32, vp, vp],

@@ -84,6 +84,54 @@ __global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __
     coords[2 * (size_t)n + 1] = atan2f(z, x) * RPI;
 }
 
+// ---------------------------------------------------------------- get_rays (nerf/utils.py:61-153)
+// Pinhole rays of B cam2world poses for N pixel indices each (inds == NULL: every pixel in row-major order), optionally
+// with the ray/box interval of K1 in the same pass (aabb != NULL).  The reference builds two H*W meshgrids, gathers them,
+// stacks, normalises and runs a [N,3] x [3,3] matmul per call (~15 launches); pixel centre = index + 0.5 (:82-83).
+__global__ void k_get_rays(const float* __restrict__ poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W,
+                           const int64_t* __restrict__ inds, uint64_t inds_stride, uint32_t N, float off_x, float off_y,
+                           int perturb, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                           const float* __restrict__ aabb, float min_near, float* __restrict__ nears,
+                           float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const float* __restrict__ P = poses + 16 * (size_t)b;
+    const int64_t pix = inds ? inds[(size_t)b * inds_stride + n] : (int64_t)n;
+    float i = (float)(uint32_t)(pix % W) + 0.5f, j = (float)(uint32_t)(pix / W) + 0.5f;
+    if (perturb) { i -= off_x; j -= off_y; }                 // :133-136
+    const float xs = (i - cx) / fx, ys = (j - cy) / fy;      // :138-139 (zs = 1)
+    const float nrm = sqrtf(fmaf(ys, ys, xs * xs) + 1.0f);   // :141
+    const float dx = xs / nrm, dy = ys / nrm, dz = 1.0f / nrm;
+    float d[3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                            // :142 directions @ R^T, :144 translation column
+        d[k] = fmaf(dz, P[4 * k + 2], fmaf(dy, P[4 * k + 1], dx * P[4 * k]));
+        o[k] = P[4 * k + 3];
+    }
+    const size_t r = (size_t)b * N + n;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rays_o[3 * r + k] = o[k]; rays_d[3 * r + k] = d[k]; }
+    if (!aabb) return;
+    const float BIG = 3.402823466e+38f;                      // K1, raymarching.cu:91-145
+    float tn = 0.f, tf = 0.f;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (miss) break;
+        const float rcp = 1.0f / d[a];
+        float lo = (aabb[a] - o[a]) * rcp, hi = (aabb[a + 3] - o[a]) * rcp;
+        if (lo > hi) { float sw = lo; lo = hi; hi = sw; }
+        if (a == 0) { tn = lo; tf = hi; }
+        else {
+            if (tn > hi || lo > tf) { miss = true; }
+            else { if (lo > tn) tn = lo; if (hi < tf) tf = hi; }
+        }
+    }
+    if (miss) { nears[r] = BIG; fars[r] = BIG; return; }
+    if (tn < min_near) tn = min_near;
+    nears[r] = tn; fars[r] = tf;
+}
+
 // ---------------------------------------------------------------- K3 / K4 / K5
 __global__ void k_morton3D(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,6 +1142,18 @@ int lae_near_far_from_aabb(const float* rays_o, const float* rays_d, const float
     if (!rays_o || !rays_d || !aabb || !nears || !fars) return LAE_ENULL;
     k_near_far<<<lae::cdiv(N, 256), 256, 0, STREAM(stream)>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
     return lae::check_launch("near_far_from_aabb");
+}
+
+int lae_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                 const int64_t* inds, uint64_t inds_batch_stride, uint32_t N, int perturb, float off_x, float off_y,
+                 float* rays_o, float* rays_d, const float* aabb, float min_near, float* nears, float* fars, void* stream) {
+    if (N == 0 || B == 0) return LAE_OK;
+    if (!poses || !rays_o || !rays_d) return LAE_ENULL;
+    if (aabb && (!nears || !fars)) return LAE_ENULL;
+    if (H == 0 || W == 0 || B > 65535u || (!inds && (uint64_t)N != (uint64_t)H * W)) return LAE_EINVAL;
+    k_get_rays<<<dim3(lae::cdiv(N, 256), B), 256, 0, STREAM(stream)>>>(poses, B, fx, fy, cx, cy, W, inds, inds_batch_stride, N, off_x,
+                                                                       off_y, perturb, rays_o, rays_d, aabb, min_near, nears, fars);
+    return lae::check_launch("get_rays");
 }
 
 int lae_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {

@@ -122,6 +122,33 @@ ORC_API void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, co
     }
 }
 
+/* nerf/utils.py:61-153 (get_rays): pinhole rays of B cam2world poses for N flat pixel indices each
+ * (inds == NULL: all H*W pixels in order).  Pixel centre = (w + 0.5, h + 0.5) (:82-83), optional offset (:133-136),
+ * camera-space direction ((i-cx)/fx, (j-cy)/fy, 1) normalised (:138-141), rotated by the pose (:142), origin =
+ * translation column (:144).  The reference evaluates this with torch ops (norm / matmul: summation order of the
+ * three terms is the library's), so it pins this restatement to a few ulp, not bit for bit. */
+ORC_API void orc_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W,
+                          const int64_t* inds, uint64_t inds_batch_stride, uint32_t N, int perturb, float off_x,
+                          float off_y, float* rays_o, float* rays_d) {
+    (void)H;
+    for (uint32_t b = 0; b < B; b++) {
+        const float* P = poses + 16 * (size_t)b;
+        for (uint32_t n = 0; n < N; n++) {
+            const int64_t pix = inds ? inds[(size_t)b * inds_batch_stride + n] : (int64_t)n;
+            float i = (float)(uint32_t)(pix % W) + 0.5f, j = (float)(uint32_t)(pix / W) + 0.5f;
+            if (perturb) { i -= off_x; j -= off_y; }
+            const float xs = (i - cx) / fx, ys = (j - cy) / fy;
+            const float nrm = sqrtf(fmaf(ys, ys, xs * xs) + 1.0f);
+            const float dx = xs / nrm, dy = ys / nrm, dz = 1.0f / nrm;
+            const size_t r = (size_t)b * N + n;
+            for (int k = 0; k < 3; k++) {
+                rays_d[3 * r + k] = fmaf(dz, P[4 * k + 2], fmaf(dy, P[4 * k + 1], dx * P[4 * k]));
+                rays_o[3 * r + k] = P[4 * k + 3];
+            }
+        }
+    }
+}
+
 /* raymarching.cu:162-198 (kernel_sph_from_ray): far hit of the ray with the
  * sphere |p| = radius, returned as (theta, phi) scaled to [-1, 1]. */
 ORC_API void orc_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N,

@@ -79,6 +79,26 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     return nears, fars
 
 
+def get_rays(poses, intrinsics, H, W, inds=None, offset=None):
+    """nerf/utils.py:61-153 for given pixel indices: poses [B,4,4], inds None (all pixels) | [N] | [B,N] int64,
+    offset None | (off_x, off_y) (perturb_ray_dirs) -> rays_o, rays_d [B,N,3]"""
+    poses = _f32(poses).reshape(-1, 4, 4)
+    B = poses.shape[0]
+    fx, fy, cx, cy = (float(np.float32(v)) for v in intrinsics)
+    if inds is None:
+        N, ip, stride = H * W, None, 0
+    else:
+        inds = np.ascontiguousarray(inds, dtype=np.int64)
+        N = inds.shape[-1]
+        stride = N if inds.ndim == 2 and inds.shape[0] == B and B > 1 else 0
+        ip = _p(inds)
+    rays_o, rays_d = np.empty((B, N, 3), np.float32), np.empty((B, N, 3), np.float32)
+    ox, oy = (0.0, 0.0) if offset is None else (float(offset[0]), float(offset[1]))
+    lib().orc_get_rays(_p(poses), u32(B), f32c(fx), f32c(fy), f32c(cx), f32c(cy), u32(H), u32(W), ip, ctypes.c_uint64(stride),
+                       u32(N), ctypes.c_int(0 if offset is None else 1), f32c(ox), f32c(oy), _p(rays_o), _p(rays_d))
+    return rays_o, rays_d
+
+
 def sph_from_ray(rays_o, rays_d, radius):
     rays_o, rays_d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
     N = rays_o.shape[0]

@@ -295,6 +295,52 @@ def look_at_poses(n, radius, seed):
     return P
 
 
+def reference_get_rays():
+    """nerf/utils.py cannot be imported here (tensorboardX, cv2, lpips, tinycudann ... are absent), and only two of its
+    functions are needed: `custom_meshgrid` (:43-48) and `get_rays` (:60-153).  They are compiled from the reference file
+    where it lies (nothing is copied) into a namespace that holds what the module itself would have imported for them."""
+    import ast
+    path = os.path.join(REF, "nerf", "utils.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("custom_meshgrid", "get_rays")]
+    assert len(keep) == 2
+    from packaging import version as pver
+    ns = {"torch": torch, "pver": pver}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["get_rays"]
+
+
+def gen_get_rays():
+    get_rays = reference_get_rays()
+    out = {}
+    poses = torch.from_numpy(look_at_poses(3, 3.2, seed=5))
+    for tag, kw in (("all", dict(B=1, H=6, W=5, N=-1, intr=(7.5, 7.0, 2.4, 3.1))),
+                    ("rand", dict(B=2, H=37, W=53, N=64, intr=(60.0, 61.5, 26.5, 18.5))),
+                    ("perturb", dict(B=1, H=9, W=7, N=-1, intr=(11.0, 11.0, 3.5, 4.5), perturb_ray_dirs=True)),
+                    ("patch", dict(B=1, H=40, W=48, N=64, intr=(50.0, 50.0, 24.0, 20.0), patch_size=4)),
+                    ("emap", dict(B=2, H=300, W=200, N=96, intr=(250.0, 250.0, 100.0, 150.0), error_map=True)),
+                    ("lego", dict(B=1, H=800, W=800, N=4096, intr=(1111.111, 1111.111, 400.0, 400.0)))):
+        B, H, W, N, intr = kw["B"], kw["H"], kw["W"], kw["N"], kw["intr"]
+        torch.manual_seed(17)
+        emap = torch.rand(B, 128 * 128) + 0.01 if kw.get("error_map") else None
+        torch.manual_seed(23)
+        res = get_rays(poses[:B], torch.tensor(intr).numpy(), H, W, N, error_map=emap, patch_size=kw.get("patch_size", 1),
+                       perturb_ray_dirs=kw.get("perturb_ray_dirs", False))
+        out[f"{tag}_poses"] = poses[:B].numpy()
+        out[f"{tag}_cfg"] = np.array([H, W, N], np.int64)
+        out[f"{tag}_intr"] = np.array(intr, np.float32)
+        out[f"{tag}_rays_o"] = res["rays_o"].numpy()
+        out[f"{tag}_rays_d"] = res["rays_d"].numpy()
+        if "inds" in res:
+            out[f"{tag}_inds"] = res["inds"].contiguous().numpy()
+        if "inds_coarse" in res:
+            out[f"{tag}_inds_coarse"] = res["inds_coarse"].numpy()
+        if kw.get("perturb_ray_dirs"):
+            torch.manual_seed(23)                     # the only draw of this case: offset = rand(2) - 0.5 (:133)
+            out[f"{tag}_offset"] = (torch.rand(2) - 0.5).numpy()
+    save("get_rays", **out)
+
+
 def gen_density_grid():
     bound, H = 2, 16
     C = 2
@@ -423,6 +469,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "editgrid":
         gen_editgrid()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "get_rays":
+        gen_get_rays()
+        sys.exit(0)
+    gen_get_rays()
     gen_editgrid()
     gen_grid_offsets()
     gen_ffmlp_init()

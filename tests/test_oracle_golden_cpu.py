@@ -221,3 +221,21 @@ def test_grow_region_queue_matches_reference_python(O, tag):
     assert np.array_equal(grid, grid1)
     assert np.array_equal(np.array(rest, np.int32).reshape(-1, 4), g[f"{tag}_queue1"])
     assert np.unpackbits(grid1).sum() > np.unpackbits(grid0).sum()
+
+
+GET_RAYS_CASES = ("all", "rand", "perturb", "patch", "emap", "lego")
+
+
+@pytest.mark.parametrize("tag", GET_RAYS_CASES)
+def test_get_rays_matches_reference(O, tag):
+    """§8f-2: the oracle's get_rays against the reference's own function (nerf/utils.py:61-153, executed by make_golden.py)
+    for every sampling mode: all pixels, random, perturbed centres, patches, error-map, the lego 800x800 batch"""
+    g = golden("get_rays")
+    H, W, N = (int(v) for v in g[f"{tag}_cfg"])
+    inds = g[f"{tag}_inds"] if f"{tag}_inds" in g.files else None
+    off = g[f"{tag}_offset"] if f"{tag}_offset" in g.files else None
+    ro, rd = O.get_rays(g[f"{tag}_poses"], g[f"{tag}_intr"], H, W, inds=inds, offset=off)
+    assert ro.shape == g[f"{tag}_rays_o"].shape and rd.shape == g[f"{tag}_rays_d"].shape
+    assert np.array_equal(ro, g[f"{tag}_rays_o"])                       # origins: a copy of the pose's translation
+    assert np.abs(rd - g[f"{tag}_rays_d"]).max() < 3e-7                  # a few ulp: torch's norm / matmul summation order
+    assert np.abs(np.linalg.norm(rd, axis=-1) - 1).max() < 3e-7
