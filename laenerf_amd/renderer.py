@@ -329,16 +329,26 @@ class NeRFRenderer(nn.Module):
     # ------------------------------------------------------------------ distillation render (renderer.py:394-480)
     @torch.no_grad()
     def render_distill(self, rays_o, rays_d, edit_bitfield, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4,
-                       grow_grid=False, frame_loop=True):
+                       grow_grid=False, frame_loop=True, perturb_depth=False, nears=None):
+        """run_cuda_distill (renderer.py:394-480).  `nears` (optional): the rays' near bounds when the caller already has
+        them (get_rays(aabb=...)); otherwise one near_far_from_aabb call provides `min_near` = nears.min() (:478)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, device = rays_o.shape[0], rays_o.device
         dens = edit_bitfield if grow_grid else self.density_bitfield
+
+        def finish(depth):                                                   # :466-469, :478
+            if perturb_depth:
+                depth = depth + (torch.rand(depth.shape, device=device) - 0.5) * (depth.max() - depth.min()) / max_steps
+            return depth, rays_o + depth[..., None] * rays_d
+
         if frame_loop and self._frame_loop_ok(rays_o):
             res = self._render_frame(rays_o, rays_d, dens, edit_bitfield, None, perturb, dt_gamma, max_steps, T_thresh, False)
-            return {"image": res["image"], "depth": res["depth"], "depth_edit": res["depth_edit"],
-                    "x_term": rays_o + res["depth"][..., None] * rays_d, "weights_edit": res["weights_edit"],
-                    "weights": res["weights_sum"]}
+            if nears is None:
+                nears, _ = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+            depth, x_term = finish(res["depth"])
+            return {"image": res["image"], "depth": depth, "depth_edit": res["depth_edit"], "x_term": x_term,
+                    "weights_edit": res["weights_edit"], "weights": res["weights_sum"], "min_near": nears.min()}
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
         weights_edit_sum = torch.zeros(N, dtype=torch.float32, device=device)
@@ -361,6 +371,6 @@ class NeRFRenderer(nn.Module):
             rays_alive, n_out = raymarching.compact_rays_alive(rays_alive, n_alive)
             n_alive = int(n_out.item())
             step += n_step
-        x_term = rays_o + depth[..., None] * rays_d
+        depth, x_term = finish(depth)
         return {"image": image, "depth": depth, "depth_edit": depth_edit, "x_term": x_term,
-                "weights_edit": weights_edit_sum, "weights": weights_sum}
+                "weights_edit": weights_edit_sum, "weights": weights_sum, "min_near": nears.min()}
