@@ -96,10 +96,13 @@ __device__ __forceinline__ void block_to_level_chunk(uint32_t nb, bool xcd_mode,
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 
-// accumulate r += w * v with the reference's rounding: fp32 -> one FMA (nvcc contraction of
-// `results[ch] += w * grid[..]`), fp16 -> float product and sum, rounded to half (:187)
+// accumulate r += w * v with the reference's rounding (`results[ch] += w * grid[..]`, :187): fp32 -> one FMA (nvcc
+// contraction).  scalar_t = at::Half: `float * Half` is a float, and the only viable `Half += float` is
+// operator+=(Half&, const Half&) -- the product is ROUNDED TO HALF first, then the two halves are added (through float,
+// rounded once: exactly the correctly rounded half sum).  Checked against torch's own Half header: 0 mismatches in 2e6
+// random cases, 15 % mismatches for a model that keeps the product in fp32.
 __device__ __forceinline__ void accum(float& r, float w, float v) { r = fmaf(w, v, r); }
-__device__ __forceinline__ void accum(half_t& r, float w, half_t v) { r = (half_t)((float)r + w * (float)v); }
+__device__ __forceinline__ void accum(half_t& r, float w, half_t v) { r = r + (half_t)(w * (float)v); }
 
 constexpr int GRID_BLOCK = 256;
 
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
                 for (int ch = 0; ch < C; ch++) {
                     if constexpr (sizeof(T) == 2) {
                         const half_t diff = (half_t)((float)tab[ir + ch] - (float)tab[il + ch]);
-                        rg[ch] = (half_t)((float)rg[ch] + w * (float)diff * dfrac[gd]);
+                        rg[ch] = rg[ch] + (half_t)(w * (float)diff * dfrac[gd]);     // Half += float: see accum()
                     } else {
                         rg[ch] += w * (tab[ir + ch] - tab[il + ch]) * dfrac[gd];
                     }

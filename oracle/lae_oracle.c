@@ -529,6 +529,18 @@ static inline cell_t grid_cell(const float* x, uint32_t D, uint32_t level, float
     return c;
 }
 
+
+/* `results[ch] += w * grid[index + ch]` (gridencoder.cu:187) for scalar_t = at::Half: `float * Half` yields a float, and
+ * the only viable `Half += float` is c10's operator+=(Half&, const Half&): the product is converted (rounded) to Half
+ * first, then Half + Half is evaluated through float and rounded once.  tests/test_oracle_properties_cpu.py compiles the
+ * statement itself against torch's Half header and compares it with this function. */
+static inline float half_accum(float r_half_valued, float w, float v_half_valued) {
+    return round_f16(r_half_valued + round_f16(w * v_half_valued));
+}
+ORC_API void orc_half_accum(const uint16_t* r, const float* w, const uint16_t* v, uint16_t* out, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) out[i] = f32_to_f16_bits(half_accum(f16_bits_to_f32(r[i]), w[i], f16_bits_to_f32(v[i])));
+}
+
 /* gridencoder.cu:87-245 (kernel_grid).  f16 != 0: table/outputs/dy_dx are
  * fp16 (uint16 storage) and every accumulation rounds to fp16 like
  * `scalar_t results[C]` does; coordinates stay fp32 (:141).
@@ -557,7 +569,7 @@ ORC_API void orc_grid_encode_forward(const float* inputs, const void* embeddings
                     }
                     uint32_t gi = grid_index(D, C, gridtype, align_corners, 0, c.hashmap_size, c.resolution, pgl);
                     for (uint32_t ch = 0; ch < C; ch++) {
-                        if (f16) res[ch] = round_f16(res[ch] + w * f16_bits_to_f32(eh[tbase + gi + ch]));
+                        if (f16) res[ch] = half_accum(res[ch], w, f16_bits_to_f32(eh[tbase + gi + ch]));
                         else res[ch] = fmaf(w, ef[tbase + gi + ch], res[ch]);
                     }
                 }
@@ -584,7 +596,7 @@ ORC_API void orc_grid_encode_forward(const float* inputs, const void* embeddings
                             if (f16) {
                                 /* half - half -> half, then float * half products, += rounds to half */
                                 float diff = round_f16(f16_bits_to_f32(eh[tbase + ir + ch]) - f16_bits_to_f32(eh[tbase + il + ch]));
-                                rg[ch] = round_f16(rg[ch] + w * diff * c.dfrac[gd]);
+                                rg[ch] = round_f16(rg[ch] + round_f16(w * diff * c.dfrac[gd]));   /* Half += float, see half_accum */
                             } else rg[ch] += w * (ef[tbase + ir + ch] - ef[tbase + il + ch]) * c.dfrac[gd];
                         }
                     }

@@ -279,3 +279,37 @@ def test_freq_encoder_is_the_nerf_positional_encoding(O):
             k = 2.0 ** f
             fd += k * (g[:, D + 2 * D * f: D + 2 * D * f + D] * np.cos(k * xd) - g[:, D + 2 * D * f + D: D + 2 * D * (f + 1)] * np.sin(k * xd))
         assert np.abs(gi - fd).max() < 1e-4 * (1 + np.abs(fd).max())
+
+
+def test_half_accumulate_is_what_c10_half_does(O, tmp_path):
+    """gridencoder.cu:187 `results[ch] += w * grid[index + ch]` with scalar_t = at::Half: the statement itself, compiled
+    against the Half header of the installed torch (the type the reference's AT_DISPATCH instantiates), against the
+    oracle's accumulate primitive -- the float product is rounded to half before the half sum (a model that keeps the
+    product in fp32 differs in ~15 % of random cases)."""
+    import ctypes
+    import os
+    import subprocess
+    import torch
+    inc = os.path.join(os.path.dirname(torch.__file__), "include")
+    src = tmp_path / "half_stmt.cpp"
+    src.write_text('#include <c10/util/Half.h>\n#include <cstdint>\n'
+                   'extern "C" void stmt(const uint16_t* r, const float* w, const uint16_t* g, uint16_t* out, uint64_t n) {\n'
+                   '    for (uint64_t i = 0; i < n; i++) {\n'
+                   '        c10::Half results(r[i], c10::Half::from_bits()), grid(g[i], c10::Half::from_bits());\n'
+                   '        results += w[i] * grid;\n'
+                   '        out[i] = results.x;\n    }\n}\n')
+    so = tmp_path / "half_stmt.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", inc, str(src), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    rng = np.random.default_rng(0)
+    n = 400000
+    r = rng.normal(0, 1, n).astype(np.float16)
+    g = (rng.normal(0, 1, n) * 10.0 ** rng.uniform(-4, 1, n)).astype(np.float16)
+    w = rng.random(n).astype(np.float32)
+    out_ref, out_orc = np.empty(n, np.uint16), np.empty(n, np.uint16)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.stmt(P(r.view(np.uint16)), P(w), P(g.view(np.uint16)), P(out_ref), ctypes.c_uint64(n))
+    O.lib().orc_half_accum(P(r.view(np.uint16)), P(w), P(g.view(np.uint16)), P(out_orc), ctypes.c_uint64(n))
+    assert np.array_equal(out_ref, out_orc)
+    single = (r.astype(np.float32) + w * g.astype(np.float32)).astype(np.float16).view(np.uint16)
+    assert (single != out_ref).mean() > 0.02                 # the two roundings are distinguishable on this sample
