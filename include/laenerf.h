@@ -294,6 +294,11 @@ LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inpu
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
                                      const void* plan, void* stream);
 
+/* MI355X-native, A/B switch of the forward for the hot configuration (fp16 table, D = 3, C = 2, linear, hash type):
+ * 0 (default) = specialised kernel with the cost-balanced level -> XCD schedule, 1 = specialised kernel with level l on
+ * XCD l mod 8, 2 = the generic kernel.  Results are bit-identical in every mode. */
+LAE_API int lae_grid_set_forward_mode(int mode);
+
 /* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
  * 1 = always the generic kernel (one global atomic per corner, what the reference does). */
 LAE_API int lae_grid_set_backward_mode(int mode);

@@ -259,6 +259,113 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
     }
 }
 
+// ---------------------------------------------------------------- K13, hot configuration
+// fp16 table, D = 3, C = 2, linear interpolation, align_corners = false, hash grid type, no dy_dx: every shipped config
+// (grid.py:96-161 defaults under autocast).  Same arithmetic per sample as k_grid_fwd (bit-identical results), but
+//  * the three level kinds are separate, branch-free code paths selected by a block-uniform switch:
+//    hashed with a power-of-two size -- the y / z hash terms cost one multiply + one add each instead of eight
+//    multiplies, byte offsets are formed before the xor (no per-corner shift), whether (x, x+1) share an aligned
+//    8-byte pair is decided once per lane (x even) instead of once per corner row, 32-bit offsets against a uniform
+//    base; dense without wrap-around -- eight plain loads off one base index (the divergent pair path cost more than
+//    it saved: an unaligned 8-byte load is issued as two), no modulo; anything else -- the generic index.
+//    110 VALU instructions per (sample, level) instead of ~200: measured alone on one XCD (tools/ubench/
+//    grid_fwd_variants.hip, 433 k samples) a dense level takes 15.5 us instead of 29, level 11 44 instead of 57.
+//  * work is dealt to the XCDs by a host-built schedule (FwdSched) instead of the fixed (l, l + 8) pairing: a level's
+//    cost is set by its vector-memory instruction issue (coarse levels) or by the L2 request rate of its XCD (fine
+//    levels, one 64-byte sector per (y, z) corner row and sample: ~57 us per level and 433 k samples whatever the
+//    kernel does), so whole hashed levels are packed longest-first and the cheap dense levels (tables <= 0.8 MB, harmless
+//    to replicate in several L2s) fill the gaps in eighths.
+struct FwdSeg { uint32_t level, c0, n; };                  // chunks [c0, c0 + n) of `level`
+constexpr int FWD_MAX_SEG = 12;
+struct FwdSched { uint32_t nseg[8]; FwdSeg seg[8][FWD_MAX_SEG]; };
+
+__global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
+    const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
+    half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
+    const uint32_t* __restrict__ B_dev) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t j = blockIdx.x >> 3, level = 0xffffffffu, chunk = 0;
+    const uint32_t ns = sched.nseg[xcd];
+    for (uint32_t q = 0; q < ns; q++) {
+        const uint32_t n = sched.seg[xcd][q].n;
+        if (j < n) { level = sched.seg[xcd][q].level; chunk = sched.seg[xcd][q].c0 + j; break; }
+        j -= n;
+    }
+    if (level == 0xffffffffu) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    if (B_dev) B = min(B, *B_dev);
+    if (b >= B) return;
+    const LevelInfo<3> li = level_info<3>(sc, offsets, level, 0u, false);
+    const char* __restrict__ tabb = reinterpret_cast<const char*>(grid + (size_t)li.table_off * 2);
+
+    struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+    const F3 in = *reinterpret_cast<const F3*>(inputs + (size_t)b * 3);
+    const float xin[3] = {in.x, in.y, in.z};
+    float fr[3];
+    uint32_t pg[3];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float x01 = (xin[d] + sc.in_shift) * sc.in_scale;
+        oob |= (x01 < 0.0f) | (x01 > 1.0f);
+        const float p = fmaf(x01, li.scale, 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)fl;
+        fr[d] = p - (float)pg[d];
+    }
+    half2_t* out = reinterpret_cast<half2_t*>(outputs + (size_t)b * os_b + (size_t)level * os_l);
+    if (oob) { const half2_t z = {(half_t)0.0f, (half_t)0.0f}; *out = z; return; }   // gridencoder.cu:118-135
+
+    uint32_t cw[8];                                        // corner idx = x + 2y + 4z, two halves each
+    if (li.use_hash && li.pow2) {
+        const uint32_t m4 = (li.hashmap_size - 1u) << 2;
+        const uint32_t hy0 = (pg[1] * 2654435761u) << 2, hy1 = hy0 + (2654435761u << 2);
+        const uint32_t hz0 = (pg[2] * 805459861u) << 2, hz1 = hz0 + (805459861u << 2);
+        const uint32_t x0 = pg[0] << 2, x1 = x0 + 4u;
+        const uint32_t h[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        if ((pg[0] & 1u) == 0 && li.hashmap_size >= 2) {   // idx(x + 1) == idx(x) ^ 1: one aligned 8-byte load per row
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                const uint32_t o0 = (x0 ^ h[yz]) & m4;
+                const uint2 w = *reinterpret_cast<const uint2*>(tabb + (o0 & ~4u));
+                cw[2 * yz] = (o0 & 4u) ? w.y : w.x;
+                cw[2 * yz + 1] = (o0 & 4u) ? w.x : w.y;
+            }
+        } else {
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + ((x0 ^ h[yz]) & m4));
+                cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + ((x1 ^ h[yz]) & m4));
+            }
+        }
+    } else if (!li.use_hash && li.nowrap) {
+        const uint32_t base = (pg[0] + pg[1] * li.stride[1] + pg[2] * li.stride[2]) << 2;     // stride[0] == 1
+        const uint32_t dy = li.stride[1] << 2, dz = li.stride[2] << 2;
+#pragma unroll
+        for (int yz = 0; yz < 4; yz++) {
+            const uint32_t o0 = base + ((yz & 1) ? dy : 0u) + ((yz >> 1) ? dz : 0u);
+            cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + o0);
+            cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + o0 + 4u);
+        }
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t pl[3] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + (idx >> 2)};
+            cw[idx] = *reinterpret_cast<const uint32_t*>(tabb + ((size_t)cell_index<3>(li, pl) << 2));
+        }
+    }
+    half_t r0 = (half_t)0.0f, r1 = (half_t)0.0f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const float w = (((idx & 1) ? fr[0] : 1 - fr[0]) * ((idx & 2) ? fr[1] : 1 - fr[1])) * ((idx & 4) ? fr[2] : 1 - fr[2]);
+        const half2_t v = __builtin_bit_cast(half2_t, cw[idx]);
+        accum(r0, w, v[0]);
+        accum(r1, w, v[1]);
+    }
+    const half2_t h2 = {r0, r1};
+    *out = h2;
+}
+
 // ---------------------------------------------------------------- K14
 // gridencoder.cu:248-340: scatter w*grad into grad_grid.  v1: one no-return atomic per
 // (corner, channel pair): global_atomic_add_f32 / global_atomic_pk_add_f16.
@@ -782,9 +889,92 @@ struct FwdArgs {
     const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
 };
 
+// ---- schedule of k_grid_fwd_lean (see the kernel's header).  Relative cost of one chunk of a level, calibrated on the
+// bench batch (tools/ubench/grid_fwd_variants.hip): dense 1; hashed 1.6 up to resolution ~80, rising with log2(resolution)
+// to 2.85 at ~550 (consecutive samples of a ray stop sharing cache lines) and 4 from ~1000 on (every corner row is its own
+// L2 request).  Only the balance depends on it, never a result.
+static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t L, hipStream_t stream);
+static float fwd_level_cost(bool hashed, uint32_t resolution) {
+    if (!hashed) return 1.0f;
+    const float lr = log2f((float)resolution);
+    if (lr <= 6.3f) return 1.6f;
+    if (lr <= 9.1f) return 1.6f + (lr - 6.3f) * (1.25f / 2.8f);
+    if (lr <= 10.0f) return 2.85f + (lr - 9.1f) * (1.15f / 0.9f);
+    return 4.0f;
+}
+static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // level l on XCD l mod 8, one level at a time
+    for (int x = 0; x < 8; x++) fs.nseg[x] = 0;
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t x = l & 7u;
+        fs.seg[x][fs.nseg[x]++] = FwdSeg{l, 0u, nb};
+    }
+}
+// returns the largest number of blocks any XCD owns
+static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const std::vector<int32_t>* offs) {
+    bool ok = offs != nullptr && L <= 32 && nb >= 64;
+    float cost[MAX_LEVELS]; bool dense[MAX_LEVELS];
+    if (ok) {
+        for (uint32_t l = 0; l < L; l++) {
+            const uint32_t res = (uint32_t)ceilf(sc.scale[l]) + 1;
+            const uint64_t size = (uint64_t)((*offs)[l + 1] - (*offs)[l]);
+            const uint64_t full = (uint64_t)(res + 1) * (res + 1) * (res + 1);
+            dense[l] = full <= size;
+            cost[l] = fwd_level_cost(!dense[l], res);
+        }
+        struct Item { float cost; uint32_t level; bool piece; };
+        std::vector<Item> items;
+        const uint32_t piece = lae::cdiv(nb, 8u);
+        for (uint32_t l = 0; l < L; l++) {
+            if (!dense[l]) items.push_back(Item{cost[l] * nb, l, false});
+            else for (uint32_t k = 0; k < 8 && k * piece < nb; k++) items.push_back(Item{cost[l] * std::min(piece, nb - k * piece), l, true});
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+        float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t pieces[8][MAX_LEVELS] = {};
+        for (int x = 0; x < 8; x++) fs.nseg[x] = 0;
+        for (const Item& it : items) {
+            int best = 0;
+            for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
+            load[best] += it.cost;
+            if (it.piece) pieces[best][it.level]++;
+            else if (fs.nseg[best] < FWD_MAX_SEG) fs.seg[best][fs.nseg[best]++] = FwdSeg{it.level, 0u, nb};
+            else ok = false;
+        }
+        for (uint32_t l = 0; l < L && ok; l++) {
+            if (!dense[l]) continue;
+            uint32_t c0 = 0;
+            for (int x = 0; x < 8; x++) {
+                if (!pieces[x][l]) continue;
+                const uint32_t n = std::min(pieces[x][l] * piece, nb - c0);
+                if (fs.nseg[x] < FWD_MAX_SEG) fs.seg[x][fs.nseg[x]++] = FwdSeg{l, c0, n}; else ok = false;
+                c0 += n;
+            }
+            if (c0 != nb) ok = false;
+        }
+    }
+    if (!ok) fwd_sched_default(fs, L, nb);
+    uint32_t mx = 0;
+    for (int x = 0; x < 8; x++) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < fs.nseg[x]; q++) t += fs.seg[x][q].n;
+        mx = std::max(mx, t);
+    }
+    return mx;
+}
+static int g_fwd_mode = 0;                                 // 0: lean kernel + balanced schedule, 1: lean + (l, l+8) map, 2: generic kernel
+
 template <typename T, int D, int C>
 static void launch_fwd(const FwdArgs& a) {
     const uint32_t nb = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
+    if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
+        if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
+            FwdSched fs;
+            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? host_offsets(a.offsets, a.L, a.stream) : nullptr);
+            k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
+                                                                      fs, a.os_b, a.os_l, a.B_dev);
+            return;
+        }
+    }
     const bool xcd = (a.L % 8) == 0;
     k_grid_fwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
                                                                 a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb,
@@ -1153,6 +1343,12 @@ int lae_grid_encode_backward_planned(const void* grad, const float* inputs, cons
     if (!plan) return LAE_ENULL;
     return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
                          interp, dtype, false, stream, in_shift, in_scale, plan);
+}
+
+int lae_grid_set_forward_mode(int mode) {
+    if (mode < 0 || mode > 2) return LAE_EINVAL;
+    g_fwd_mode = mode;
+    return LAE_OK;
 }
 
 int lae_grid_set_backward_mode(int mode) {

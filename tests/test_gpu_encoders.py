@@ -53,6 +53,39 @@ def test_grid_forward_fp16_bit_exact(O, kw):
     assert np.allclose(N(dd), O.from_f16_bits(ref_dd), rtol=2e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("kw", [dict(scale=0.5), dict(scale=0.5, B=70001), dict(scale=0.5, B=40000, T_log2=14), dict(scale=0.5, L=8, B=20000),
+                                dict(scale=0.5, L=24, desired=8192, B=17000), dict(scale=0.5, B=30000, desired=4096, base=8),
+                                dict(scale=0.5, B=257, L=3), dict(scale=0.5, B=66000, T_log2=21, L=12)])
+def test_grid_forward_hot_configuration_all_modes(O, kw):
+    """fp16 table, D=3, C=2, no dy_dx: the specialised kernel under the balanced schedule (mode 0), under the (l, l+8) map
+    (mode 1) and the generic kernel (mode 2) -- each bit-identical to the oracle, in both output layouts, with and without
+    the coordinate map, including out-of-range inputs and batches smaller than the schedule's granularity"""
+    from laenerf_amd import _lib
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, **kw)
+    L, B, base = offsets.shape[0] - 1, x.shape[0], kw.get("base", 16)
+    th = O.to_f16_bits(table)
+    ref, _ = O.grid_encode_forward(x, th, offsets, pls, base, f16=True)
+    xm = (x * 2 - 1).astype(np.float32)                                   # the same points in [-1, 1]: in_map = (shift 1, scale 0.5)
+    ref_m, _ = O.grid_encode_forward(((xm + np.float32(1.0)) * np.float32(0.5)).astype(np.float32), th, offsets, pls, base, f16=True)
+    try:
+        for mode in (0, 1, 2):
+            assert _lib.load().lae_grid_set_forward_mode(mode) == 0
+            out = torch.full((L, B, 2), 7.0, device=DEV, dtype=torch.half)
+            G.grid_encode_forward(T(x), half_from_bits(th), T(offsets), out, B, 3, 2, L, np.log2(pls), base, None, 0, False, 0)
+            assert np.array_equal(bits_from_half(out), ref), mode
+            out2 = torch.full((B, L * 2), 7.0, device=DEV, dtype=torch.half)
+            G.grid_encode_forward(T(x), half_from_bits(th), T(offsets), out2, B, 3, 2, L, np.log2(pls), base, None, 0, False, 0, blc=True)
+            assert np.array_equal(bits_from_half(out2).reshape(B, L, 2).transpose(1, 0, 2), ref), mode
+            out3 = torch.full((L, B, 2), 7.0, device=DEV, dtype=torch.half)
+            G.grid_encode_forward(T(xm), half_from_bits(th), T(offsets), out3, B, 3, 2, L, np.log2(pls), base, None, 0, False, 0,
+                                  in_map=(1.0, 0.5))
+            assert np.array_equal(bits_from_half(out3), ref_m), mode
+    finally:
+        _lib.load().lae_grid_set_forward_mode(0)
+    assert _lib.load().lae_grid_set_forward_mode(3) == -1
+
+
 @pytest.mark.parametrize("kw", [dict(B=20000), dict(L=4, B=5000), dict(D=2, L=4), dict(C=4, L=8, T_log2=14, desired=512),
                                 dict(C=1, L=8, T_log2=14), dict(gridtype=1, T_log2=15, desired=1024)])
 def test_grid_backward_fp32(O, kw):

@@ -105,13 +105,88 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const float* __restrict__ xyz, co
         for (int idx = 0; idx < 8; idx++) {
             const float w = (((idx & 1) ? fr[0] : 1 - fr[0]) * ((idx & 2) ? fr[1] : 1 - fr[1])) * ((idx & 4) ? fr[2] : 1 - fr[2]);
             const half2_t v = __builtin_bit_cast(half2_t, cw[idx]);
-            r0 = (half_t)((float)r0 + w * (float)v[0]);
-            r1 = (half_t)((float)r1 + w * (float)v[1]);
+            r0 = r0 + (half_t)(w * (float)v[0]);              // Half += float: product rounded to half first (gridencoder.cu:187)
+            r1 = r1 + (half_t)(w * (float)v[1]);
         }
         half2_t h = {r0, r1};
         out[(size_t)level * B + b] = h;
         if (!(VAR & 2)) return;
     }
+}
+
+// VAR 256: lean specialisation -- hashed power-of-two levels: y / z hash terms by one multiply + one add each, byte offsets
+// formed before the xor (no shifts per corner), pairing decided once per lane (x even), 32-bit offsets against a uniform
+// base; dense levels: eight plain loads (no divergent pair path), no modulo.
+__global__ __launch_bounds__(BLOCK) void k_fwd_lean(const float* __restrict__ xyz, const half2_t* __restrict__ grid,
+                                                    const int32_t* __restrict__ offsets, half2_t* __restrict__ out, uint32_t B,
+                                                    Scales sc, LevelMap map, uint32_t nb, uint32_t loops) {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t nlv = map.n[xcd];
+    if (nlv == 0) return;
+    const uint32_t slot = map.interleave ? j % nlv : j / nb;
+    const uint32_t jc = map.interleave ? j / nlv : j % nb;
+    if (slot >= nlv || jc >= nb) return;
+    const uint32_t level = map.lv[xcd][slot];
+    const float scale = sc.scale[level];
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const uint32_t off = (uint32_t)offsets[level], size = (uint32_t)offsets[level + 1] - off;
+    const uint32_t s1 = res + 1, s2 = (res + 1) * (res + 1);
+    const bool hash = (uint64_t)s2 * (res + 1) > size;
+    const char* __restrict__ tabb = reinterpret_cast<const char*>(grid + off);
+    const uint32_t b = jc * BLOCK + threadIdx.x;
+    if (b >= B) return;
+    float fr[3]; uint32_t pg[3];
+    const F3 v3 = *reinterpret_cast<const F3*>(xyz + (size_t)b * 3);
+    const float xin[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float x01 = (xin[d] + 1.0f) * 0.5f;
+        const float p = fmaf(x01, scale, 0.5f);
+        const float fl = floorf(p);
+        pg[d] = (uint32_t)fl;
+        fr[d] = p - fl;
+    }
+    uint32_t cw[8];
+    if (hash) {                                            // size is a power of two on every hashed level of this table
+        const uint32_t m4 = (size - 1u) << 2;
+        const uint32_t hy0 = (pg[1] * 2654435761u) << 2, hy1 = hy0 + (2654435761u << 2);
+        const uint32_t hz0 = (pg[2] * 805459861u) << 2, hz1 = hz0 + (805459861u << 2);
+        const uint32_t x0 = pg[0] << 2, x1 = x0 + 4u;
+        const uint32_t h[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        if ((pg[0] & 1u) == 0) {
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                const uint32_t o0 = (x0 ^ h[yz]) & m4;     // entry of x; x + 1 sits in the other half of the aligned pair
+                const u32x2 w = *reinterpret_cast<const u32x2*>(tabb + (o0 & ~4u));
+                cw[2 * yz] = (o0 & 4u) ? w.y : w.x; cw[2 * yz + 1] = (o0 & 4u) ? w.x : w.y;
+            }
+        } else {
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + ((x0 ^ h[yz]) & m4));
+                cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + ((x1 ^ h[yz]) & m4));
+            }
+        }
+    } else {
+        const uint32_t base = (pg[0] + pg[1] * s1 + pg[2] * s2) << 2;
+        const uint32_t dy = s1 << 2, dz = s2 << 2;
+#pragma unroll
+        for (int yz = 0; yz < 4; yz++) {
+            const uint32_t o0 = base + ((yz & 1) ? dy : 0u) + ((yz >> 1) ? dz : 0u);
+            cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + o0);
+            cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + o0 + 4u);
+        }
+    }
+    half_t r0 = (half_t)0.f, r1 = (half_t)0.f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const float w = (((idx & 1) ? fr[0] : 1 - fr[0]) * ((idx & 2) ? fr[1] : 1 - fr[1])) * ((idx & 4) ? fr[2] : 1 - fr[2]);
+        const half2_t v = __builtin_bit_cast(half2_t, cw[idx]);
+        r0 = r0 + (half_t)(w * (float)v[0]);
+        r1 = r1 + (half_t)(w * (float)v[1]);
+    }
+    half2_t h2 = {r0, r1};
+    out[(size_t)level * B + b] = h2;
 }
 
 static LevelMap map_levels(const std::vector<std::vector<int>>& per_xcd, uint32_t interleave = 0) {
@@ -173,6 +248,7 @@ int main(int argc, char** argv) {
 #define CASE(V) case V: k_fwd<V><<<blocks, BLOCK>>>(d_xyz, d_tab, d_off, dst, B, sc, m, nb, loops); break;
             switch (var) {
                 CASE(0) CASE(1) CASE(2) CASE(4) CASE(8) CASE(12) CASE(16) CASE(32) CASE(64) CASE(128) CASE(140) CASE(142) CASE(204)
+                case 256: k_fwd_lean<<<blocks, BLOCK>>>(d_xyz, d_tab, d_off, dst, B, sc, m, nb, loops); break;
                 default: printf("variant %d not instantiated\n", var); exit(1);
             }
         };
@@ -207,21 +283,17 @@ int main(int argc, char** argv) {
         run(var, m, loops, d_out, name, 16);
         check(name);
     };
-    full(0, map_levels(prod, 1), 1, "prod pairs, INTERLEAVED blocks");
-    full(32, map_levels(prod, 1), 1, "prod pairs, interleaved, never pair");
-    full(2, map_levels(prod, 1), 2, "prod pairs, interleaved, loop 2");
-    { std::vector<std::vector<int>> v(8); for (int x = 0; x < 8; x++) v[x] = {x + 8, x}; full(0, map_levels(v, 1), 1, "(l+8, l) interleaved"); }
-    { std::vector<std::vector<int>> v = {{8, 0, 1}, {9, 2, 3}, {10, 4}, {11, 5}, {12, 6}, {13, 7}, {14}, {15}};
-      full(0, map_levels(v, 1), 1, "{8,0,1},{9,2,3},{10,4},{11,5},{12,6},{13,7},{14},{15} il");
-      full(0, map_levels(v, 0), 1, "same map, sequential"); }
-    { std::vector<std::vector<int>> v = {{8, 0, 1, 2}, {9, 3, 4, 5}, {10, 6}, {11, 7}, {12}, {13}, {14}, {15}};
-      full(0, map_levels(v, 1), 1, "{8,0,1,2},{9,3,4,5},{10,6},{11,7},{12},..,{15} il"); }
-    { std::vector<std::vector<int>> v = {{8, 9}, {0, 1, 2, 3, 4, 5, 6, 7}, {10}, {11}, {12}, {13}, {14}, {15}};
-      full(0, map_levels(v, 1), 1, "{8,9},{0..7},{10},..,{15} il"); }
-    for (int l : {15, 7}) { std::vector<std::vector<int>> v(8); v[7] = {7, 15}; (void)l; }
-    { std::vector<std::vector<int>> v(8); v[7] = {7, 15}; run(0, map_levels(v, 1), 1, d_out, "levels 7+15 on one XCD interleaved", 2); }
-    { std::vector<std::vector<int>> v(8); v[7] = {7, 6, 15}; run(0, map_levels(v, 1), 1, d_out, "levels 6+7+15 on one XCD interleaved", 3); }
-    { std::vector<std::vector<int>> v(8); v[7] = {14, 15}; run(0, map_levels(v, 1), 1, d_out, "levels 14+15 on one XCD interleaved", 2); }
+    full(256, m_prod, 1, "prod map, LEAN kernel");
+    { std::vector<std::vector<int>> v(8); for (int x = 0; x < 8; x++) v[x] = {x + 8, x}; full(0, map_levels(v), 1, "(l+8, l) fine first");
+      full(256, map_levels(v), 1, "(l+8, l) fine first, LEAN"); }
+    for (int var : {0, 256}) {
+        for (int l : {0, 3, 5, 8, 11, 15}) {
+            std::vector<std::vector<int>> v(8); v[l & 7] = {l};
+            char name[64]; snprintf(name, sizeof name, "solo level %d", l);
+            run(var, map_levels(v), 1, d_out, name, 1);
+        }
+    }
+    return 0;
     // solo levels and subsets (time only)
     for (int l = 0; l < 16; l++) {
         std::vector<std::vector<int>> v(8); v[l & 7] = {l};
