@@ -48,6 +48,8 @@ def parse():
                    help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
                         "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
+    p.add_argument("--march-beside", choices=["forward", "backward"], default="backward",
+                   help="pipelined mode: which half of step k the march of step k+1 runs beside")
     p.add_argument("--no-pipeline", action="store_true",
                    help="one graph per step; default: the march of step k+1 (no weight dependence) is its own graph, replayed on a "
                         "side stream beside the shading / backward / optimizer graph of step k")
@@ -252,7 +254,7 @@ def style_step(dev, P=100000, steps=30):
             # recomposition + MSE + weight + offset losses as one node (palette.hip); the palette-only term stays in torch
             loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt)
             loss = loss + opt.scale(m.palet_loss(params))
-        loss.backward()
+        opt.backward(loss)
         opt.step()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -309,6 +311,8 @@ def main():
             args.steps, args.warmup = 20, 3
         return frame_workload(args, world, rank, dev, backend_name)
 
+    if os.environ.get("LAE_BENCH_MAIN_PRIO"):                  # experiment hook: the step's main stream at another priority
+        torch.cuda.stream(torch.cuda.Stream(priority=int(os.environ["LAE_BENCH_MAIN_PRIO"]))).__enter__()
     torch.manual_seed(1234 + rank)
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
     r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
@@ -340,7 +344,7 @@ def main():
             else:
                 res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024)
                 loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], gt))
-        loss.backward()
+        scaler.backward(loss) if fused_loss else loss.backward()
         if not args.no_optimizer and not args.dp:
             if args.torch_optimizer:
                 scaler.step(opt)
@@ -389,7 +393,7 @@ def main():
         raise SystemExit("--dp needs the FusedAdam path")
     pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer and not args.dp
     if not args.no_graph:
-        side = torch.cuda.Stream()
+        side = torch.cuda.Stream(priority=int(os.environ.get("LAE_BENCH_SIDE_PRIO", "0")))
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations, workspaces)
             for _ in range(3):
@@ -426,9 +430,14 @@ def main():
             with torch.cuda.graph(g, pool=g_march[0].pool() if g_march else None):
                 marched.append(r.march_train(batches[b][0], batches[b][1], perturb=True, max_steps=1024, plan_backward=True))
             g_march.append(g)
+        # The rest of the step is two graphs, {encoder, head, compositing + criterion} and {backward, Adam}: the march of the
+        # next step starts beside the SECOND one (LDS- / HBM-bound kernels with idle VALU slots) -- beside the first it
+        # competed with the L2-request-bound encoder for the same wave slots (--march-beside forward: 0.503 ms/step).
+        g_fwd, g_bwd, losses = [], [], []
+        late = args.march_beside == "backward"
         for b in range(n_batches):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=g_rest[0].pool() if g_rest else None):
+            with torch.cuda.graph(g, pool=g_fwd[0].pool() if g_fwd else None):
                 with torch.autocast("cuda", dtype=torch.float16):
                     if fused_loss:
                         res = r.shade_train(marched[b], bg_color=1, gt=batches[b][2], scaler=scaler)
@@ -436,12 +445,16 @@ def main():
                     else:
                         res = r.shade_train(marched[b], bg_color=1)
                         loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], batches[b][2]))
-                loss.backward()
-                opt.step()
                 n_graph_samples.append(res["n_samples"])
-            g_rest.append(g)
-        graph = g_rest[0]
+            g_fwd.append(g); losses.append(loss)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g_fwd[0].pool()):
+                scaler.backward(losses[b]) if fused_loss else losses[b].backward()
+                opt.step()
+            g_bwd.append(g)
+        graph = g_fwd[0]
         ev_march = [torch.cuda.Event() for _ in range(n_batches)]
+        ev_mid = [torch.cuda.Event() for _ in range(n_batches)]
         ev_rest = [torch.cuda.Event() for _ in range(n_batches)]
         state = {"primed": -1}
 
@@ -456,10 +469,16 @@ def main():
                 side.wait_stream(main)
                 launch_march(b)
             main.wait_event(ev_march[b])
-            side.wait_event(ev_rest[(b - 1) % n_batches]) if i > 0 else None   # stay at most one step ahead
-            launch_march(nxt)
+            if not late:
+                side.wait_event(ev_rest[(b - 1) % n_batches]) if i > 0 else None   # stay at most one step ahead
+                launch_march(nxt)
+            g_fwd[b].replay()
+            if late:
+                ev_mid[b].record(main)
+                side.wait_event(ev_mid[b])
+                launch_march(nxt)
             state["primed"] = nxt
-            g_rest[b].replay()
+            g_bwd[b].replay()
             ev_rest[b].record(main)
             return n_graph_samples[b]
         for b in range(n_batches):

@@ -472,6 +472,9 @@ def _wrap_timed(name, fn):
         if not _timing["on"] or (_timing["only"] is not None and name not in _timing["only"]):
             return fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # keep the stream busy while the host enqueues {e0, kernels, e1}: with an idle GPU the interval would also hold
+        # the host's launch latency (Python + ctypes, 5-25 us), which is not kernel time
+        torch.cuda._sleep(_timing.get("sleep_cycles", 150000))
         e0.record()
         r = fn(*a, **k)
         e1.record()

@@ -197,7 +197,7 @@ static LevelMap map_levels(const std::vector<std::vector<int>>& per_xcd, uint32_
 static uint32_t max_slots(const LevelMap& m) { uint32_t s = 0; for (int x = 0; x < 8; x++) s = m.n[x] > s ? m.n[x] : s; return s; }
 
 int main(int argc, char** argv) {
-    const uint32_t T = 1u << 19, H = 16;
+    const uint32_t T = 1u << (argc > 2 ? atoi(argv[2]) : 19), H = 16;
     const float pls = exp2f(log2f(2048.0f / 16.0f) / 15.0f), S = log2f(pls);
     Scales sc; std::vector<int32_t> offs(L + 1); int32_t o = 0;
     for (int l = 0; l < L; l++) {
