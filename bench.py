@@ -547,7 +547,7 @@ def main():
                        "march_pipelined_on_side_stream": bool(pipelined),
                        "parallelism": (f"{world} data-parallel ranks, one flat gradient all-reduce per dtype per step" if args.dp else
                                        f"{world} independent ray-batch replicas (no data-path collective)")},
-            "roofline": {"kernel": "k_grid_fwd (hash-grid encode forward, fp16 table)", "bound": "hbm",
+            "roofline": {"kernel": "k_grid_fwd_lean (hash-grid encode forward, fp16 table)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_sample": GRID_FWD_BYTES_FP16,
