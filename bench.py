@@ -424,7 +424,7 @@ def main():
         # of step k.  The counting half of the hash-grid backward (positions only) rides along in that graph.  Same kernels and the same work per step; the two graph families use separate memory pools because
         # they run concurrently, and every march graph keeps its own output buffers (read by its shading graph).
         main = torch.cuda.current_stream()
-        g_march, g_rest, marched, n_graph_samples = [], [], [], []
+        g_march, marched, n_graph_samples = [], [], []
         for b in range(n_batches):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=g_march[0].pool() if g_march else None):
