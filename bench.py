@@ -48,6 +48,9 @@ def parse():
                    help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
                         "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
+    p.add_argument("--steps-per-graph", type=int, default=4,
+                   help="pipelined mode: consecutive train steps captured into one graph replay (1, 2, 4, 8 or 16; reduced to a "
+                        "divisor of --steps).  A graph boundary costs 15-18 us of device time on this stack")
     p.add_argument("--march-beside", choices=["forward", "backward"], default="backward",
                    help="pipelined mode: which half of step k the march of step k+1 runs beside")
     p.add_argument("--no-pipeline", action="store_true",
@@ -424,7 +427,82 @@ def main():
         # of step k.  The counting half of the hash-grid backward (positions only) rides along in that graph.  Same kernels and the same work per step; the two graph families use separate memory pools because
         # they run concurrently, and every march graph keeps its own output buffers (read by its shading graph).
         main = torch.cuda.current_stream()
-        g_march, marched, n_graph_samples = [], [], []
+        marched, n_graph_samples = [], []
+        G = max(1, min(int(args.steps_per_graph), n_batches))
+        while G > 1 and (args.steps % G or n_batches % G):
+            G //= 2
+        if G > 1:
+            # G consecutive steps per replay: {march(b) ... march(b+G-1)} on the side stream, one group ahead of
+            # {shade, backward, Adam of b; ... of b+G-1} on the main stream.  Every step does exactly the kernels of the
+            # one-step graphs; only the graph boundaries (15-18 us each, profiles/r1m) are shared by G steps.
+            P = n_batches // G
+            g_side = []
+            for p_ in range(P):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=g_side[0].pool() if g_side else None):
+                    for b in range(p_ * G, (p_ + 1) * G):
+                        marched.append(r.march_train(batches[b][0], batches[b][1], perturb=True, max_steps=1024, plan_backward=True))
+                g_side.append(g)
+            g_main = []
+            for p_ in range(P):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=g_main[0].pool() if g_main else None):
+                    for b in range(p_ * G, (p_ + 1) * G):
+                        with torch.autocast("cuda", dtype=torch.float16):
+                            if fused_loss:
+                                res = r.shade_train(marched[b], bg_color=1, gt=batches[b][2], scaler=scaler)
+                                loss = res["loss"]
+                            else:
+                                res = r.shade_train(marched[b], bg_color=1)
+                                loss = scaler.scale(torch.nn.functional.mse_loss(res["image"], batches[b][2]))
+                        scaler.backward(loss) if fused_loss else loss.backward()
+                        opt.step()
+                        n_graph_samples.append(res["n_samples"])
+                g_main.append(g)
+            graph = g_main[0]
+            ev_side = [torch.cuda.Event() for _ in range(P)]
+            ev_main = [torch.cuda.Event() for _ in range(P)]
+            state = {"primed": -1}
+
+            def launch_side(p_):
+                with torch.cuda.stream(side):
+                    g_side[p_].replay()
+                    ev_side[p_].record(side)
+
+            A = 2 if P >= 4 else 1                            # side groups kept this far ahead of the main stream
+
+            def step(i):                                    # noqa: F811
+                b = i % n_batches
+                if b % G:                                   # this step rides in the replay issued at the group's first step
+                    return n_graph_samples[b]
+                p_ = b // G
+                if state["primed"] != p_:                   # first group after a break in the sequence: marches in line
+                    side.wait_stream(main)
+                    for a in range(A):
+                        launch_side((p_ + a) % P)
+                # With the side stream two groups ahead, the marches of this group finished while the host was still
+                # enqueuing the previous group, so the main stream usually needs NO cross-stream wait: its graphs queue up
+                # back to back.  (A wait on a not yet signalled event of another stream costs ~50 us at every boundary.)
+                if not ev_side[p_].query():
+                    main.wait_event(ev_side[p_])
+                g_main[p_].replay()
+                ev_main[p_].record(main)
+                nxt = (p_ + A) % P
+                # buffers of group `nxt` were last read by the main graph of that group one cycle ago (its event still holds
+                # that record: this cycle's replay of it is not enqueued yet)
+                side.wait_event(ev_main[nxt]) if i >= G else None
+                launch_side(nxt)
+                state["primed"] = (p_ + 1) % P
+                return n_graph_samples[b]
+            for p_ in range(P):
+                ev_main[p_].record(main)
+            first = ((n_warm + G - 1) // G) * G - 2 * G      # whole groups, ending right before the first timed step
+            n_warm = first + 2 * G
+            for i in range(first, n_warm):
+                step(i)
+            torch.cuda.synchronize()
+    if pipelined and G == 1:
+        g_march = []
         for b in range(n_batches):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=g_march[0].pool() if g_march else None):
@@ -469,17 +547,13 @@ def main():
                 side.wait_stream(main)
                 launch_march(b)
             main.wait_event(ev_march[b])
-            if not late:
-                side.wait_event(ev_rest[(b - 1) % n_batches]) if i > 0 else None   # stay at most one step ahead
-                launch_march(nxt)
-            g_fwd[b].replay()
-            if late:
-                ev_mid[b].record(main)
-                side.wait_event(ev_mid[b])
-                launch_march(nxt)
-            state["primed"] = nxt
+            g_fwd[b].replay()                               # main first, see the grouped path
+            ev_mid[b].record(main)
             g_bwd[b].replay()
             ev_rest[b].record(main)
+            side.wait_event(ev_mid[b] if late else ev_rest[(b - 1) % n_batches]) if (late or i > 0) else None
+            launch_march(nxt)
+            state["primed"] = nxt
             return n_graph_samples[b]
         for b in range(n_batches):
             ev_rest[b].record(main)
@@ -544,7 +618,7 @@ def main():
                        "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
                        "optimizer_in_timed_region": not args.no_optimizer,
                        "hip_graph_replay": bool(graph),
-                       "march_pipelined_on_side_stream": bool(pipelined),
+                       "march_pipelined_on_side_stream": bool(pipelined), "steps_per_graph_replay": (G if pipelined else 1),
                        "parallelism": (f"{world} data-parallel ranks, one flat gradient all-reduce per dtype per step" if args.dp else
                                        f"{world} independent ray-batch replicas (no data-path collective)")},
             "roofline": {"kernel": "k_grid_fwd_lean (hash-grid encode forward, fp16 table)", "bound": "hbm",
