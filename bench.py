@@ -48,7 +48,7 @@ def parse():
                    help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
                         "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
-    p.add_argument("--steps-per-graph", type=int, default=4,
+    p.add_argument("--steps-per-graph", type=int, default=8,
                    help="pipelined mode: consecutive train steps captured into one graph replay (1, 2, 4, 8 or 16; reduced to a "
                         "divisor of --steps).  A graph boundary costs 15-18 us of device time on this stack")
     p.add_argument("--march-beside", choices=["forward", "backward"], default="backward",
@@ -329,7 +329,7 @@ def main():
         from laenerf_amd.optim import FusedAdam
         opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     fused_loss = not args.torch_loss and not args.torch_optimizer
-    n_batches = 16
+    n_batches = 16 if args.steps_per_graph <= 4 else 32      # resident ray batches; >= 4 groups of --steps-per-graph steps
     batches = []
     for b in range(n_batches):
         # one training view per step, random pixels of it: what the reference's loader does (DataLoader batch_size = 1,
