@@ -353,11 +353,11 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
 // slabs of 45 KB); the 16 partial sums are combined in a fixed tree.
 // accumulate != 0: gw += sum (the optimizer's persistent gradient buffer) instead of gw = sum.
 constexpr int DWR_GROUPS = 16;
-__global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
-                                                               half_t* __restrict__ gw, int accumulate = 0) {
+__device__ __forceinline__ void dw_reduce_body(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW, half_t* __restrict__ gw,
+                                               int accumulate, uint32_t block) {
     __shared__ float part[DWR_GROUPS][64];
     const uint32_t e = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * 64 + e;
+    const uint32_t i = block * 64 + e;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (i < nW) {
         uint32_t k = sg;
@@ -379,6 +379,18 @@ __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __re
             for (int u = 0; u < w; u++) t[u] = t[u] + t[u + w];
         gw[i] = accumulate ? (half_t)((float)gw[i] + t[0]) : (half_t)t[0];
     }
+}
+__global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
+                                                               half_t* __restrict__ gw, int accumulate = 0) {
+    dw_reduce_body(slabs, n_slices, nW, gw, accumulate, blockIdx.x);
+}
+// the same reduction for two networks in one launch (blocks [0, nb_a) reduce A, the rest B): one graph node less per step
+__global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce2(const float* __restrict__ slabs_a, uint32_t n_a, uint32_t nW_a,
+                                                                half_t* __restrict__ gw_a, const float* __restrict__ slabs_b,
+                                                                uint32_t n_b, uint32_t nW_b, half_t* __restrict__ gw_b,
+                                                                uint32_t nb_a, int accumulate) {
+    if (blockIdx.x < nb_a) dw_reduce_body(slabs_a, n_a, nW_a, gw_a, accumulate, blockIdx.x);
+    else dw_reduce_body(slabs_b, n_b, nW_b, gw_b, accumulate, blockIdx.x - nb_a);
 }
 
 // ---------------------------------------------------------------- fused NeRF head (network_ff.py:51-81 in one kernel)
@@ -994,7 +1006,9 @@ int g_bwd_fused_variant = 0;
 
 template <int IN, int NH, int MODE = 0>
 int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
-                     HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0) {
+                     HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0, float* slabs = nullptr, uint32_t* n_slices_out = nullptr) {
+    // slabs != nullptr: the partial slabs go to the caller's region (room for 2 * num_cus slices) and the reduction is
+    // left to the caller (lae_nerf_head_backward reduces both networks in one launch)
     const uint32_t nW = 64 * (IN + 64 * NH + 16);
     const uint32_t n_tiles = B / 16;
     uint32_t blocks;
@@ -1010,7 +1024,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
             attr_set = true;
         }
         blocks = std::max(1u, std::min(lae::cdiv(n_tiles, WAVES), (uint32_t)lae::num_cus() * 2));
-        ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_coop<IN, NH, MODE, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     } else {
@@ -1023,11 +1037,12 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
             attr_set = true;
         }
         blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
-        ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     }
-    k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
+    if (n_slices_out) *n_slices_out = blocks;
+    if (!slabs) k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
     return LAE_OK;
 }
 
@@ -1374,12 +1389,22 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
     HeadBwdArgs ha{dirs, rgbs, grad_rgbs, grad_sigmas, density_scale, 0};
     HeadBwdArgs hs{};
     hs.level_major = enc_level_major;
+    // partial slabs of both networks side by side in the workspace, reduced by ONE launch after the second backward kernel
+    const uint32_t nW_c = 64 * (32 + 128 + 16), nW_s = 64 * (32 + 64 + 16);
+    const size_t cap = (size_t)lae::num_cus() * 2;
+    float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, cap * (nW_c + nW_s) * sizeof(float)));
+    if (!ws) return LAE_ELAUNCH;
+    float* ws_s = ws + cap * nW_c;
+    uint32_t n_c = 0, n_s = 0;
     int rc = launch_bwd_fused<32, 2, 1>(nullptr, (const half_t*)h, (const half_t*)color_weights, M, (half_t*)grad_h,
-                                        (half_t*)grad_color_weights, s, ha, accumulate_weight_grads);
+                                        (half_t*)grad_color_weights, s, ha, accumulate_weight_grads, ws, &n_c);
     if (rc != LAE_OK) return rc;
     rc = launch_bwd_fused<32, 1, 0>((const half_t*)grad_h, (const half_t*)enc, (const half_t*)sigma_weights, M, (half_t*)grad_enc,
-                                    (half_t*)grad_sigma_weights, s, hs, accumulate_weight_grads);
+                                    (half_t*)grad_sigma_weights, s, hs, accumulate_weight_grads, ws_s, &n_s);
     if (rc != LAE_OK) return rc;
+    const uint32_t nb_c = lae::cdiv(nW_c, 64u), nb_s = lae::cdiv(nW_s, 64u);
+    k_dw_reduce2<<<nb_c + nb_s, 64 * DWR_GROUPS, 0, s>>>(ws, n_c, nW_c, (half_t*)grad_color_weights, ws_s, n_s, nW_s,
+                                                        (half_t*)grad_sigma_weights, nb_c, accumulate_weight_grads);
     return lae::check_launch("nerf_head_backward");
 }
 
