@@ -13,6 +13,7 @@
 // reference evaluates exp2f per thread, gridencoder.cu:138) and passed by value;
 // the oracle uses the same host libm, so fp32 results are bit-identical to it.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
@@ -890,17 +891,17 @@ struct FwdArgs {
 };
 
 // ---- schedule of k_grid_fwd_lean (see the kernel's header).  Relative cost of one chunk of a level, calibrated on the
-// bench batch (tools/ubench/grid_fwd_variants.hip): dense 1; hashed 1.6 up to resolution ~80, rising with log2(resolution)
-// to 2.85 at ~550 (consecutive samples of a ray stop sharing cache lines) and 4 from ~1000 on (every corner row is its own
-// L2 request).  Only the balance depends on it, never a result.
+// bench batches (tools/ubench/grid_fwd_variants.hip, then a sweep with tools/grid_fwd_bench.py on one-view and 16-view
+// batches): dense 1; hashed 1.25 up to resolution ~80, rising with log2(resolution) to 2.3 at ~550 (consecutive samples of a
+// ray stop sharing cache lines) and 4.5 from ~1000 on (every corner row is its own L2 request).  Only the balance depends on it, never a result.
 static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t L, hipStream_t stream);
 static float fwd_level_cost(bool hashed, uint32_t resolution) {
     if (!hashed) return 1.0f;
     const float lr = log2f((float)resolution);
-    if (lr <= 6.3f) return 1.6f;
-    if (lr <= 9.1f) return 1.6f + (lr - 6.3f) * (1.25f / 2.8f);
-    if (lr <= 10.0f) return 2.85f + (lr - 9.1f) * (1.15f / 0.9f);
-    return 4.0f;
+    if (lr <= 6.3f) return 1.25f;
+    if (lr <= 9.1f) return 1.25f + (lr - 6.3f) * (1.05f / 2.8f);
+    if (lr <= 10.0f) return 2.3f + (lr - 9.1f) * (2.2f / 0.9f);
+    return 4.5f;
 }
 static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // level l on XCD l mod 8, one level at a time
     for (int x = 0; x < 8; x++) fs.nseg[x] = 0;

@@ -7,7 +7,7 @@ from laenerf_amd.gridencoder import GridEncoder
 from laenerf_amd import raymarching as rm
 from laenerf_amd.backend import gridencoder_backend as G
 dev = "cuda:0"
-o, d = S.lego_like_rays(4096, seed=0)
+o, d = S.lego_like_rays(4096, seed=0, n_views=int(os.environ.get('VIEWS', '16')))
 bits = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
 to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 n, f = rm.near_far_from_aabb(to, td, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
