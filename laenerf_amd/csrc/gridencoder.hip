@@ -695,8 +695,10 @@ __global__ __launch_bounds__(256) void k_bin_scan_blocks(uint32_t* __restrict__ 
 }
 
 // bucket totals -> exclusive offsets (global item index).  One small block.
-__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t n) {
+__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t n,
+                                                   uint32_t* __restrict__ tickets) {
     __shared__ uint32_t lds[17];
+    if (threadIdx.x < 2) tickets[threadIdx.x] = 0;          // work queue of the accumulate pass starts empty-handed
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -720,7 +722,7 @@ template <typename T>
 __global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
     bool align_corners, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
-    const HItem<T>* __restrict__ queue) {
+    const HItem<T>* __restrict__ queue, uint32_t* __restrict__ tickets) {
     constexpr bool HALF = sizeof(T) == 2;
     constexpr uint32_t SHIFT = HShift<T>::value, PART = 1u << SHIFT;
     __shared__ unsigned long long acc64[16384];         // 128 KiB: int64[8192][2] (fp16 grads) or float2[16384]
@@ -737,7 +739,16 @@ __global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
     __syncthreads();
     uint32_t total = 0;
     for (uint32_t l = 0; l < L; l++) total += s_cnt[l];
-    for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
+    // Buckets are handed out through one device-side counter, finest levels (the full queues) first: with the static
+    // round-robin deal 788 buckets over 256 workgroups meant 3 buckets for most and 4 for some, of very different sizes.
+    __shared__ uint32_t s_ticket;
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(&tickets[0], 1u);
+        __syncthreads();
+        const uint32_t t = s_ticket;
+        __syncthreads();
+        if (t >= total) break;
+        const uint32_t item = total - 1u - t;
         uint32_t level = 0, bk = item;
         while (bk >= s_cnt[level]) { bk -= s_cnt[level]; level++; }
         const uint32_t SUB = s_sub[level], p = bk / SUB;
@@ -794,6 +805,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
         }
         __syncthreads();
     }
+    if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) { tickets[0] = 0; tickets[1] = 0; }   // last one out resets
 }
 
 // [L][B][2] -> [B][L][2] through an LDS tile: the gather kernel writes level-major (each level's block stores 256
@@ -1129,18 +1141,19 @@ static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t
 // {bucket totals | bucket offsets | per-block exclusive counts}; EXEC (fill + accumulate) needs the gradients.  A caller
 // may run PLAN early -- e.g. right after the march, beside the forward pass (lae_grid_encode_backward_plan) -- the default
 // entry points run both back to back in the library workspace.
-static inline size_t bin_tab_bytes(uint32_t L) { return (((size_t)2 * L * BK_MAX * 4 + 255) / 256) * 256; }
+static inline size_t bin_tab_bytes(uint32_t L) { return (((size_t)2 * L * BK_MAX * 4 + 255) / 256) * 256 + 256; }   // + {ticket, done} of k_bin_acc
 static inline size_t bin_plan_bytes(uint32_t B, uint32_t L) {
     const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
     return bin_tab_bytes(L) + (((size_t)nb * L * BK_MAX * 4 + 255) / 256) * 256;
 }
-struct BinPlan { uint32_t* counts; uint32_t* offs; uint32_t* block_counts; };
+struct BinPlan { uint32_t* counts; uint32_t* offs; uint32_t* block_counts; uint32_t* tickets; };
 static inline BinPlan bin_plan_at(void* buf, uint32_t L) {
     uint8_t* p = reinterpret_cast<uint8_t*>(buf);
     BinPlan bp;
     bp.counts = reinterpret_cast<uint32_t*>(p);
     bp.offs = bp.counts + (size_t)L * BK_MAX;
     bp.block_counts = reinterpret_cast<uint32_t*>(p + bin_tab_bytes(L));
+    bp.tickets = reinterpret_cast<uint32_t*>(p + bin_tab_bytes(L) - 256);
     return bp;
 }
 
@@ -1151,7 +1164,7 @@ static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, ui
     k_bin<T, false><<<nb * L, BIN_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
                                                         bp.block_counts, bp.offs, nullptr);
     k_bin_scan_blocks<<<lae::cdiv(n_tab, 4), 256, 0, a.stream>>>(bp.block_counts, bp.counts, L, nb);
-    k_bin_scan<<<1, 1024, 0, a.stream>>>(bp.counts, bp.offs, (uint32_t)n_tab);
+    k_bin_scan<<<1, 1024, 0, a.stream>>>(bp.counts, bp.offs, (uint32_t)n_tab, bp.tickets);
 }
 
 template <typename T>
@@ -1162,7 +1175,8 @@ static int bwd_exec(const void* gT, const float* inputs, const int32_t* offsets,
     const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
     k_bin<T, true><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
                                                        bp.block_counts, bp.offs, queue);
-    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, bp.counts, bp.offs, queue);
+    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, bp.counts, bp.offs, queue,
+                                                                        bp.tickets);
     // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel; skipped when the host copy of
     // the level sizes shows that no level needs it
     bool need_generic = true;
