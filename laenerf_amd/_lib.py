@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "liblaenerf_hip.so")
+SO_PATH = os.environ.get("LAE_HIP_LIB") or os.path.join(_HERE, "lib", "liblaenerf_hip.so")   # LAE_HIP_LIB: A/B against another build
 
 u32, u64, f32, i32, vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p
 
