@@ -14,7 +14,10 @@ SO = os.path.join(LIBDIR, "liblaenerf_hip.so")
 SOURCES = ["raymarching.hip", "gridencoder.hip", "shencoder.hip", "freqencoder.hip", "ffmlp.hip", "densitygrid.hip", "optimizer.hip", "loss.hip", "palette.hip", "editgrid.hip", "lae_common.cpp"]
 # -ffp-contract=off: only explicit fmaf() fuses -> bit-identical sample indices/positions vs the oracle
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         # MFMA accumulators in VGPRs: with the default AGPR form every accumulator tile is copied back with
+         # v_accvgpr_read before the VALU epilogue (88 copies per 16-row tile in the fused head, 1036 -> 940 instructions)
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _deps():
