@@ -294,6 +294,13 @@ LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inpu
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
                                      const void* plan, void* stream);
 
+/* Host-only helper (no GPU call; used by the CPU tests): the level -> XCD schedule of the specialised forward for a table
+ * with the given level offsets (HOST pointer, L + 1 ints) and `n_chunks` 256-sample chunks.  nseg_out[8]; segs_out[8][12][3] =
+ * (level, first chunk, chunk count) per XCD in execution order.  Returns the largest number of workgroups any XCD owns
+ * (the launch is 8 x that), or a negative error code. */
+LAE_API int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks,
+                              uint32_t* nseg_out, uint32_t* segs_out);
+
 /* MI355X-native, A/B switch of the forward for the hot configuration (fp16 table, D = 3, C = 2, linear, hash type):
  * 0 (default) = specialised kernel with the cost-balanced level -> XCD schedule, 1 = specialised kernel with level l on
  * XCD l mod 8, 2 = the generic kernel.  Results are bit-identical in every mode. */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grid_set_forward_mode": [i32],
+    "lae_grid_forward_schedule": [vp, u32, f32, u32, u32, vp, vp],
     "lae_grad_total_variation": [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, i32, i32, vp],
     "lae_sh_encode_forward": [vp, vp, u32, u32, u32, vp, vp],
     "lae_sh_encode_backward": [vp, vp, u32, u32, u32, vp, vp, vp],

@@ -1385,6 +1385,24 @@ int lae_grid_encode_backward_planned(const void* grad, const float* inputs, cons
                          interp, dtype, false, stream, in_shift, in_scale, plan);
 }
 
+int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks, uint32_t* nseg_out,
+                              uint32_t* segs_out) {
+    if (!offsets_host || !nseg_out || !segs_out) return LAE_ENULL;
+    LevelScales sc;
+    if (fill_scales(sc, L, S, H) != LAE_OK || L > 8 * FWD_MAX_SEG) return LAE_EINVAL;
+    const std::vector<int32_t> offs(offsets_host, offsets_host + L + 1);
+    FwdSched fs;
+    const uint32_t per_xcd = fwd_sched_build(fs, L, n_chunks, sc, &offs);
+    for (int x = 0; x < 8; x++) {
+        nseg_out[x] = fs.nseg[x];
+        for (uint32_t q = 0; q < fs.nseg[x]; q++) {
+            uint32_t* o = segs_out + ((size_t)x * FWD_MAX_SEG + q) * 3;
+            o[0] = fs.seg[x][q].level; o[1] = fs.seg[x][q].c0; o[2] = fs.seg[x][q].n;
+        }
+    }
+    return (int)per_xcd;
+}
+
 int lae_grid_set_forward_mode(int mode) {
     if (mode < 0 || mode > 2) return LAE_EINVAL;
     g_fwd_mode = mode;

@@ -93,3 +93,39 @@ def test_synthetic_generators_are_seeded():
     assert np.allclose(np.linalg.norm(d1, axis=-1), 1, atol=1e-6)
     o, d = S.frame_rays(8, 8)
     assert o.shape == (64, 3) and d.shape == (64, 3)
+
+
+def test_grid_forward_schedule_covers_every_chunk_once_and_balances(hip_lib):
+    """host logic of the specialised grid forward (no GPU needed): every (level, chunk) appears in exactly one segment, no XCD
+    holds more than 12 segments, whole hashed levels stay on one XCD (their table lives in that XCD's L2), and the
+    modelled cost is balanced; small launches fall back to level l on XCD l mod 8"""
+    import ctypes
+    from laenerf_amd.gridencoder.grid import level_offsets
+    for L, log2_T, desired, nb in ((16, 19, 2048, 973), (16, 19, 4096, 8100), (8, 14, 512, 300), (24, 19, 8192, 700), (16, 19, 2048, 12)):
+        pls = np.exp2(np.log2(desired / 16) / (L - 1))
+        offs = level_offsets(3, L, pls, 16, log2_T, False)
+        nseg = (ctypes.c_uint32 * 8)()
+        segs = (ctypes.c_uint32 * (8 * 12 * 3))()
+        per_xcd = hip_lib.lae_grid_forward_schedule(offs.ctypes.data_as(ctypes.c_void_p), L, ctypes.c_float(np.log2(pls)), 16, nb, nseg, segs)
+        assert per_xcd > 0
+        seen = np.zeros((L, nb), np.int32)
+        owners = [set() for _ in range(L)]
+        blocks = []
+        for x in range(8):
+            assert nseg[x] <= 12
+            tot = 0
+            for q in range(nseg[x]):
+                lvl, c0, n = segs[(x * 12 + q) * 3], segs[(x * 12 + q) * 3 + 1], segs[(x * 12 + q) * 3 + 2]
+                seen[lvl, c0:c0 + n] += 1
+                owners[lvl].add(x)
+                tot += n
+            blocks.append(tot)
+        assert (seen == 1).all()
+        assert max(blocks) == per_xcd
+        res = [int(np.ceil(16 * pls ** l)) for l in range(L)]
+        hashed = [(res[l] + 1) ** 3 > offs[l + 1] - offs[l] for l in range(L)]
+        assert all(len(owners[l]) == 1 for l in range(L) if hashed[l])
+        if nb < 64:                                                        # fallback map
+            assert all(owners[l] == {l % 8} for l in range(L))
+        elif L == 16:
+            assert any(len(owners[l]) > 1 for l in range(L) if not hashed[l])   # dense levels are dealt out in pieces
