@@ -329,7 +329,7 @@ def main():
         from laenerf_amd.optim import FusedAdam
         opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     fused_loss = not args.torch_loss and not args.torch_optimizer
-    n_batches = 16 if args.steps_per_graph <= 4 else 32      # resident ray batches; >= 4 groups of --steps-per-graph steps
+    n_batches = max(16, 4 * min(int(args.steps_per_graph), 16))   # resident ray batches: >= 4 groups of --steps-per-graph steps
     batches = []
     for b in range(n_batches):
         # one training view per step, random pixels of it: what the reference's loader does (DataLoader batch_size = 1,
@@ -428,7 +428,7 @@ def main():
         # they run concurrently, and every march graph keeps its own output buffers (read by its shading graph).
         main = torch.cuda.current_stream()
         marched, n_graph_samples = [], []
-        G = max(1, min(int(args.steps_per_graph), n_batches))
+        G = max(1, min(int(args.steps_per_graph), 16))
         while G > 1 and (args.steps % G or n_batches % G):
             G //= 2
         if G > 1:
