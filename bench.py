@@ -314,8 +314,6 @@ def main():
             args.steps, args.warmup = 20, 3
         return frame_workload(args, world, rank, dev, backend_name)
 
-    if os.environ.get("LAE_BENCH_MAIN_PRIO"):                  # experiment hook: the step's main stream at another priority
-        torch.cuda.stream(torch.cuda.Stream(priority=int(os.environ["LAE_BENCH_MAIN_PRIO"]))).__enter__()
     torch.manual_seed(1234 + rank)
     net = NeRFNetwork(bound=1).to(dev)                        # L=16, T=2^19, F=2; FFMLP 2x64 / 3x64
     r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev)
@@ -396,7 +394,7 @@ def main():
         raise SystemExit("--dp needs the FusedAdam path")
     pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer and not args.dp
     if not args.no_graph:
-        side = torch.cuda.Stream(priority=int(os.environ.get("LAE_BENCH_SIDE_PRIO", "0")))
+        side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations, workspaces)
             for _ in range(3):
