@@ -1,0 +1,35 @@
+"""-m gpu: bench.py keeps the driver's contract -- one JSON line on stdout with the agreed keys, the roofline and cpu_baseline
+objects, exactly K timed steps -- on a shortened run (small CPU-baseline sample, no frame / style extras)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "3", "--cpu-rays", "4096",
+                          "--no-frame", "--no-style"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "Mrays/s" and j["n_gpus"] == 1 and j["steps"] == 24 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 4096 / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["bytes_per_sample"] * r["samples_per_launch"] / r["avg_launch_us"] / 1e3) < 0.02 * r["achieved"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert j["value"] > 100 * c["value"]
