@@ -244,3 +244,48 @@ def test_freq_encoder(O, D, deg):
     assert out.dtype == torch.float32 and out.shape == (x.shape[0], 1, dim)
     with pytest.raises(RuntimeError):
         freq_encode(torch.zeros(4, D), deg, D + 2 * D * deg)                     # CPU tensor: no fallback
+
+
+def test_grid_backward_plan_can_be_executed_twice(O):
+    """a plan (counting pass + scans) serves any number of fill / accumulate executions: the accumulate pass hands its
+    buckets out through a ticket that the last workgroup resets, so a second execution on the same plan must find it
+    cleared and add the same gradient again"""
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, B=30000)
+    B, L, C = x.shape[0], offsets.shape[0] - 1, 2
+    g = (np.random.default_rng(7).standard_normal((L, B, C)) * 1e-2).astype(np.float32)
+    gh = half_from_bits(O.to_f16_bits(g))
+    S_ = np.log2(pls)
+    plan = G.grid_backward_plan(T(x), T(offsets), B, 3, 2, L, S_, 16, 0, False, 0, True)
+    once = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    G.grid_encode_backward(gh, T(x), None, T(offsets), once, B, 3, C, L, S_, 16, None, None, 0, False, 0, plan=plan)
+    twice = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    for _ in range(2):
+        G.grid_encode_backward(gh, T(x), None, T(offsets), twice, B, 3, C, L, S_, 16, None, None, 0, False, 0, plan=plan)
+    hashed = int(offsets[5])
+    assert float(once[hashed:].float().abs().sum()) > 0
+    # the second execution adds the same exact per-partition sums on top of the first (one fp16 rounding of a + a = exact)
+    assert torch.equal(twice[hashed:], (once[hashed:].float() * 2).half())
+
+
+def test_fused_adam_backward_helper_equals_loss_backward():
+    """FusedAdam.backward(loss) = loss.backward() without autograd's ones_like fill: same gradients"""
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=14).to(DEV)
+    net.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    opt = FusedAdam(net, param_groups=net.get_params(1e-2))
+    x = torch.rand(4096, 3, device=DEV) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(4096, 3, device=DEV), dim=-1)
+    grads = []
+    for helper in (False, True):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, color = net(x, d)
+            loss = opt.scale((color.float() ** 2).mean() + 1e-3 * sigma.float().mean())
+        opt.backward(loss) if helper else loss.backward()
+        grads.append([m.shadow.grad_half.clone() for m in (net.encoder, net.sigma_net, net.color_net)])
+    assert float(grads[0][0].float().abs().sum()) > 0
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
