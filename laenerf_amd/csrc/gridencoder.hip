@@ -250,7 +250,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
                         const half_t diff = (half_t)((float)tab[ir + ch] - (float)tab[il + ch]);
                         rg[ch] = rg[ch] + (half_t)(w * (float)diff * dfrac[gd]);     // Half += float: see accum()
                     } else {
-                        rg[ch] += w * (tab[ir + ch] - tab[il + ch]) * dfrac[gd];
+                        rg[ch] = fmaf(w * (tab[ir + ch] - tab[il + ch]), dfrac[gd], rg[ch]);   // `+=` of a product: nvcc contracts (:236)
                     }
                 }
             }
@@ -859,7 +859,7 @@ __global__ void k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict
             const T gv = grad[(size_t)b * gs_b + (size_t)l * gs_l + ch];
             const T dv = dd[(size_t)l * D * C + d * C + ch];
             if constexpr (sizeof(T) == 2) r = (half_t)((float)r + (float)(half_t)((float)gv * (float)dv));
-            else r += gv * dv;
+            else r = fmaf(gv, dv, r);
         }
     grad_inputs[t] = r;
 }

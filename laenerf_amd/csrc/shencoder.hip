@@ -62,7 +62,7 @@ __global__ void k_sh_bwd(const float* __restrict__ grad, uint32_t B, uint32_t C2
     const float* g = grad + (size_t)b * C2;
     const float* dd = dy_dx + (size_t)b * 3 * C2 + (size_t)d * C2;
     float r = grad_inputs[t];
-    for (uint32_t ch = 0; ch < C2; ch++) r += g[ch] * dd[ch];
+    for (uint32_t ch = 0; ch < C2; ch++) r = fmaf(g[ch], dd[ch], r);     // shencoder.cu:378 `+=` of a product
     grad_inputs[t] = r;
 }
 

@@ -25,6 +25,26 @@ def lego_like_rays(n_rays, H=800, W=800, focal=1111.1, radius=4.03 * 0.8, seed=0
     return cam[view].astype(np.float32), d.astype(np.float32)
 
 
+def flower_like_rays(n_rays, H=756, W=1008, focal=890.0, seed=0, n_views=34, spread=0.06, z_cam=1.5):
+    """llff/flower-shaped batch (scripts/configs_llff/flower.sh: bound 2, pose scale 0.02, offset (0, 0, 1.5), min_near
+    0.2): forward-facing cameras INSIDE the bound-2 box, a few centimetres apart around (0, 0, z_cam), all looking down -z
+    at the scene near the origin; n_rays random pixels of random views (nerf/utils.py:108)."""
+    rng = np.random.default_rng(seed)
+    view = rng.integers(0, n_views, n_rays)
+    cam = np.stack([rng.uniform(-spread, spread, n_views), rng.uniform(-spread, spread, n_views),
+                    z_cam + rng.uniform(-0.01, 0.01, n_views)], -1)
+    fwd = -cam / np.linalg.norm(cam, axis=-1, keepdims=True)            # converge on the origin (llff captures do, roughly)
+    up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up); right /= np.linalg.norm(right, axis=-1, keepdims=True)
+    upv = np.cross(right, fwd)
+    pix = rng.integers(0, H * W, n_rays)
+    x = ((pix % W).astype(np.float64) + 0.5 - W / 2) / focal
+    y = -((pix // W).astype(np.float64) + 0.5 - H / 2) / focal
+    d = fwd[view] + x[:, None] * right[view] + y[:, None] * upv[view]
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return cam[view].astype(np.float32), d.astype(np.float32)
+
+
 def frame_rays(H, W, focal=None, radius=4.03 * 0.8, theta=1.0, phi=0.7):
     """all H*W rays of one view (full-frame inference, cfg4-style)"""
     focal = focal if focal is not None else 1111.1 * W / 800
@@ -69,6 +89,25 @@ def sphere_density_grid(cascade=1, bound=1.0, H=128, radius=0.6, value=20.0, box
         if boxes:
             occ |= (np.abs(xs - 0.55) < 0.2) & (np.abs(ys + 0.3) < 0.25) & (np.abs(zs) < 0.15)
             occ |= (np.abs(xs + 0.5) < 0.12) & (np.abs(ys - 0.45) < 0.3) & (np.abs(zs - 0.4) < 0.3)
+        grid[c, occ] = value
+    return grid
+
+
+def flower_density_grid(H=128, value=20.0):
+    """occupancy for the flower-shaped batches (bound 2 -> 2 cascades, renderer.py:74): a blob at the origin (cascade 0
+    and 1), two petals, and a wall behind it at z in [-1.7, -1.4] that only the outer cascade can hold."""
+    cx, cy, cz = _morton_inverse_table(H)
+    grid = np.zeros((2, H ** 3), dtype=np.float32)
+    for c in range(2):
+        b = float(2 ** c)
+        half = b / H
+        xs = (2 * (cx.astype(np.float32) + 0.5) / H - 1) * b
+        ys = (2 * (cy.astype(np.float32) + 0.5) / H - 1) * b
+        zs = (2 * (cz.astype(np.float32) + 0.5) / H - 1) * b
+        occ = xs * xs + ys * ys + zs * zs < (0.45 + half) ** 2
+        occ |= (np.abs(xs - 0.5) < 0.25) & (np.abs(ys - 0.2) < 0.08) & (np.abs(zs - 0.1) < 0.3)
+        occ |= (np.abs(xs + 0.4) < 0.08) & (np.abs(ys + 0.5) < 0.3) & (np.abs(zs) < 0.25)
+        occ |= (zs > -1.7) & (zs < -1.4) & (np.abs(xs) < 1.8) & (np.abs(ys) < 1.8)
         grid[c, occ] = value
     return grid
 

@@ -28,9 +28,18 @@
  *
  * Floating-point policy: the reference is compiled by nvcc, which contracts
  * a*b+c into one FMA.  Every place where the reference source has that shape is
- * written here as an explicit fmaf(); the file is compiled with
- * -ffp-contract=off so nothing else fuses.  The HIP kernels follow the same
- * rule, which makes sample counts / offsets / positions bit-identical.
+ * written here as FMA(a, b, c); the file is compiled with -ffp-contract=off so
+ * nothing else fuses.  The HIP kernels follow the same rule, which makes sample
+ * counts / offsets / positions bit-identical.
+ *
+ * TWO FLAVOURS (SURVEY.md section 7 "Hard parts", raymarching.cu:345-398): nvcc's
+ * contraction choices are a model, not an observation (the reference cannot run
+ * here).  Built with -DORC_NO_FMA every FMA(a, b, c) is the two-rounding a*b+c
+ * instead (liblae_oracle_nofma.so).  tests/test_oracle_flavours_cpu.py checks
+ * that every INTEGER output of the path (rays, counter, alive lists, edit_occ,
+ * Morton codes, bitfields) is identical under both flavours on the march
+ * fixtures and that positions differ by at most 1 ulp: the bit-exactness claims
+ * for indices therefore do not depend on the contraction model.
  */
 #include <math.h>
 #include <stdint.h>
@@ -38,6 +47,19 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
+
+#ifdef ORC_NO_FMA
+#define FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+ORC_API int orc_flavour_fma(void) {
+#ifdef ORC_NO_FMA
+    return 0;
+#else
+    return 1;
+#endif
+}
 
 static inline float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 static inline float signf_(float x) { return copysignf(1.0f, x); }
@@ -138,11 +160,11 @@ ORC_API void orc_get_rays(const float* poses, uint32_t B, float fx, float fy, fl
             float i = (float)(uint32_t)(pix % W) + 0.5f, j = (float)(uint32_t)(pix / W) + 0.5f;
             if (perturb) { i -= off_x; j -= off_y; }
             const float xs = (i - cx) / fx, ys = (j - cy) / fy;
-            const float nrm = sqrtf(fmaf(ys, ys, xs * xs) + 1.0f);
+            const float nrm = sqrtf(FMA(ys, ys, xs * xs) + 1.0f);
             const float dx = xs / nrm, dy = ys / nrm, dz = 1.0f / nrm;
             const size_t r = (size_t)b * N + n;
             for (int k = 0; k < 3; k++) {
-                rays_d[3 * r + k] = fmaf(dz, P[4 * k + 2], fmaf(dy, P[4 * k + 1], dx * P[4 * k]));
+                rays_d[3 * r + k] = FMA(dz, P[4 * k + 2], FMA(dy, P[4 * k + 1], dx * P[4 * k]));
                 rays_o[3 * r + k] = P[4 * k + 3];
             }
         }
@@ -245,9 +267,9 @@ typedef struct { float x, y, z, dt, tt; uint32_t index; int occ; } probe_t;
 
 static inline probe_t marcher_probe(const marcher_t* m, float t) {
     probe_t p;
-    p.x = clampf(fmaf(t, m->dx, m->ox), -m->bound, m->bound);      /* :361-363 */
-    p.y = clampf(fmaf(t, m->dy, m->oy), -m->bound, m->bound);
-    p.z = clampf(fmaf(t, m->dz, m->oz), -m->bound, m->bound);
+    p.x = clampf(FMA(t, m->dx, m->ox), -m->bound, m->bound);      /* :361-363 */
+    p.y = clampf(FMA(t, m->dy, m->oy), -m->bound, m->bound);
+    p.z = clampf(FMA(t, m->dz, m->oz), -m->bound, m->bound);
     p.dt = clampf(t * m->dt_gamma, m->dt_min, m->dt_max);          /* :365 */
     float amax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
     int lp = level_of(amax, m->Cf);
@@ -258,9 +280,9 @@ static inline probe_t marcher_probe(const marcher_t* m, float t) {
     /* :374-376  (int) clamp(0.5 * (x * rbound + 1) * H, 0, H-1); the double
      * product of the reference rounds to the same float as (0.5f*v)*H */
     float hm1 = (float)(m->H - 1);
-    int nx = (int)clampf((0.5f * fmaf(p.x, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
-    int ny = (int)clampf((0.5f * fmaf(p.y, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
-    int nz = (int)clampf((0.5f * fmaf(p.z, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
+    int nx = (int)clampf((0.5f * FMA(p.x, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
+    int ny = (int)clampf((0.5f * FMA(p.y, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
+    int nz = (int)clampf((0.5f * FMA(p.z, mip_rbound, 1.0f)) * m->Hf, 0.0f, hm1);
     p.index = (uint32_t)level * m->H * m->H * m->H + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
     p.occ = (m->grid[p.index >> 3] >> (p.index & 7u)) & 1;         /* :378-379 */
     if (!p.occ) {                                                  /* :390-394 */
@@ -268,9 +290,9 @@ static inline probe_t marcher_probe(const marcher_t* m, float t) {
         float ax = (float)nx + 0.5f + 0.5f * signf_(m->dx);
         float ay = (float)ny + 0.5f + 0.5f * signf_(m->dy);
         float az = (float)nz + 0.5f + 0.5f * signf_(m->dz);
-        float tx = fmaf((ax * m->rH) * 2 - 1, mip_bound, -p.x) * m->rdx;
-        float ty = fmaf((ay * m->rH) * 2 - 1, mip_bound, -p.y) * m->rdy;
-        float tz = fmaf((az * m->rH) * 2 - 1, mip_bound, -p.z) * m->rdz;
+        float tx = FMA((ax * m->rH) * 2 - 1, mip_bound, -p.x) * m->rdx;
+        float ty = FMA((ay * m->rH) * 2 - 1, mip_bound, -p.y) * m->rdy;
+        float tz = FMA((az * m->rH) * 2 - 1, mip_bound, -p.z) * m->rdz;
         p.tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     } else p.tt = t;
     return p;
@@ -296,7 +318,7 @@ ORC_API void orc_march_rays_train(const float* rays_o, const float* rays_d, cons
         marcher_init(&m, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, bound, dt_gamma, max_steps, C, H, grid);
         const float near = nears[n], far = fars[n], noise = noises[n];
         float t0 = near;
-        t0 = fmaf(clampf(t0 * dt_gamma, m.dt_min, m.dt_max), noise, t0);          /* :351 */
+        t0 = FMA(clampf(t0 * dt_gamma, m.dt_min, m.dt_max), noise, t0);          /* :351 */
 
         float t = t0;
         uint32_t num_steps = 0;
@@ -352,7 +374,7 @@ ORC_API void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* ra
         uint8_t* pe = edit_occ ? edit_occ + (size_t)n * n_step : NULL;
         float t = rays_t[index];
         const float far = fars[index];
-        t = fmaf(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);          /* :746 */
+        t = FMA(clampf(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);          /* :746 */
         float last_t = t;
         uint32_t step = 0;
         while (t < far && step < n_step) {
@@ -388,9 +410,9 @@ ORC_API void orc_composite_rays_train_forward(const float* sigmas, const float* 
             for (uint32_t k = 0; k < num_steps; k++) {
                 float alpha = 1.0f - expf(-s[k] * dl[2 * k]);
                 float w = alpha * T;
-                r = fmaf(w, c[3 * k], r); g = fmaf(w, c[3 * k + 1], g); b = fmaf(w, c[3 * k + 2], b);
+                r = FMA(w, c[3 * k], r); g = FMA(w, c[3 * k + 1], g); b = FMA(w, c[3 * k + 2], b);
                 t += dl[2 * k + 1];
-                d = fmaf(w, t, d);
+                d = FMA(w, t, d);
                 ws += w;
                 T *= 1.0f - alpha;
                 if (T < T_thresh) break;                                           /* :557 (after accumulating) */
@@ -425,14 +447,14 @@ ORC_API void orc_composite_rays_train_backward(const float* grad_weights_sum, co
         for (uint32_t k = 0; k < num_steps; k++) {
             float alpha = 1.0f - expf(-s[k] * dl[2 * k]);
             float w = alpha * T;
-            r = fmaf(w, c[3 * k], r); g = fmaf(w, c[3 * k + 1], g); b = fmaf(w, c[3 * k + 2], b);
+            r = FMA(w, c[3 * k], r); g = FMA(w, c[3 * k + 1], g); b = FMA(w, c[3 * k + 2], b);
             ws += w;
             T *= 1.0f - alpha;
             gc[3 * k] = gi[0] * w; gc[3 * k + 1] = gi[1] * w; gc[3 * k + 2] = gi[2] * w;    /* :657-659 */
-            gs[k] = dl[2 * k] * (gi[0] * (T * c[3 * k] - (rf - r)) +                  /* :662-667 */
-                                 gi[1] * (T * c[3 * k + 1] - (gf - g)) +
-                                 gi[2] * (T * c[3 * k + 2] - (bf - b)) +
-                                 gws * (1 - wsf));
+            /* :662-667: a left-to-right sum of four products; nvcc contracts each `+ x*y` into the running sum and
+             * each `T*c - (..)` into one FMA (same policy as the forward paths) */
+            const float x0 = FMA(T, c[3 * k], -(rf - r)), x1 = FMA(T, c[3 * k + 1], -(gf - g)), x2 = FMA(T, c[3 * k + 2], -(bf - b));
+            gs[k] = dl[2 * k] * FMA(gws, 1 - wsf, FMA(gi[2], x2, FMA(gi[1], x1, gi[0] * x0)));
             if (T < T_thresh) break;
         }
         (void)ws;
@@ -465,10 +487,10 @@ ORC_API void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thres
             float T = 1 - ws;
             float w = alpha * T;
             ws += w;
-            if (eo && eo[step]) { wse += w; de = fmaf(w, t, de); }
+            if (eo && eo[step]) { wse += w; de = FMA(w, t, de); }
             t += dl[2 * step + 1];
-            d = fmaf(w, t, d);
-            r = fmaf(w, c[3 * step], r); g = fmaf(w, c[3 * step + 1], g); b = fmaf(w, c[3 * step + 2], b);
+            d = FMA(w, t, d);
+            r = FMA(w, c[3 * step], r); g = FMA(w, c[3 * step + 1], g); b = FMA(w, c[3 * step + 2], b);
             if (T < T_thresh) break;                                               /* :1012 */
             step++;
         }
@@ -515,10 +537,10 @@ static inline cell_t grid_cell(const float* x, uint32_t D, uint32_t level, float
     cell_t c; c.oob = 0;
     for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) c.oob = 1;
     c.hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
-    c.scale = fmaf(exp2f((float)level * S), (float)H, -1.0f);                      /* :138 */
+    c.scale = FMA(exp2f((float)level * S), (float)H, -1.0f);                      /* :138 */
     c.resolution = (uint32_t)ceilf(c.scale) + 1;
     for (uint32_t d = 0; d < D; d++) {
-        float p = fmaf(x[d], c.scale, align_corners ? 0.0f : 0.5f);               /* :148 */
+        float p = FMA(x[d], c.scale, align_corners ? 0.0f : 0.5f);               /* :148 */
         float fl = floorf(p);
         c.pg[d] = (uint32_t)fl;
         p -= (float)c.pg[d];
@@ -570,7 +592,7 @@ ORC_API void orc_grid_encode_forward(const float* inputs, const void* embeddings
                     uint32_t gi = grid_index(D, C, gridtype, align_corners, 0, c.hashmap_size, c.resolution, pgl);
                     for (uint32_t ch = 0; ch < C; ch++) {
                         if (f16) res[ch] = half_accum(res[ch], w, f16_bits_to_f32(eh[tbase + gi + ch]));
-                        else res[ch] = fmaf(w, ef[tbase + gi + ch], res[ch]);
+                        else res[ch] = FMA(w, ef[tbase + gi + ch], res[ch]);
                     }
                 }
             }
@@ -597,7 +619,7 @@ ORC_API void orc_grid_encode_forward(const float* inputs, const void* embeddings
                                 /* half - half -> half, then float * half products, += rounds to half */
                                 float diff = round_f16(f16_bits_to_f32(eh[tbase + ir + ch]) - f16_bits_to_f32(eh[tbase + il + ch]));
                                 rg[ch] = round_f16(rg[ch] + round_f16(w * diff * c.dfrac[gd]));   /* Half += float, see half_accum */
-                            } else rg[ch] += w * (ef[tbase + ir + ch] - ef[tbase + il + ch]) * c.dfrac[gd];
+                            } else rg[ch] = FMA(w * (ef[tbase + ir + ch] - ef[tbase + il + ch]), c.dfrac[gd], rg[ch]);   /* :236 `+=` of a product */
                         }
                     }
                 }
@@ -652,7 +674,7 @@ ORC_API void orc_grid_encode_backward(const void* grad, const float* inputs, con
                 size_t gidx = grad_blc ? ((size_t)b * L + l) * C + ch : ((size_t)l * B + b) * C + ch;
                 size_t didx = (size_t)b * L * D * C + (size_t)l * D * C + d * C + ch;
                 if (f16) r = round_f16(r + round_f16(f16_bits_to_f32(gh[gidx]) * f16_bits_to_f32(dh[didx])));
-                else r += gf[gidx] * df[didx];
+                else r = FMA(gf[gidx], df[didx], r);                                /* :362 */
             }
             if (f16) gih[(size_t)b * D + d] = f32_to_f16_bits(r); else gif[(size_t)b * D + d] = r;
         }
@@ -667,7 +689,7 @@ ORC_API void orc_grad_total_variation(const float* inputs, const float* embeddin
     for (uint32_t level = 0; level < L; level++) {
         const size_t tbase = (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
-        const float scale = fmaf(exp2f((float)level * S), (float)H, -1.0f);
+        const float scale = FMA(exp2f((float)level * S), (float)H, -1.0f);
         const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
         for (uint32_t b = 0; b < B; b++) {
             const float* x = inputs + (size_t)b * D;
@@ -675,7 +697,7 @@ ORC_API void orc_grad_total_variation(const float* inputs, const float* embeddin
             for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
             if (oob) continue;
             uint32_t pg[5];
-            for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)floorf(fmaf(x[d], scale, align_corners ? 0.0f : 0.5f));
+            for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)floorf(FMA(x[d], scale, align_corners ? 0.0f : 0.5f));
             float res[8] = {0}, idelta[8] = {0};
             uint32_t index = grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pg);
             float w = weight / (float)(2 * D);
@@ -792,7 +814,7 @@ ORC_API void orc_sh_encode_backward(const float* grad, uint32_t B, uint32_t D, u
     const uint32_t C2 = C * C;
     for (uint32_t b = 0; b < B; b++) for (uint32_t d = 0; d < D; d++) {
         float r = grad_inputs[(size_t)b * D + d];
-        for (uint32_t ch = 0; ch < C2; ch++) r += grad[(size_t)b * C2 + ch] * dy_dx[(size_t)b * D * C2 + d * C2 + ch];
+        for (uint32_t ch = 0; ch < C2; ch++) r = FMA(grad[(size_t)b * C2 + ch], dy_dx[(size_t)b * D * C2 + d * C2 + ch], r);
         grad_inputs[(size_t)b * D + d] = r;
     }
 }
@@ -885,7 +907,7 @@ ORC_API void orc_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, 
         for (uint32_t l = 0; l < num_layers; l++) {
             for (uint32_t o = 0; o < hidden; o++) {
                 float acc = 0;
-                for (uint32_t k = 0; k < K; k++) acc = fmaf(cur[k], Wl[(size_t)o * K + k], acc);
+                for (uint32_t k = 0; k < K; k++) acc = FMA(cur[k], Wl[(size_t)o * K + k], acc);
                 nxt[o] = round_f16(act_fwd(activation, acc));
             }
             if (forward_buffer)
@@ -896,7 +918,7 @@ ORC_API void orc_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, 
         }
         for (uint32_t o = 0; o < out_dim; o++) {
             float acc = 0;
-            for (uint32_t k = 0; k < hidden; k++) acc = fmaf(cur[k], Wl[(size_t)o * hidden + k], acc);
+            for (uint32_t k = 0; k < hidden; k++) acc = FMA(cur[k], Wl[(size_t)o * hidden + k], acc);
             outputs[(size_t)b * out_dim + o] = f32_to_f16_bits(act_fwd(output_activation, acc));
         }
     }
@@ -924,10 +946,10 @@ ORC_API void orc_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, co
         for (uint32_t o = 0; o < out_dim; o++) g[o] = f16_bits_to_f32(grad[(size_t)b * out_dim + o]);
         for (uint32_t o = 0; o < out_dim; o++)
             for (uint32_t k = 0; k < hidden; k++)
-                dW[off_out + (size_t)o * hidden + k] = fmaf(g[o], f16_bits_to_f32(hlast[k]), dW[off_out + (size_t)o * hidden + k]);
+                dW[off_out + (size_t)o * hidden + k] = FMA(g[o], f16_bits_to_f32(hlast[k]), dW[off_out + (size_t)o * hidden + k]);
         for (uint32_t k = 0; k < hidden; k++) {
             float acc = 0;
-            for (uint32_t o = 0; o < out_dim; o++) acc = fmaf(g[o], W[off_out + (size_t)o * hidden + k], acc);
+            for (uint32_t o = 0; o < out_dim; o++) acc = FMA(g[o], W[off_out + (size_t)o * hidden + k], acc);
             gp[k] = round_f16(act_bwd(activation, acc, f16_bits_to_f32(hlast[k])));
         }
         for (uint32_t k = 0; k < hidden; k++) backward_buffer[((size_t)0 * B + b) * hidden + k] = f32_to_f16_bits(gp[k]);
@@ -937,10 +959,10 @@ ORC_API void orc_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, co
             const uint16_t* hin = forward_buffer + ((size_t)(l - 1) * B + b) * hidden;
             for (uint32_t o = 0; o < hidden; o++)
                 for (uint32_t k = 0; k < hidden; k++)
-                    dW[offW + (size_t)o * hidden + k] = fmaf(gp[o], f16_bits_to_f32(hin[k]), dW[offW + (size_t)o * hidden + k]);
+                    dW[offW + (size_t)o * hidden + k] = FMA(gp[o], f16_bits_to_f32(hin[k]), dW[offW + (size_t)o * hidden + k]);
             for (uint32_t k = 0; k < hidden; k++) {
                 float acc = 0;
-                for (uint32_t o = 0; o < hidden; o++) acc = fmaf(gp[o], W[offW + (size_t)o * hidden + k], acc);
+                for (uint32_t o = 0; o < hidden; o++) acc = FMA(gp[o], W[offW + (size_t)o * hidden + k], acc);
                 g[k] = round_f16(act_bwd(activation, acc, f16_bits_to_f32(hin[k])));
             }
             memcpy(gp, g, sizeof(float) * hidden);
@@ -950,11 +972,11 @@ ORC_API void orc_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, co
         /* input layer */
         for (uint32_t o = 0; o < hidden; o++)
             for (uint32_t k = 0; k < in_dim; k++)
-                dW[(size_t)o * in_dim + k] = fmaf(gp[o], f16_bits_to_f32(inputs[(size_t)b * in_dim + k]), dW[(size_t)o * in_dim + k]);
+                dW[(size_t)o * in_dim + k] = FMA(gp[o], f16_bits_to_f32(inputs[(size_t)b * in_dim + k]), dW[(size_t)o * in_dim + k]);
         if (calc_grad_inputs && grad_inputs) {
             for (uint32_t k = 0; k < in_dim; k++) {
                 float acc = 0;
-                for (uint32_t o = 0; o < hidden; o++) acc = fmaf(gp[o], W[(size_t)o * in_dim + k], acc);
+                for (uint32_t o = 0; o < hidden; o++) acc = FMA(gp[o], W[(size_t)o * in_dim + k], acc);
                 grad_inputs[(size_t)b * in_dim + k] = f32_to_f16_bits(acc);
             }
         }

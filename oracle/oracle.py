@@ -16,24 +16,49 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblae_oracle.so")
+_SO_NOFMA = os.path.join(_HERE, "liblae_oracle_nofma.so")
 
 
 def build(force=False):
     src = os.path.join(_HERE, "lae_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    stale = any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO_NOFMA))
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
-_lib = None
+_libs = {}
+_flavour = "fma"
 
 
 def lib():
-    global _lib
-    if _lib is None:
+    """the oracle library of the active flavour ("fma": FMA(a,b,c) = fmaf, the default and the one every parity test
+    uses; "nofma": a*b+c with two roundings -- only for the contraction-independence tests)."""
+    if _flavour not in _libs:
         build()
-        _lib = ctypes.CDLL(_SO)
-    return _lib
+        so = ctypes.CDLL(_SO if _flavour == "fma" else _SO_NOFMA)
+        so.orc_flavour_fma.restype = ctypes.c_int
+        assert so.orc_flavour_fma() == (1 if _flavour == "fma" else 0)
+        _libs[_flavour] = so
+    return _libs[_flavour]
+
+
+class flavour:
+    """`with oracle.flavour("nofma"): ...` runs the enclosed oracle calls on the un-fused build."""
+
+    def __init__(self, name):
+        assert name in ("fma", "nofma"), name
+        self.name = name
+
+    def __enter__(self):
+        global _flavour
+        self.prev, _flavour = _flavour, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _flavour
+        _flavour = self.prev
+        return False
 
 
 def _p(a):

@@ -206,6 +206,40 @@ def gen_run_path():
          weights_sum=res["weights_sum"].numpy(), num_steps=np.int64(96))
 
 
+# ---------------------------------------------------------------- D2. BASELINE configs[0]: the `run` path end to end
+def gen_cfg0():
+    """configs[0] (lego 64x64, 1024 rays/batch, L=4 hash grid, nn.Linear nets, cuda_ray off): ONE train step of the
+    reference's own NeRFNetwork (nerf/network.py) through NeRFRenderer.run (renderer.py:128-256) with the settings of
+    main_nerf.py:32-35 (num_steps 512, upsample_steps 0), fp32, loss = MSE, gradients of every parameter.
+    The table is capped at 2^14 entries per level so that the fixture stays small (BASELINE's T only changes sizes)."""
+    torch.manual_seed(5)
+    net = LinearNet(bound=1, cuda_ray=False, min_near=0.2)
+    enc = GridEncoder(num_levels=4, log2_hashmap_size=14, desired_resolution=2048)
+    g = torch.Generator().manual_seed(2)
+    enc.embeddings.data = f16r((torch.rand(enc.embeddings.shape, generator=g) * 2 - 1) * 0.5)
+    net.encoder, net.in_dim = enc, enc.output_dim
+    net.sigma_net[0] = torch.nn.Linear(enc.output_dim, net.hidden_dim, bias=False)
+    for p_ in list(net.sigma_net.parameters()) + list(net.color_net.parameters()):
+        p_.data = f16r(p_.data)
+    o, d = S.lego_like_rays(1024, H=64, W=64, focal=1111.1 * 64 / 800, seed=3)
+    target = torch.rand(1024, 3, generator=torch.Generator().manual_seed(8))
+    net.train()
+    res = net.run(torch.from_numpy(o)[None], torch.from_numpy(d)[None], num_steps=512, upsample_steps=0, bg_color=1, perturb=False)
+    loss = ((res["image"][0] - target) ** 2).mean()
+    loss.backward()
+    out = dict(rays_o=o, rays_d=d, target=target.numpy(), table=enc.embeddings.detach().numpy().astype(np.float16),
+               offsets=enc.offsets.numpy(), pls=np.float64(enc.per_level_scale),
+               image=res["image"][0].detach().numpy(), depth=res["depth"][0].detach().numpy(),
+               weights_sum=res["weights_sum"].detach().numpy(), loss=np.float64(loss.item()),
+               g_table_norm=np.float64(enc.embeddings.grad.norm().item()), g_table_sample=enc.embeddings.grad.numpy()[::211].copy(),
+               num_steps=np.int64(512))
+    for i, layer in enumerate(net.sigma_net):
+        out[f"sigma_w{i}"], out[f"g_sigma_w{i}"] = layer.weight.detach().numpy(), layer.weight.grad.numpy().copy()
+    for i, layer in enumerate(net.color_net):
+        out[f"color_w{i}"], out[f"g_color_w{i}"] = layer.weight.detach().numpy(), layer.weight.grad.numpy().copy()
+    save("cfg0_run_step", **out)
+
+
 # ---------------------------------------------------------------- E. run_cuda / run_cuda_distill orchestration
 def make_ff_net(bound, seed):
     torch.manual_seed(seed)
@@ -472,12 +506,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "get_rays":
         gen_get_rays()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg0":
+        gen_cfg0()
+        sys.exit(0)
     gen_get_rays()
     gen_editgrid()
     gen_grid_offsets()
     gen_ffmlp_init()
     gen_mlp_chain()
     gen_run_path()
+    gen_cfg0()
     gen_ops()
     gen_e2e("b1", 1)
     gen_e2e("b2", 2)

@@ -41,8 +41,9 @@ def test_train_render_and_gradients(tag):
         res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
         loss = ((res["image"] - T(g["target"])) ** 2).mean()
     assert np.array_equal(N(r.step_counter[0]), g["train_counter"])            # sample count / ray count: exact
-    assert np.abs(N(res["image"]) - g["train_image"]).max() < 5e-4
-    assert np.abs(N(res["weights_sum"]) - g["train_ws"]).max() < 5e-4
+    # north_star tolerance: 1e-4 RGB at the golden run's settings (fp32 table, fp16 MLP weights)
+    assert np.abs(N(res["image"]) - g["train_image"]).max() < 1e-4
+    assert np.abs(N(res["weights_sum"]) - g["train_ws"]).max() < 1e-4
     hit = g["train_ws"] > 0
     assert np.abs(N(res["depth"])[hit] - g["train_depth"][hit]).max() < 2e-3
     assert loss.item() == pytest.approx(float(g["train_loss"]), rel=2e-3)
@@ -62,7 +63,7 @@ def test_train_render_and_gradients(tag):
     with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
         res2 = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
     assert np.array_equal(N(res2["weights_sum"]) == 0, g["train2_ws"] == 0)
-    assert np.abs(N(res2["image"]) - g["train2_image"]).max() < 5e-4
+    assert np.abs(N(res2["image"]) - g["train2_image"]).max() < 1e-4
 
 
 @pytest.mark.parametrize("tag", ["b1", "b2"])
@@ -74,12 +75,12 @@ def test_eval_and_distill_render(tag):
     with torch.autocast("cuda", dtype=torch.float16):
         for dc in (True, False):                                        # device-side compaction == host boolean mask
             ev = r.render_eval(o, d, bg_color=1, max_steps=256, device_compaction=dc)
-            assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 5e-4
+            assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 1e-4
             hit = g["train_ws"] > 0
             assert np.abs(N(ev["depth"])[hit] - g["eval_depth"][hit]).max() < 2e-3
         ds = r.render_distill(o, d, T(g["edit_bitfield"]), max_steps=256)
     for k, ref in (("image", "dist_image"), ("weights", "dist_weights"), ("weights_edit", "dist_weights_edit")):
-        assert np.abs(N(ds[k]) - g[ref]).max() < 5e-4, k
+        assert np.abs(N(ds[k]) - g[ref]).max() < 1e-4, k
     for k, ref in (("depth", "dist_depth"), ("depth_edit", "dist_depth_edit"), ("x_term", "dist_x_term")):
         assert np.abs(N(ds[k]) - g[ref]).max() < 3e-3, k
 
@@ -219,3 +220,93 @@ def test_fused_criterion_equals_separate_loss():
     lo = int(net.encoder.offsets[4].item())
     assert torch.equal(g0[2][lo:], g1[2][lo:])
     assert (g0[2][:lo] - g1[2][:lo]).abs().max().item() <= 2e-3 * g0[2][:lo].abs().max().item()
+
+
+def test_cfg0_run_path_train_step():
+    """BASELINE configs[0]: lego 64x64, 1024 rays, L=4 hash grid, nn.Linear nets, cuda_ray off -> NeRFRenderer.run with
+    num_steps 512 / upsample_steps 0 (main_nerf.py:32-35), fp32, one train step (forward, MSE, backward) against the
+    reference's own NeRFNetwork + renderer.run executed by tests/golden/make_golden.py::gen_cfg0"""
+    from laenerf_amd.network import NeRFNetworkLinear
+    from laenerf_amd.renderer import NeRFRenderer
+    g = golden("cfg0_run_step")
+    net = NeRFNetworkLinear(bound=1, num_levels=4, log2_hashmap_size=14).to(DEV)
+    assert np.array_equal(N(net.encoder.offsets), g["offsets"])
+    net.encoder.embeddings.data = T(g["table"].astype(np.float32))
+    for i, layer in enumerate(net.sigma_net):
+        layer.weight.data = T(g[f"sigma_w{i}"])
+    for i, layer in enumerate(net.color_net):
+        layer.weight.data = T(g[f"color_w{i}"])
+    r = NeRFRenderer(net, bound=1, min_near=0.2).to(DEV)
+    net.train(); r.train()
+    res = r.run(T(g["rays_o"])[None], T(g["rays_d"])[None], num_steps=int(g["num_steps"]), upsample_steps=0, bg_color=1, perturb=False)
+    assert np.abs(N(res["image"][0]) - g["image"]).max() < 1e-4              # north_star RGB tolerance (observed ~1e-6)
+    assert np.abs(N(res["weights_sum"]) - g["weights_sum"]).max() < 1e-4
+    dep, dref = N(res["depth"][0]), g["depth"]
+    assert np.array_equal(np.isnan(dep), np.isnan(dref)) and np.nanmax(np.abs(dep - dref)) < 1e-4
+    loss = ((res["image"][0] - T(g["target"])) ** 2).mean()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for i, layer in enumerate(net.sigma_net):
+        ref = g[f"g_sigma_w{i}"]
+        assert np.abs(N(layer.weight.grad) - ref).max() < 1e-3 * np.abs(ref).max() + 1e-9, f"sigma {i}"
+    for i, layer in enumerate(net.color_net):
+        ref = g[f"g_color_w{i}"]
+        assert np.abs(N(layer.weight.grad) - ref).max() < 1e-3 * np.abs(ref).max() + 1e-9, f"color {i}"
+    gt = N(net.encoder.embeddings.grad)
+    assert np.linalg.norm(gt) == pytest.approx(float(g["g_table_norm"]), rel=1e-4)
+    ref = g["g_table_sample"]
+    assert np.abs(gt[::211] - ref).max() < 1e-3 * np.abs(ref).max() + 1e-9
+
+
+def test_flower_shaped_full_size_properties(O):
+    """BASELINE configs[2] sizes (scripts/configs_llff/flower.sh: bound 2 -> cascade 2, offset (0,0,1.5) -> cameras
+    inside the box, min_near 0.2; 4096 rays, T=2^19, finest resolution 4096): size-independent properties + oracle spot
+    checks on subsets the oracle finishes in seconds"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd import raymarching as rm
+    from laenerf_amd.gridencoder import GridEncoder
+    bound, C = 2.0, 2
+    o, d = S.flower_like_rays(4096, seed=0)
+    bits = S.pack_bits_np(S.flower_density_grid(), 10.0)
+    assert bits.shape[0] == 2 * 128 ** 3 // 8                                  # 512 KiB bitfield
+    to, td, tb = T(o), T(d), T(bits)
+    aabb = T(np.array([-bound] * 3 + [bound] * 3, np.float32))
+    n, f = rm.near_far_from_aabb(to, td, aabb, 0.2)
+    n0, f0 = O.near_far_from_aabb(o, d, [-bound] * 3 + [bound] * 3, 0.2)
+    assert np.array_equal(N(n), n0) and np.array_equal(N(f), f0) and (n0 == np.float32(0.2)).all()   # origins inside: near = min_near
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, bound, tb, C, 128, n, f, counter, -1, False, 128, False, 0, 1024)
+    r = N(rays); total = int(counter[0].item())
+    assert r[:, 2].sum() == total and np.array_equal(r[:, 1], np.concatenate([[0], np.cumsum(r[:-1, 2])]))
+    # per-ray sample counts and positions of the first 384 rays == oracle (rays are independent; perturb off)
+    sub = 384
+    ref = O.march_rays_train(o[:sub], d[:sub], bound, bits, C, 128, n0[:sub], f0[:sub], np.zeros(sub, np.float32))
+    assert np.array_equal(r[:sub, 2], ref[3][:, 2]) and np.array_equal(r[:sub, 1], ref[3][:, 1])
+    m = int(ref[4][0])
+    assert np.array_equal(N(xyzs)[:m], ref[0][:m]) and np.array_equal(N(deltas)[:m], ref[2][:m])
+    # every sample lies in an occupied voxel of ITS cascade (level 1 where max|x| >= 1, raymarching.cu:42-47, 368)
+    p = N(xyzs)[:total].astype(np.float64)
+    level = (np.abs(p).max(1) >= 1.0).astype(np.int64)
+    assert 0.2 < level.mean() < 0.8                                            # both cascades are exercised
+    mip_bound = np.where(level == 1, 2.0, 1.0)[:, None]
+    nidx = np.clip(0.5 * (p / mip_bound + 1) * 128, 0, 127).astype(np.int32)
+    idx = level * 128 ** 3 + O.morton3D(nidx).astype(np.int64)
+    assert np.all((bits[idx >> 3] >> (idx & 7)) & 1)
+    # hash grid at flower size: desired_resolution 2048 * bound = 4096, T = 2^19 -> 6 328 848 entries (SURVEY 8)
+    enc = GridEncoder(desired_resolution=4096).to(DEV)
+    assert int(enc.offsets[-1].item()) == 6328848
+    enc.embeddings.data.uniform_(-1, 1)
+    pts = xyzs[:total]
+    y1 = enc(pts, bound=bound)
+    subp = N(pts[:4096])
+    refy, _ = O.grid_encode_forward((subp + bound) / (2 * bound), N(enc.embeddings), N(enc.offsets), enc.per_level_scale, 16, out_blc=True)
+    assert np.allclose(N(y1[:4096]), refy, atol=1e-5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yh = enc(pts, bound=bound)
+    th = O.to_f16_bits(N(enc.embeddings))
+    refh, _ = O.grid_encode_forward((subp + bound) / (2 * bound), th, N(enc.offsets), enc.per_level_scale, 16, f16=True, out_blc=True)
+    assert np.array_equal(N(yh[:4096]).astype(np.float16).view(np.uint16), refh)          # fp16 table path: bit exact
+    y = enc(pts, bound=bound)
+    gr = torch.randn_like(y)
+    y.backward(gr)
+    assert enc.embeddings.grad.double().sum().item() == pytest.approx(gr.double().sum().item(), rel=1e-3, abs=1e-2)

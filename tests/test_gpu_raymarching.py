@@ -67,6 +67,33 @@ def test_march_rays_train_bit_exact(O, C, bound, dtg, max_steps):
         assert np.array_equal(N(xyzs), ref[0]) and np.array_equal(N(dirs), ref[1]) and np.array_equal(N(deltas), ref[2])
 
 
+@pytest.mark.parametrize("C,bound,dtg,perturb", [(C, b, g, p) for (C, b) in ((1, 1.0), (2, 2.0), (4, 8.0))
+                                                for g in (0.0, 1 / 128) for p in (False, True)])
+def test_march_integer_outputs_match_both_oracle_flavours(O, C, bound, dtg, perturb):
+    """`rays` / `counter` of the HIP marcher equal the oracle built with fused AND with un-fused multiply-adds
+    (tests/test_oracle_flavours_cpu.py): the bit-exactness of indices / offsets does not rest on the nvcc
+    contraction model; positions agree with the un-fused build to 1 ulp of the larger operand."""
+    from laenerf_amd.backend import raymarching_backend as B
+    Nr = 1024
+    sc = scene(C, bound, n_rays=Nr, seed=10 + C)
+    noises = np.random.default_rng(3).random(Nr).astype(np.float32) if perturb else np.zeros(Nr, np.float32)
+    M = Nr * 1024
+    xyzs = torch.empty(M, 3, device=DEV); dirs = torch.empty(M, 3, device=DEV); deltas = torch.empty(M, 2, device=DEV)
+    rays = torch.empty(Nr, 3, dtype=torch.int32, device=DEV); counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    B.march_rays_train(T(sc["o"]), T(sc["d"]), T(sc["bits"]), bound, dtg, 1024, Nr, C, 128, M, T(sc["nears"]), T(sc["fars"]),
+                       xyzs, dirs, deltas, rays, counter, T(noises))
+    for fl in ("fma", "nofma"):
+        with O.flavour(fl):
+            ref = O.march_rays_train(sc["o"], sc["d"], bound, sc["bits"], C, 128, sc["nears"], sc["fars"], noises,
+                                     dt_gamma=dtg, max_steps=1024)
+        assert np.array_equal(N(rays), ref[3]) and np.array_equal(N(counter), ref[4]), fl
+        total = int(ref[4][0])
+        if fl == "fma":
+            assert np.array_equal(N(xyzs)[:total], ref[0][:total]) and np.array_equal(N(deltas)[:total], ref[2][:total])
+        else:
+            assert np.abs(N(xyzs)[:total] - ref[0][:total]).max() <= 4.8e-7
+
+
 def test_march_rays_train_record_overflow_falls_back_to_walk(O):
     """a half-occupied random grid at bound 8 spreads a ray's 1024 samples over more candidate chunks than the emit
     pass keeps records for (24): those rays are walked again and must still be bit-identical"""

@@ -239,3 +239,32 @@ def test_get_rays_matches_reference(O, tag):
     assert np.array_equal(ro, g[f"{tag}_rays_o"])                       # origins: a copy of the pose's translation
     assert np.abs(rd - g[f"{tag}_rays_d"]).max() < 3e-7                  # a few ulp: torch's norm / matmul summation order
     assert np.abs(np.linalg.norm(rd, axis=-1) - 1).max() < 3e-7
+
+
+def test_cfg0_run_step_forward_from_oracle_pieces(O):
+    """BASELINE configs[0] (`run` path, L=4 grid, nn.Linear nets, 1024 rays x 512 steps) restated with the oracle's
+    operators + numpy against the reference's own NeRFRenderer.run / NeRFNetwork forward (cfg0_run_step.npz)"""
+    g = golden("cfg0_run_step")
+    o, d, T = g["rays_o"], g["rays_d"], int(g["num_steps"])
+    N = o.shape[0]
+    nears, fars = O.near_far_from_aabb(o, d, [-1, -1, -1, 1, 1, 1], 0.2)
+    z = nears[:, None] + (fars - nears)[:, None] * np.linspace(0, 1, T, dtype=np.float32)[None]
+    xyz = np.clip(o[:, None] + d[:, None] * z[..., None], -1, 1).astype(np.float32)
+    table = g["table"].astype(np.float32)
+    enc, _ = O.grid_encode_forward(((xyz.reshape(-1, 3) + 1) / 2).astype(np.float32), table, g["offsets"], float(g["pls"]), 16, out_blc=True)
+    h = np.maximum(enc @ g["sigma_w0"].T, 0) @ g["sigma_w1"].T
+    sigma = np.exp(h[:, 0]).reshape(N, T)
+    sample_dist = (fars - nears) / T
+    deltas = np.concatenate([z[:, 1:] - z[:, :-1], sample_dist[:, None]], 1)
+    alphas = 1 - np.exp(-deltas * sigma)
+    trans = np.cumprod(np.concatenate([np.ones((N, 1), np.float32), 1 - alphas + 1e-15], 1), 1)[:, :-1]
+    w = alphas * trans
+    sh, _ = O.sh_encode_forward(np.repeat(d, T, axis=0), 4)
+    c = np.concatenate([sh, h[:, 1:]], 1)
+    c = np.maximum(np.maximum(c @ g["color_w0"].T, 0) @ g["color_w1"].T, 0) @ g["color_w2"].T
+    rgb = (1 / (1 + np.exp(-c))).reshape(N, T, 3) * (w > 1e-4)[..., None]
+    ws = w.sum(1)
+    image = (w[..., None] * rgb).sum(1) + (1 - ws)[:, None]
+    assert np.abs(ws - g["weights_sum"]).max() < 2e-5
+    assert np.abs(image - g["image"]).max() < 2e-5
+    assert ((image - g["target"]) ** 2).mean() == pytest.approx(float(g["loss"]), rel=1e-5)
