@@ -9,7 +9,20 @@
  *     autograd.Functions do),
  *   - enqueues its kernels on `stream` (a hipStream_t passed as void*; NULL =
  *     the legacy default stream, which is what the reference launched on),
- *   - never synchronises the host, never allocates device memory,
+ *   - never synchronises the host and never frees or reallocates memory the caller
+ *     passed in.  LIBRARY-OWNED WORKSPACES (the counterpart of the reference's
+ *     process-global split-K streams + CUTLASS workspace, ffmlp.cu:711-740,
+ *     cutlass_matmul.h:335-352): the fp32 dW slabs of the MLP backward, the
+ *     level-major staging of the [B, L*C] grid-encoder layouts and the bin queues of
+ *     the grid backward live in grow-only device buffers, one set per device.
+ *     WARM-UP CONTRACT: the first call at a new largest size hipMalloc()s (a host-
+ *     side, possibly blocking, call); steady state allocates nothing.  A buffer
+ *     that is outgrown is retired, NOT freed -- kernels in flight and captured HIP
+ *     graphs keep using the address they were given -- until lae_free_workspaces().
+ *     Growth is refused (LAE_ELAUNCH, message in lae_last_error) while `stream` is
+ *     being captured: run the call once eagerly at its largest size before
+ *     capturing.  The library acts on the CURRENT device of the calling thread;
+ *     the caller makes the device of its pointers current (hipSetDevice) first,
  *   - returns LAE_OK (0) or a negative LAE_E* code; the Python shim turns a
  *     non-zero code into RuntimeError (the reference threw c10::Error /
  *     std::runtime_error for the same conditions).
@@ -196,7 +209,8 @@ LAE_API int lae_composite_rays_distill(uint32_t n_alive, uint32_t n_step, float 
  * step >= max_steps), then `image + (1 - weights_sum) * bg` (blend_bg) and `clamp(depth - nears, 0) / (fars - nears)`
  * (scale_depth).  The host never waits for the device inside the loop: it sizes launches from a lagging upper bound of
  * n_alive mirrored into pinned memory.  Not stream-capturable (LAE_EINVAL while capturing).
- *   table_f16 [sum level sizes, 2] fp16, offsets [L+1] int32, L = 16, S = log2(per_level_scale), base_resolution;
+ *   table_f16 [sum level sizes, 2] fp16, offsets [L+1] int32 (device), offsets_host = the same L+1 ints in HOST memory
+ *   or NULL (only the level -> XCD balance of the encoder depends on it), L = 16, S = log2(per_level_scale), base_resolution;
  *   sigma_weights / color_weights: FFMLP flat fp16 images of the 32->64->64->16 and 32->64->64->64->16 nets;
  *   noises [N] or NULL (perturb, applied in the first iteration only, renderer.py:365); bg_rays [N,3] or NULL (then
  *   bg_r/g/b); outputs weights_sum, depth [N], image [N,3] fp32 (+ weights_edit, depth_edit [N] when edit_grid);
@@ -209,7 +223,8 @@ LAE_API uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64
 LAE_API int lae_render_frame_set_overlap(int on);
 LAE_API int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
                      const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
-                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, uint32_t L, float S,
+                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,
+                     uint32_t L, float S,
                      uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp,
                      const void* sigma_weights, const void* color_weights, float density_scale, float T_thresh,
                      uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
@@ -240,17 +255,6 @@ LAE_API int lae_grid_encode_forward(const float* inputs, const void* embeddings,
                             float S, uint32_t H, void* dy_dx, uint32_t gridtype,
                             int align_corners, uint32_t interp, int dtype, void* stream);
 
-/* MI355X-native variant: writes outputs as [B, L*C] directly (what grid.py:57
- * produces with an extra permute+reshape copy).  Same arithmetic.
- * in_shift / in_scale: every coordinate is read as (x + in_shift) * in_scale -- GridEncoder.forward's
- * `(inputs + bound) / (2 * bound)` (grid.py:149) with in_shift = bound, in_scale = fp32(1 / (2 * bound)); pass 0, 1
- * for coordinates already in [0, 1]. */
-LAE_API int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings,
-                                const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
-                                uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                float in_shift, float in_scale, void* stream);
-
 /* gridencoder.cu:473-503  grid_encode_backward(grad[L,B,C], inputs, embeddings, offsets,
  * grad_embeddings[sO,C] (pre-zeroed, accumulated into), B, D, C, L, S, H,
  * dy_dx or NULL, grad_inputs[B,D] or NULL, gridtype, align_corners, interp) */
@@ -260,31 +264,37 @@ LAE_API int lae_grid_encode_backward(const void* grad, const float* inputs, cons
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                              int align_corners, uint32_t interp, int dtype, void* stream);
 
-/* MI355X-native variant: grad given as [B, L*C] (no permute copy, grid.py:75). */
-LAE_API int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const void* embeddings,
-                                 const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                 uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                 const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                                 int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                 void* stream);
-
-/* General forms: blc = 0 -> [L,B,C] outputs / gradients (the reference layout, and what the fused field op keeps between
- * encoder and MLP so that no transpose is needed), blc = 1 -> [B, L*C]; plus the coordinate map. */
+/* MI355X-native general forms.
+ *   blc = 0: [L,B,C] outputs / gradients (the reference's backend layout, and what the fused field op keeps between
+ *            encoder and MLP so that no transpose is needed); blc = 1: [B, L*C] directly (what grid.py:57 / grid.py:75
+ *            produce with a permute + reshape copy).  Same arithmetic.
+ *   in_shift / in_scale: every coordinate is read as (x + in_shift) * in_scale -- GridEncoder.forward's
+ *            `(inputs + bound) / (2 * bound)` (grid.py:149) with in_shift = bound, in_scale = fp32(1 / (2 * bound)); pass
+ *            0, 1 for coordinates already in [0, 1].
+ *   offsets_host: the caller's HOST copy of `offsets` (L + 1 ints) or NULL.  The reference hands the backend a device
+ *            tensor only; the module that built it (grid.py:118-127) has the numbers on the host, and passing them lets
+ *            the library balance the forward's level -> XCD schedule and skip the launch of the generic atomic kernel
+ *            when no level needs it.  It never changes a result: with NULL the forward uses the fixed level l -> XCD
+ *            l mod 8 map and the backward always launches the (then idle) companion kernel.  Nothing is cached between
+ *            calls (round 1 cached a device->host copy keyed on the device pointer, which a reused address could make
+ *            stale). */
 LAE_API int lae_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int blc, float in_shift,
-                               float in_scale, void* stream);
+                               float in_scale, const int32_t* offsets_host, void* stream);
 LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                void* stream);
+                                const int32_t* offsets_host, void* stream);
 
-/* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- counting sort bookkeeping: per
- * (level, table partition) item counts, their scans -- depends on the sample positions only, so a caller can run it as
- * soon as the positions exist (e.g. right after the march, on another stream beside the forward pass) and hand the
- * result to the second half, which needs the gradients.  plan: lae_grid_backward_plan_bytes(B, L) bytes of device
- * memory, read-only for `_planned`.  grad is level-major [L, B, 2] (the layout of lae_grid_encode_backward). */
+/* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- the bookkeeping of a counting
+ * sort: items per (level, 1024 samples, table partition), their scans -- depends on the sample positions only,
+ * so a caller can run it as soon as the positions exist (e.g. right after the march, on another stream beside the
+ * forward pass) and hand the result to the second half, which needs the gradients.  plan:
+ * lae_grid_backward_plan_bytes(B, L) bytes of device memory owned by the caller, read-only for `_planned` except for its
+ * work-queue words, which every execution resets itself (a plan serves any number of executions, one at a time).
+ * grad is level-major [L, B, 2] (the layout of lae_grid_encode_backward). */
 LAE_API uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L);
 LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                   float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
@@ -292,7 +302,13 @@ LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* of
 LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                     const void* plan, void* stream);
+                                     const int32_t* offsets_host, const void* plan, void* stream);
+
+/* Bytes of LIBRARY workspace the binned backward (D = 3, C = 2) takes for B samples and L levels when it runs both halves
+ * itself: the plan + the item queue, sized for the worst case of 8 items per (sample, level) at 10 bytes each for fp16
+ * gradients (hashed levels produce 4; only the front of the queue is touched) + the partial sums of split partitions.
+ * Informational: the workspace is library-owned (see the header comment: warm up eagerly before capturing). */
+LAE_API uint64_t lae_grid_backward_workspace_bytes(uint32_t B, uint32_t L, int dtype);
 
 /* Host-only helper (no GPU call; used by the CPU tests): the level -> XCD schedule of the specialised forward for a table
  * with the given level offsets (HOST pointer, L + 1 ints) and `n_chunks` 256-sample chunks.  nseg_out[8]; segs_out[8][12][3] =
@@ -306,8 +322,9 @@ LAE_API int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, f
  * XCD l mod 8, 2 = the generic kernel.  Results are bit-identical in every mode. */
 LAE_API int lae_grid_set_forward_mode(int mode);
 
-/* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (no scattered global atomics),
- * 1 = always the generic kernel (one global atomic per corner, what the reference does). */
+/* MI355X-native: 0 (default) = binned / LDS-accumulated backward for D = 3, C = 2 (contributions routed to the owner
+ * of a 4096-entry table partition, fp16 sums exact, no scattered global atomics), 1 = always the generic kernel (one
+ * global atomic per corner, what the reference does). */
 LAE_API int lae_grid_set_backward_mode(int mode);
 
 /* gridencoder.cu:639-645  grad_total_variation(inputs[B,D], embeddings, grad, offsets,
@@ -486,6 +503,12 @@ LAE_API int lae_ffmlp_set_mode(int mode);
  * these are accepted and ignored (kept so FFMLP.__init__ runs unmodified). */
 LAE_API int lae_allocate_splitk(uint64_t size);
 LAE_API int lae_free_splitk(void);
+
+/* MI355X-native: library workspaces (see the header comment).  lae_free_workspaces() frees the live and the retired
+ * buffers of every device after synchronising it; the caller guarantees that no captured graph that used the library
+ * is replayed afterwards.  lae_workspace_bytes(0 / 1) = bytes currently held live / retired. */
+LAE_API int lae_free_workspaces(void);
+LAE_API uint64_t lae_workspace_bytes(int retired);
 
 #ifdef __cplusplus
 }

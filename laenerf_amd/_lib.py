@@ -38,19 +38,18 @@ SIGNATURES = {
     "lae_composite_rays_distill": [u32, u32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_render_frame_workspace_bytes": [u32, u32, u64],
     "lae_render_frame_set_overlap": [i32],
-    "lae_render_frame": [vp, vp, u32, vp, f32, vp, vp, f32, f32, u32, u32, u32, vp, vp, u32, f32, u32, u32, i32, u32, vp, vp, f32, f32,
+    "lae_render_frame": [vp, vp, u32, vp, f32, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, u32, f32, u32, u32, i32, u32, vp, vp, f32, f32,
                          u32, u64, vp, vp, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp, vp],
     "lae_compact_scratch_bytes": [u32],
     "lae_compact_rays_alive": [vp, u32, vp, vp, vp, vp],
     "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
-    "lae_grid_encode_forward_blc": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, f32, f32, vp],
     "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
-    "lae_grid_encode_backward_blc": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, f32, f32, vp],
-    "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp],
-    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp],
+    "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp],
+    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp],
+    "lae_grid_backward_workspace_bytes": [u32, u32, i32],
     "lae_grid_backward_plan_bytes": [u32, u32],
     "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
+    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grid_set_forward_mode": [i32],
     "lae_grid_forward_schedule": [vp, u32, f32, u32, u32, vp, vp],
@@ -84,16 +83,20 @@ SIGNATURES = {
     "lae_ffmlp_set_mode": [i32],
     "lae_allocate_splitk": [u64],
     "lae_free_splitk": [],
+    "lae_free_workspaces": [],
+    "lae_workspace_bytes": [i32],
     "lae_version": [],
     "lae_last_error": [],
 }
 _RESTYPES = {
     "lae_march_rays_train_scratch_bytes": u64,
     "lae_compact_scratch_bytes": u64,
-    "lae_grid_backward_plan_bytes": u64,
     "lae_palette_backward_scratch_bytes": u64,
     "lae_style_loss_scratch_bytes": u64,
     "lae_render_frame_workspace_bytes": u64,
+    "lae_workspace_bytes": u64,
+    "lae_grid_backward_workspace_bytes": u64,
+    "lae_grid_backward_plan_bytes": u64,
     "lae_version": ctypes.c_char_p,
     "lae_last_error": ctypes.c_char_p,
 }
@@ -137,9 +140,19 @@ def stream():
 
 
 def need_cuda(*tensors):
+    """every tensor on the GPU, and on the CURRENT device: the library launches on (and sizes its workspaces for) the
+    device that is current in the calling thread -- one process per GPU, or `with torch.cuda.device(i):` around the call"""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("laenerf_amd: tensor must be on the GPU (HIP backend, no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"laenerf_amd: tensor on cuda:{t.device.index} but the current device is cuda:{cur}; "
+                               "make the tensor's device current (torch.cuda.set_device / torch.cuda.device)")
 
 
 def need_contig(*tensors):

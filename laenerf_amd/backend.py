@@ -30,6 +30,15 @@ def _dtype_code(t):
     raise RuntimeError(f"laenerf_amd: unsupported dtype {t.dtype} (float32 / float16 only)")
 
 
+def _host_i32(a, n):
+    """host pointer of a C-contiguous int32 numpy array with n entries (None -> NULL); the array must outlive the call only"""
+    if a is None:
+        return None
+    if not (isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags.c_contiguous and a.size == n):
+        raise RuntimeError("laenerf_amd: offsets_host must be a contiguous int32 numpy array with L + 1 entries")
+    return a.ctypes.data
+
+
 def _need_f32(*ts):
     for t in ts:
         if t is not None and t.dtype != torch.float32:
@@ -37,16 +46,33 @@ def _need_f32(*ts):
 
 
 _scratch = {}
+_scratch_retired = []
 
 
 def _workspace(device, nbytes):
-    """grow-only per-device scratch buffer for scans/compaction (stream-ordered reuse)"""
+    """grow-only per-device scratch buffer for scans / compaction (stream-ordered reuse).  Same policy as the library's
+    own workspaces (include/laenerf.h): an outgrown buffer is retired, not freed -- captured graphs and queued kernels
+    keep the address they were given -- and growth inside a stream capture is refused (warm up eagerly first)."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("laenerf_amd: scratch buffer must grow inside a stream capture; run the same call once "
+                               "eagerly (warm-up) at the largest size before capturing")
+        if buf is not None:
+            _scratch_retired.append(buf)
+        buf = torch.empty(max(int(nbytes) * 3 // 2, 1 << 20), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf
+
+
+def free_workspaces():
+    """drop every scratch buffer (Python side and library side).  Only when no captured graph that used the backend
+    will be replayed again."""
+    torch.cuda.synchronize()
+    _scratch.clear()
+    _scratch_retired.clear()
+    check(_lib.load().lae_free_workspaces(), "free_workspaces")
 
 
 # --------------------------------------------------------------------------- _raymarching
@@ -210,7 +236,7 @@ class _RayMarching:
     def render_frame(rays_o, rays_d, N, aabb, min_near, grid, edit_grid, bound, dt_gamma, max_steps, C, H, table_f16, offsets, L, S,
                      base_resolution, gridtype, align_corners, interp, sigma_weights, color_weights, density_scale, T_thresh,
                      max_n_step, row_budget, noises, bg_rays, bg_rgb, blend_bg, scale_depth, weights_sum, depth, image,
-                     weights_edit, depth_edit, want_stats=False):
+                     weights_edit, depth_edit, want_stats=False, offsets_host=None):
         """whole inference loop of run_cuda / run_cuda_distill as one call (include/laenerf.h lae_render_frame)"""
         import ctypes
         tensors = (rays_o, rays_d, aabb, grid, edit_grid, table_f16, offsets, sigma_weights, color_weights, noises, bg_rays,
@@ -225,11 +251,14 @@ class _RayMarching:
         key = ("frame", rays_o.device.index if rays_o.device.index is not None else torch.cuda.current_device())
         ws = _scratch.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                _scratch_retired.append(ws)               # same policy as _workspace: never free what the stream may still use
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=rays_o.device)
             _scratch[key] = ws
         stats = (ctypes.c_uint32 * 4)() if want_stats else None
         check(lib.lae_render_frame(ptr(rays_o), ptr(rays_d), N, ptr(aabb), float(min_near), ptr(grid), ptr(edit_grid), float(bound),
-                                   float(dt_gamma), max_steps, C, H, ptr(table_f16), ptr(offsets), L, float(S), base_resolution,
+                                   float(dt_gamma), max_steps, C, H, ptr(table_f16), ptr(offsets), _host_i32(offsets_host, L + 1), L, float(S),
+                                   base_resolution,
                                    gridtype, int(bool(align_corners)), interp, ptr(sigma_weights), ptr(color_weights),
                                    float(density_scale), float(T_thresh), max_n_step, int(row_budget), ptr(noises), ptr(bg_rays), float(bg_rgb[0]),
                                    float(bg_rgb[1]), float(bg_rgb[2]), int(bool(blend_bg)), int(bool(scale_depth)), ptr(weights_sum),
@@ -256,8 +285,9 @@ class _RayMarching:
 class _GridEncoder:
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
-                            interp, blc=False, in_map=(0.0, 1.0)):
-        """blc / in_map are MI355X extensions: [B, L*C] output layout; coordinates read as (x + in_map[0]) * in_map[1]"""
+                            interp, blc=False, in_map=(0.0, 1.0), offsets_host=None):
+        """blc / in_map / offsets_host are MI355X extensions: [B, L*C] output layout; coordinates read as
+        (x + in_map[0]) * in_map[1]; the module's host copy of `offsets` (int32 numpy array, include/laenerf.h)"""
         need_cuda(inputs, embeddings, offsets, outputs, dy_dx); need_contig(inputs, embeddings, offsets, outputs, dy_dx)
         if inputs.dtype != torch.float32 or offsets.dtype != torch.int32:
             raise RuntimeError("grid_encode_forward: inputs must be float32, offsets int32")   # gridencoder.cu:461-463
@@ -266,16 +296,16 @@ class _GridEncoder:
         lib = _lib.load()
         args = (ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs), B, D, C, L, float(S), H, ptr(dy_dx), gridtype,
                 int(bool(align_corners)), interp, _dtype_code(embeddings))
-        if blc:
-            check(lib.lae_grid_encode_forward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_forward")
-        elif tuple(in_map) != (0.0, 1.0):
-            check(lib.lae_grid_encode_forward_ex(*args, 0, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_forward")
+        if blc or tuple(in_map) != (0.0, 1.0) or offsets_host is not None:
+            check(lib.lae_grid_encode_forward_ex(*args, int(bool(blc)), float(in_map[0]), float(in_map[1]), _host_i32(offsets_host, L + 1),
+                                                 stream()), "grid_encode_forward")
         else:
             check(lib.lae_grid_encode_forward(*args, stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_backward_plan(inputs, offsets, B, D, C, L, S, H, gridtype, align_corners, interp, half, in_map=(0.0, 1.0)):
-        """first half of the binned grid backward (positions only) -> plan tensor for grid_encode_backward(plan=...)"""
+        """first half of the binned grid backward (positions only: count pass + scans) -> plan tensor for
+        grid_encode_backward(plan=...)"""
         need_cuda(inputs, offsets); need_contig(inputs, offsets)
         lib = _lib.load()
         plan = torch.empty(int(lib.lae_grid_backward_plan_bytes(B, L)), dtype=torch.uint8, device=inputs.device)
@@ -286,7 +316,7 @@ class _GridEncoder:
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                             gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0), plan=None):
+                             gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0), offsets_host=None, plan=None):
         """plan (MI355X extension): result of grid_backward_plan for the same inputs -- skips the count pass and scans"""
         ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs, plan)
         need_cuda(*ts); need_contig(*ts)
@@ -298,16 +328,20 @@ class _GridEncoder:
                 raise RuntimeError("grid_encode_backward: a plan needs level-major gradients and no input gradient")
             check(lib.lae_grid_encode_backward_planned(ptr(grad), ptr(inputs), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                                                        gridtype, int(bool(align_corners)), interp, _dtype_code(grad), float(in_map[0]),
-                                                       float(in_map[1]), ptr(plan), stream()), "grid_encode_backward")
+                                                       float(in_map[1]), _host_i32(offsets_host, L + 1), ptr(plan), stream()),
+                  "grid_encode_backward")
             return
         args = (ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad))
-        if blc:
-            check(lib.lae_grid_encode_backward_blc(*args, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_backward")
-        elif tuple(in_map) != (0.0, 1.0):
-            check(lib.lae_grid_encode_backward_ex(*args, 0, float(in_map[0]), float(in_map[1]), stream()), "grid_encode_backward")
+        if blc or tuple(in_map) != (0.0, 1.0) or offsets_host is not None:
+            check(lib.lae_grid_encode_backward_ex(*args, int(bool(blc)), float(in_map[0]), float(in_map[1]), _host_i32(offsets_host, L + 1),
+                                                  stream()), "grid_encode_backward")
         else:
             check(lib.lae_grid_encode_backward(*args, stream()), "grid_encode_backward")
+
+    @staticmethod
+    def grid_backward_workspace_bytes(B, L, half=True):
+        return int(_lib.load().lae_grid_backward_workspace_bytes(B, L, 1 if half else 0))
 
     @staticmethod
     def set_backward_mode(mode):

@@ -1024,7 +1024,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
             attr_set = true;
         }
         blocks = std::max(1u, std::min(lae::cdiv(n_tiles, WAVES), (uint32_t)lae::num_cus() * 2));
-        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_coop<IN, NH, MODE, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     } else {
@@ -1037,7 +1037,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
             attr_set = true;
         }
         blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
-        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float)));
+        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     }
@@ -1237,7 +1237,7 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
     const uint32_t n_jobs = MB * NB0 + MB * MB * n_hidden + MB;
     // slices: aim for ~4 workgroups per CU in total, at least 64 rows per slice, bounded by the workspace
     uint32_t n_slices = max(1u, min(B / 64, (uint32_t)(n_cus() * 2) / n_jobs));
-    float* g_ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)n_slices * nW * sizeof(float)));
+    float* g_ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)n_slices * nW * sizeof(float), s));
     if (!g_ws) return LAE_ELAUNCH;
     uint32_t rows_per_slice = lae::cdiv(B, n_slices);
     rows_per_slice = (rows_per_slice + 63) / 64 * 64;
@@ -1392,7 +1392,7 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
     // partial slabs of both networks side by side in the workspace, reduced by ONE launch after the second backward kernel
     const uint32_t nW_c = 64 * (32 + 128 + 16), nW_s = 64 * (32 + 64 + 16);
     const size_t cap = (size_t)lae::num_cus() * 2;
-    float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, cap * (nW_c + nW_s) * sizeof(float)));
+    float* ws = reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, cap * (nW_c + nW_s) * sizeof(float), s));
     if (!ws) return LAE_ELAUNCH;
     float* ws_s = ws + cap * nW_c;
     uint32_t n_c = 0, n_s = 0;

@@ -371,36 +371,20 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
 // gridencoder.cu:248-340: scatter w*grad into grad_grid.  v1: one no-return atomic per
 // (corner, channel pair): global_atomic_add_f32 / global_atomic_pk_add_f16.
 // ---- constants and predicates of the binned backward (defined here because the generic kernel below is its companion)
-constexpr uint32_t BK_MAX = 256;              // buckets per level in the tables
-constexpr uint32_t BK_TARGET = 16;            // target workgroups per level
-constexpr int BIN_THREADS = 256;
-constexpr int BIN_SPT = 16;                   // consecutive samples per lane
-constexpr uint32_t E_NONE = 0xffffu;
-
-template <typename T> struct HShift { static constexpr uint32_t value = sizeof(T) == 2 ? 13 : 14; };
-template <typename T> struct HItem;
-template <> struct HItem<half_t> { uint32_t e; half2_t v0, v1; uint32_t pad; };            // 16 B
-template <> struct HItem<float> { uint32_t e; float v0x, v0y, v1x, v1y; uint32_t pad; };    // 24 B
+constexpr uint32_t PART_SHIFT = 12, PART = 1u << PART_SHIFT;   // table entries per partition (= per accumulate workgroup)
+constexpr uint32_t BK_MAX = 512;              // partitions per level the binned path handles (level size <= 2^21 entries)
+constexpr uint32_t BK_TARGET = 16;            // target workgroups per level (levels with fewer partitions are split into sub-ranges)
 
 struct LevelBins { uint32_t P, SUB; };
-template <typename T>
 __host__ __device__ __forceinline__ LevelBins level_bins_of(uint32_t hashmap_size) {
-    constexpr uint32_t SHIFT = HShift<T>::value;
     LevelBins lb;
-    lb.P = (hashmap_size + (1u << SHIFT) - 1) >> SHIFT;
+    lb.P = (hashmap_size + PART - 1) >> PART_SHIFT;
     lb.SUB = lb.P >= BK_TARGET ? 1u : (BK_TARGET + lb.P - 1) / lb.P;
     return lb;
 }
-template <typename T>
-__device__ __forceinline__ LevelBins level_bins(const LevelInfo<3>& li) { return level_bins_of<T>(li.hashmap_size); }
-
-// A level goes through the binned pipeline when its buckets fit the tables and, for hashed levels, both x corners of a
-// (y', z') pair provably share a partition (x' + 1 < 2^SHIFT).  Everything else is left to the generic atomic kernel.
-template <typename T>
-__host__ __device__ __forceinline__ bool level_is_binned(uint32_t hashmap_size, uint32_t resolution, bool use_hash) {
-    const LevelBins lb = level_bins_of<T>(hashmap_size);
-    return lb.P * lb.SUB <= BK_MAX && !(use_hash && resolution + 1 > (1u << HShift<T>::value));
-}
+// A level goes through the binned pipeline when its partitions fit the directory rows; anything larger is left to the
+// generic atomic kernel.
+__host__ __device__ __forceinline__ bool level_is_binned(uint32_t hashmap_size) { return level_bins_of(hashmap_size).P <= BK_MAX; }
 
 
 template <typename T, int D, int C>
@@ -415,7 +399,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     if (b >= B) return;
     const LevelInfo<D> li = level_info<D>(sc, offsets, level, gridtype, align_corners);
     if (only_unbinned) {      // companion of the binned fast path: only the levels it leaves out
-        if constexpr (D == 3) { if (level_is_binned<T>(li.hashmap_size, li.resolution, li.use_hash)) return; }
+        if constexpr (D == 3) { if (level_is_binned(li.hashmap_size)) return; }
     }
     T* __restrict__ tab = grad_grid + (size_t)li.table_off * C;
 
@@ -462,350 +446,529 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
     }
 }
 
-// ---------------------------------------------------------------- K14, MI355X form (D = 3, C = 2)
-// Scattered global float atomics execute at the memory side on gfx950 (~20 G requests/s chip-wide,
-// MI355X_MICROARCH "Global float atomics"): 128 of them per sample made k_grid_bwd 54% of the train step.
-// Here the gradient table is cut into 128 KiB partitions (32768 half2 / 16384 float2 entries) and ONE
-// persistent workgroup owns a partition in LDS: it streams the samples, keeps the contributions that fall
-// into its partition with LDS atomics (ds_pk_add_f16 / ds_add_f32) and finally adds the partition to
-// grad_grid with plain coalesced read-modify-writes.  No global atomic on the hashed levels.
-//   hashed level : partition = index >> SHIFT depends only on the (y', z') corner pair because x' < 2^SHIFT, so
-//                  one test covers the two x corners; every partition workgroup scans all samples.
-//   dense level  : few partitions; the samples are additionally cut into slices and each LANE walks a run of
-//                  consecutive samples, summing in registers while the cell stays the same (samples of one ray
-//                  share coarse cells) -- this removes the same-address LDS conflicts.  Slices of one partition
-//                  are combined with contiguous (full-rate) global atomics.
-// grads come in [L][B][2] (the reference's layout); the [B, L*2] variant is transposed into a workspace first.
-constexpr int LB_THREADS = 1024;
+// ---------------------------------------------------------------- K14, MI355X form (D = 3, C = 2), round 2
+// Scattered global float atomics execute at the memory side on gfx950 (~20 G requests/s chip-wide, MI355X_MICROARCH
+// "Global float atomics"): 128 of them per sample made k_grid_bwd 54 % of the first train step.  Instead the gradient
+// table is cut into partitions of PART = 4096 entries and the contributions are ROUTED to the partition's owner by a
+// counting sort:
+//
+//   k_bwd_walk<COUNT> : block = UNIT = (level, 1024 consecutive samples), 4 consecutive samples per lane.  While the cell
+//                is unchanged the 8 corner contributions are summed in registers; every finished cell yields ITEMS: one
+//                per (y', z') corner row = {key: entry e0 inside the partition | how to get e1 from e0, values of the x
+//                and x+1 corners} (10 bytes for fp16 gradients) -- both x corners share a partition unless the pair
+//                straddles a partition boundary, which costs two single-corner items.  COUNT only needs the positions:
+//                items per partition (LDS histogram) -> the unit's counter row + its column of the per-partition table.
+//   k_bwd_scan_units / k_bwd_scan_parts : exclusive scans over the units of a partition and over the partitions:
+//                where every unit's run of every partition starts in the queue.
+//   k_bwd_walk<FILL>  : same walk with the gradients; items are ranked inside the block (LDS counters), laid out
+//                partition by partition in an LDS staging area and leave for the queue as whole runs (consecutive lanes,
+//                consecutive slots: in round 1 every 16-byte item was its own L2 request and the pass ran at the L2
+//                request rate).  No global atomics anywhere.
+//   k_bwd_acc  : one workgroup per (level, partition[, sub-range]) -- handed out through a device-side ticket, fullest
+//                first -- streams its contiguous queue range, accumulates in LDS and adds the partition to the table with
+//                coalesced read-modify-writes.  fp16 gradients accumulate EXACTLY as 2^-24 fixed point in int64 LDS words
+//                (every fp16 value is a multiple of 2^-24; random-address ds_add_u64 costs ~0.3 cycles per lane-op,
+//                tools/ubench/lds_acc2.hip), and the table entry becomes RN_half(old + sum) with ONE rounding: order
+//                independent, deterministic.  A non-finite contribution (overflowed loss scale) marks its entry, which is
+//                written as NaN so that the optimizer's non-finite scan sees it (an integer accumulator would otherwise
+//                silently turn Inf into a finite number).  fp32 gradients use ds_add_f32.
+// Levels with few partitions are split into SUB sub-ranges so that ~16 workgroups share every level; each stores its exact
+// partial sums and the last to arrive adds them in a fixed order (no float atomics: same bits whatever the order).
+// Levels with more than BK_MAX partitions (T > 2^21) are left to k_grid_bwd.
+template <typename T> struct BVal;
+template <> struct BVal<half_t> { using type = uint2; };       // {half2 of corner x, half2 of corner x+1}
+template <> struct BVal<float> { using type = float4; };
+constexpr int FILL_THREADS = 256;
+constexpr int SPT = 4;                                         // consecutive samples per lane and segment
+constexpr int SEGS = 1;                                        // segments per block: a lane walks SPT * SEGS consecutive samples
+constexpr uint32_t UNIT_SAMPLES = FILL_THREADS * SPT;          // 512
+constexpr uint32_t STAGE_CAP = 4096;                           // items staged in LDS (all of a unit unless corner pairs split)
+constexpr uint32_t KEY_SINGLE = 15u, KEY_NEXT = 14u;           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1); 14 -> e0 + 1
+constexpr int ACC_THREADS = 1024;
+constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
+constexpr uint32_t SUB_RECS = 32;                              // sub-range records per level (P * SUB < 32 whenever SUB > 1)
+constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
+constexpr uint32_t TICKET_WORDS = TICKET_ARRIVALS + MAX_LEVELS * SUB_RECS;
+template <typename T> constexpr uint32_t sub_rec_words() { return (sizeof(T) == 2 ? 2 * PART : PART) + PART / 64; }
 
-template <typename T>
-__device__ __forceinline__ void lds_acc_add(uint32_t* acc, uint32_t e, float v0, float v1) {
-    if constexpr (sizeof(T) == 2) {
-        half2_t v = {(half_t)v0, (half_t)v1};
-        __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) half2_t*)(acc) + e, v);
-    } else {
-        float* a = reinterpret_cast<float*>(acc) + 2 * e;
-        atomicAdd(a, v0);
-        atomicAdd(a + 1, v1);
-    }
+// the plan: everything the fill / accumulate passes need to know about where items go (positions only)
+struct BwdPlan {
+    uint16_t* cnt;        // [L * U][BK_MAX]   per unit: items per (partition, lane copy) counter
+    uint32_t* part_cnt;   // [L][BK_MAX][U]    per partition: items of every unit, then (in place) their exclusive prefix
+    uint32_t* totals;     // [L][BK_MAX]       items per partition
+    uint32_t* offs;       // [L][BK_MAX]       first queue slot of every partition
+    uint32_t* tickets;    // [TICKET_WORDS]
+};
+
+__device__ __forceinline__ uint32_t pack_half2(float a, float b) {
+    const half2_t h = {(half_t)a, (half_t)b};
+    return __builtin_bit_cast(uint32_t, h);
 }
 
-// MI355X grid backward, work-efficient form (D = 3, C = 2).
-//   k_bin<COUNT> : every lane walks BIN_SPT CONSECUTIVE samples of one level (samples of a ray stay in a cell for
-//                  many steps at coarse/mid levels) and sums the 8 corner contributions in registers while the cell is
-//                  unchanged; each finished cell emits ITEMS = {entry offsets e0|e1<<16, value0, value1}:
-//                    hashed level : 4 items, one per (y',z') corner pair (both x corners share a partition because
-//                                   x' < 2^SHIFT, and bucket = hash >> SHIFT depends on (y',z') only)
-//                    dense level  : 8 single-corner items (e1 = NONE)
-//                  COUNT pass: per-bucket item counts (LDS histogram -> one global add per bucket per block).
-//   k_bin_scan   : exclusive scan of the bucket counts -> queue offsets / cursors.
-//   k_bin<FILL>  : same walk, items appended to their bucket's queue (block-local rank from the LDS histogram,
-//                  one global cursor add per bucket per block -> contiguous runs).
-//   k_bin_acc    : one workgroup per bucket: queue -> LDS accumulators -> grad_grid.
-// bucket = (level, partition p of 2^SHIFT entries, sub-bucket): levels with few partitions are split into SUB
-// sub-buckets by block id so that ~16 workgroups share every level.
-// fp16 grads accumulate EXACTLY as 2^-24 fixed point in int64 LDS words (ds_add_u64 ~0.8 cycles / lane-op vs ~3.2 for
-// ds_add_f32 / ds_pk_add_f16 on gfx950, tools/ubench/lds_atomic.hip; every fp16 value is a multiple of 2^-24), so the
-// result is the correctly rounded sum of the fp16 contributions, independent of order.  fp32 grads use ds_add_f32.
 template <typename T, bool FILL>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin(
+__global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
-    uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t nb,
-    uint32_t* __restrict__ block_counts, const uint32_t* __restrict__ offs, HItem<T>* __restrict__ queue) {
-    constexpr uint32_t SHIFT = HShift<T>::value, PART = 1u << SHIFT;
-    const uint32_t level = blockIdx.x / nb, chunk = blockIdx.x % nb;
+    uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t U, BwdPlan plan,
+    typename BVal<T>::type* __restrict__ qvals, uint16_t* __restrict__ qkeys) {
+    using V = typename BVal<T>::type;
+    const uint32_t NBLK = U / SEGS;                           // U is a multiple of SEGS
+    const uint32_t level = blockIdx.x / NBLK, chunk = blockIdx.x % NBLK;
+    if (FILL && blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < TICKET_WORDS; k += FILL_THREADS) plan.tickets[k] = 0;   // work queue / arrival counters of the accumulate pass
     const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
-    const LevelBins lb = level_bins<T>(li);
-    const uint32_t nbk = lb.P * lb.SUB;
-    if (!level_is_binned<T>(li.hashmap_size, li.resolution, li.use_hash)) return;   // handled by the generic atomic kernel
-    __shared__ uint32_t hist[BK_MAX];
-    __shared__ uint32_t base[BK_MAX];
-    const uint32_t tid = threadIdx.x;
-    uint32_t* __restrict__ my_counts = block_counts + ((size_t)level * nb + chunk) * BK_MAX;
-    hist[tid] = 0;                                      // BIN_THREADS == BK_MAX
-    // FILL: queue position of this block's first item per bucket = bucket offset + exclusive count of earlier blocks
-    if (FILL) base[tid] = tid < nbk ? offs[level * BK_MAX + tid] + my_counts[tid] : 0u;
-    __syncthreads();
-    const uint32_t sub = chunk % lb.SUB;
-    const uint32_t pmask = lb.P - 1, emask = min(li.hashmap_size, PART) - 1;
-    const bool nowrap = li.nowrap;
-    const uint32_t b0 = (chunk * BIN_THREADS + tid) * BIN_SPT;
+    const uint32_t P = (li.hashmap_size + PART - 1) >> PART_SHIFT;
+    if (P > BK_MAX) return;                                // handled by the generic atomic kernel
+    __shared__ uint32_t hist[BK_MAX], start[BK_MAX + 1], gbase[FILL ? BK_MAX : 1];
+    __shared__ __attribute__((aligned(16))) V s_vals[FILL ? STAGE_CAP : 1];
+    __shared__ __attribute__((aligned(16))) uint16_t s_keys[FILL ? STAGE_CAP : 8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // a lane walks SPT * SEGS consecutive samples; every segment of SPT samples per lane is a UNIT with its own counter
+    // row / queue runs (the staging area holds one unit), the cell a lane is in is carried from segment to segment
+    const uint32_t b0 = (chunk * FILL_THREADS + tid) * (SPT * SEGS);
+    // few partitions: all lanes of a wave count into the same one or two counters, and same-address LDS atomics of one
+    // instruction serialise -> NC copies per partition, lane l uses copy l mod NC (sub-runs inside the partition's run).
+    // Coarse levels keep arrival order instead: the accumulate pass merges neighbouring repeats.
+    const uint32_t NC = (P <= BK_MAX / 8 && li.resolution >= COARSE_RES) ? 8u : 1u;
+    const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
+    const bool wide_ok = (reinterpret_cast<uintptr_t>(inputs) & 15) == 0;
+    const bool gwide = FILL && ((size_t)level * B * 2 * sizeof(T)) % 16 == 0 && (reinterpret_cast<uintptr_t>(gradT) & 15) == 0;
 
-    // ---- pass A: walk the samples, build the merged cells in registers (at most BIN_SPT cells)
-    // per cell: key coords + 16 accumulated values.  Processed twice (rank, then emit) to keep registers small.
-    float xs[BIN_SPT][3]; float g0[BIN_SPT], g1[BIN_SPT];
-    if (b0 + BIN_SPT <= B) {
-        const float4* src = reinterpret_cast<const float4*>(inputs + (size_t)b0 * 3);      // 96 B per lane, 16 B aligned
-        float4 v[BIN_SPT * 3 / 4];
-#pragma unroll
-        for (int i = 0; i < BIN_SPT * 3 / 4; i++) v[i] = src[i];
-        const float* vf = reinterpret_cast<const float*>(v);
-#pragma unroll
-        for (int s_ = 0; s_ < BIN_SPT; s_++) { xs[s_][0] = vf[3 * s_]; xs[s_][1] = vf[3 * s_ + 1]; xs[s_][2] = vf[3 * s_ + 2]; }
-    } else {
-#pragma unroll
-        for (int s_ = 0; s_ < BIN_SPT; s_++) {
-            const uint32_t b = min(b0 + s_, B - 1);
-            xs[s_][0] = inputs[(size_t)b * 3]; xs[s_][1] = inputs[(size_t)b * 3 + 1]; xs[s_][2] = inputs[(size_t)b * 3 + 2];
-        }
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < BIN_SPT; s_++)
-#pragma unroll
-        for (int d = 0; d < 3; d++) xs[s_][d] = (xs[s_][d] + sc.in_shift) * sc.in_scale;
-    if constexpr (FILL) {                               // the COUNT pass depends on the positions only (it can run before
-        const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;   // the gradients exist: lae_grid_encode_backward_plan)
-        // a lane's BIN_SPT gradients are contiguous (64 B in fp16): wide loads when the whole window is in range and the
-        // level's slice keeps 16-byte alignment (one vector-memory instruction per 4 / 2 samples instead of one each)
-        if (b0 + BIN_SPT <= B && ((size_t)level * B * 2 * sizeof(T)) % 16 == 0 && (reinterpret_cast<uintptr_t>(gradT) & 15) == 0) {
-            if constexpr (sizeof(T) == 2) {
-                const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const half2_t*>(g_lvl) + b0);
-#pragma unroll
-                for (int q = 0; q < BIN_SPT / 4; q++) {
-                    const uint4 v = src[q];
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const half2_t gv = __builtin_bit_cast(half2_t, w[k]);
-                        g0[4 * q + k] = (float)gv[0]; g1[4 * q + k] = (float)gv[1];
-                    }
-                }
-            } else {
-                const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(g_lvl) + b0);
-#pragma unroll
-                for (int q = 0; q < BIN_SPT / 2; q++) {
-                    const float4 v = src[q];
-                    g0[2 * q] = v.x; g1[2 * q] = v.y; g0[2 * q + 1] = v.z; g1[2 * q + 1] = v.w;
-                }
-            }
-        } else {
-#pragma unroll
-        for (int s_ = 0; s_ < BIN_SPT; s_++) {
-            const uint32_t b = min(b0 + s_, B - 1);
-            if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
-            else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
-        }
-        }
-    } else {
-#pragma unroll
-        for (int s_ = 0; s_ < BIN_SPT; s_++) { g0[s_] = 0.f; g1[s_] = 0.f; }
-    }
-
-    // emit one finished cell: `mode` 0 = count/rank (returns ranks through rk[]), 1 = write items
     uint32_t cpg[3] = {0, 0, 0};
+    bool have = false;
     float a0[8], a1[8];
-    auto cell_items = [&](auto&& visit) {
-        // visit(bucket, e, v0a, v0b, v1a, v1b) for every item of the current cell
+#pragma unroll
+    for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
+
+    // items of the cell cp: visit(corner slot of the x corner, counter index, key, pair?) per corner row
+    auto cell_items = [&](const uint32_t (&cp)[3], auto&& visit) {
+        uint32_t hy0 = 0, hy1 = 0, hz0 = 0, hz1 = 0, key0 = 0;
         if (li.use_hash) {
-            const uint32_t hy0 = cpg[1] * 2654435761u, hy1 = hy0 + 2654435761u;
-            const uint32_t hz0 = cpg[2] * 805459861u, hz1 = hz0 + 805459861u;
+            hy0 = cp[1] * 2654435761u; hy1 = hy0 + 2654435761u;
+            hz0 = cp[2] * 805459861u; hz1 = hz0 + 805459861u;
+        } else key0 = cp[0] * li.stride[0] + cp[1] * li.stride[1] + cp[2] * li.stride[2];
 #pragma unroll
-            for (int yz = 0; yz < 4; yz++) {
+        for (int yz = 0; yz < 4; yz++) {
+            uint32_t i0, i1;
+            if (li.use_hash) {
                 const uint32_t h = ((yz & 1) ? hy1 : hy0) ^ ((yz & 2) ? hz1 : hz0);
-                const uint32_t bk = ((h >> SHIFT) & pmask) * lb.SUB + sub;
-                const uint32_t e = ((cpg[0] ^ h) & emask) | ((((cpg[0] + 1) ^ h) & emask) << 16);
-                visit(yz, bk, e, a0[2 * yz], a1[2 * yz], a0[2 * yz + 1], a1[2 * yz + 1]);
+                i0 = cp[0] ^ h; i1 = (cp[0] + 1) ^ h;
+            } else {
+                i0 = key0 + ((yz & 1) ? li.stride[1] : 0u) + ((yz & 2) ? li.stride[2] : 0u);
+                i1 = i0 + li.stride[0];
             }
-        } else {
-            const uint32_t key = cpg[0] * li.stride[0] + cpg[1] * li.stride[1] + cpg[2] * li.stride[2];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t idx = key + ((c & 1) ? li.stride[0] : 0u) + ((c & 2) ? li.stride[1] : 0u) + ((c & 4) ? li.stride[2] : 0u);
-                if (!nowrap) idx = li.pow2 ? (idx & (li.hashmap_size - 1)) : (idx % li.hashmap_size);
-                const uint32_t bk = (idx >> SHIFT) * lb.SUB + sub;
-                // corner order c = x + 2y + 4z; accumulators are stored pair-major: slot = 2*(c>>1) + (c&1)
-                visit(c, bk, (idx & (PART - 1)) | (E_NONE << 16), a0[c], a1[c], 0.0f, 0.0f);
+            if (li.pow2) { i0 &= li.hashmap_size - 1; i1 &= li.hashmap_size - 1; }
+            else if (li.use_hash || !li.nowrap) { i0 %= li.hashmap_size; i1 %= li.hashmap_size; }
+            const uint32_t e0 = i0 & (PART - 1), e1 = i1 & (PART - 1), d = e0 ^ e1;
+            const bool same_part = (i0 >> PART_SHIFT) == (i1 >> PART_SHIFT) && d != 0;
+            const uint32_t c0 = (i0 >> PART_SHIFT) * NC + (lane & (NC - 1)), c1 = (i1 >> PART_SHIFT) * NC + (lane & (NC - 1));
+            if (same_part && e1 == e0 + 1) visit(2 * yz, c0, e0 | (KEY_NEXT << 12), true);
+            else if (same_part && (d & (d + 1)) == 0) visit(2 * yz, c0, e0 | ((uint32_t)(__builtin_popcount(d) - 1) << 12), true);
+            else {
+                visit(2 * yz, c0, e0 | (KEY_SINGLE << 12), false);
+                visit(2 * yz + 1, c1, e1 | (KEY_SINGLE << 12), false);
             }
         }
     };
 
-    // one sweep over the lane's samples.  COUNT: histogram only.  FILL: slot = LDS fill counter (any unique slot in
-    // the block's reserved range is fine; the accumulation is order independent for fp16, see k_bin_acc).
-    {
-        bool have = false;
-#pragma unroll
-        for (int c = 0; c < 8; c++) { a0[c] = 0; a1[c] = 0; }
-        auto finish = [&]() {
-            if (!FILL) {
-                cell_items([&](int, uint32_t bk, uint32_t, float, float, float, float) { atomicAdd(&hist[bk], 1u); });
-            } else {
-                cell_items([&](int, uint32_t bk, uint32_t e, float va, float vb, float vc, float vd) {
-                    HItem<T> it;
-                    it.e = e; it.pad = 0;
-                    if constexpr (sizeof(T) == 2) { it.v0 = half2_t{(half_t)va, (half_t)vb}; it.v1 = half2_t{(half_t)vc, (half_t)vd}; }
-                    else { it.v0x = va; it.v0y = vb; it.v1x = vc; it.v1y = vd; }
-                    queue[(size_t)base[bk] + atomicAdd(&hist[bk], 1u)] = it;
-                });
+    for (int seg = 0; seg < SEGS; seg++) {
+        const uint32_t u = chunk * SEGS + seg, unit = level * U + u;
+        const uint32_t bs = b0 + seg * SPT;
+        const bool last = seg == SEGS - 1;
+        if (!FILL) { for (uint32_t k = tid; k < BK_MAX; k += FILL_THREADS) hist[k] = 0; }
+        else {
+            // the unit's own counters (from the count pass) and where its run of every partition starts in the queue
+            for (uint32_t k = tid; k < BK_MAX / 2; k += FILL_THREADS) {
+                const uint32_t w = reinterpret_cast<const uint32_t*>(plan.cnt + (size_t)unit * BK_MAX)[k];
+                hist[2 * k] = w & 0xffffu; hist[2 * k + 1] = w >> 16;
             }
+            for (uint32_t k = tid; k < P; k += FILL_THREADS)
+                gbase[k] = plan.offs[level * BK_MAX + k] + plan.part_cnt[((size_t)level * BK_MAX + k) * U + u];
+        }
+        // ---- positions (and gradients) of SPT consecutive samples
+        float xs[SPT][3], g0[SPT], g1[SPT];
+        if (bs + SPT <= B && wide_ok) {
+            const float4* src = reinterpret_cast<const float4*>(inputs + (size_t)bs * 3);            // 48 B per lane
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
+            xs[0][0] = v0.x; xs[0][1] = v0.y; xs[0][2] = v0.z; xs[1][0] = v0.w; xs[1][1] = v1.x; xs[1][2] = v1.y;
+            xs[2][0] = v1.z; xs[2][1] = v1.w; xs[2][2] = v2.x; xs[3][0] = v2.y; xs[3][1] = v2.z; xs[3][2] = v2.w;
+        } else {
 #pragma unroll
-            for (int c = 0; c < 8; c++) { a0[c] = 0; a1[c] = 0; }
-        };
-#pragma unroll
-        for (int s_ = 0; s_ < BIN_SPT; s_++) {
-            if (b0 + s_ >= B) break;
-            float frac[3]; uint32_t pg[3]; bool ok = true;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float xv = xs[s_][d];
-                ok = ok && !(xv < 0.0f) && !(xv > 1.0f);
-                float pp = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
-                const float fl = floorf(pp);
-                pg[d] = (uint32_t)fl;
-                pp -= (float)pg[d];
-                if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
-                frac[d] = pp;
-            }
-            if (!ok) continue;
-            if (!have || pg[0] != cpg[0] || pg[1] != cpg[1] || pg[2] != cpg[2]) {
-                if (have) finish();
-                cpg[0] = pg[0]; cpg[1] = pg[1]; cpg[2] = pg[2]; have = true;
-            }
-            // slot c = x + 2y + 4z = x + 2*yz: the same numbering serves the pair items (hashed) and corner items (dense)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const float w = (((c & 1) ? frac[0] : 1 - frac[0]) * ((c & 2) ? frac[1] : 1 - frac[1])) * ((c & 4) ? frac[2] : 1 - frac[2]);
-                a0[c] = fmaf(w, g0[s_], a0[c]); a1[c] = fmaf(w, g1[s_], a1[c]);
+            for (int s_ = 0; s_ < SPT; s_++) {
+                const uint32_t b = min(bs + s_, B - 1);
+                xs[s_][0] = inputs[(size_t)b * 3]; xs[s_][1] = inputs[(size_t)b * 3 + 1]; xs[s_][2] = inputs[(size_t)b * 3 + 2];
             }
         }
-        if (have) finish();
-    }
-    if (!FILL) {
+        if constexpr (FILL) {
+            if (bs + SPT <= B && gwide) {
+                if constexpr (sizeof(T) == 2) {
+                    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const half2_t*>(g_lvl) + bs);
+                    const uint32_t w[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { const half2_t h = __builtin_bit_cast(half2_t, w[k]); g0[k] = (float)h[0]; g1[k] = (float)h[1]; }
+                } else {
+                    const float4* gs = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(g_lvl) + bs);
+                    const float4 ga = gs[0], gb = gs[1];
+                    g0[0] = ga.x; g1[0] = ga.y; g0[1] = ga.z; g1[1] = ga.w; g0[2] = gb.x; g1[2] = gb.y; g0[3] = gb.z; g1[3] = gb.w;
+                }
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < SPT; s_++) {
+                    const uint32_t b = min(bs + s_, B - 1);
+                    if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
+                    else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < SPT; s_++) { g0[s_] = 0.f; g1[s_] = 0.f; }
+        }
+        uint32_t pgs[SPT][3]; float frs[SPT][3]; bool oks[SPT];
+#pragma unroll
+        for (int s_ = 0; s_ < SPT; s_++) {
+            bool ok = bs + s_ < B;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float xv = (xs[s_][d] + sc.in_shift) * sc.in_scale;
+                ok = ok && !(xv < 0.0f) && !(xv > 1.0f);                     // gridencoder.cu:276-281
+                float pp = fmaf(xv, li.scale, align_corners ? 0.0f : 0.5f);
+                const float fl = floorf(pp);
+                pgs[s_][d] = (uint32_t)fl;
+                pp -= (float)pgs[s_][d];
+                if (interp == 1) pp = pp * pp * (3.0f - 2.0f * pp);
+                frs[s_][d] = pp;
+            }
+            oks[s_] = ok;
+        }
         __syncthreads();
-        my_counts[tid] = hist[tid];                     // coalesced; zeros included (the scan reads every slot)
+        if constexpr (!FILL) {
+            // ---- how many items does each (partition, copy) counter get from this unit
+            auto count_cell = [&]() { cell_items(cpg, [&](int, uint32_t ci, uint32_t, bool) { atomicAdd(&hist[ci], 1u); }); };
+#pragma unroll
+            for (int s_ = 0; s_ < SPT; s_++) {
+                if (!oks[s_]) continue;
+                if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
+                    if (have) count_cell();
+                    cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
+                }
+            }
+            if (last && have) count_cell();
+            __syncthreads();
+            for (uint32_t k = tid; k < BK_MAX / 2; k += FILL_THREADS)
+                reinterpret_cast<uint32_t*>(plan.cnt + (size_t)unit * BK_MAX)[k] = hist[2 * k] | (hist[2 * k + 1] << 16);   // <= 8192 each
+            for (uint32_t k = tid; k < P; k += FILL_THREADS) {
+                uint32_t n = 0;
+                for (uint32_t c = 0; c < NC; c++) n += hist[k * NC + c];
+                plan.part_cnt[((size_t)level * BK_MAX + k) * U + u] = n;
+            }
+            __syncthreads();                                   // hist is zeroed again by the next segment
+        } else {
+            // ---- exclusive scan over the counters (one wave, 8 counters per lane) -> where each sub-run starts in the staging area
+            if (tid < 64) {
+                uint32_t v[BK_MAX / 64], sum = 0;
+#pragma unroll
+                for (int k = 0; k < (int)(BK_MAX / 64); k++) { v[k] = hist[tid * (BK_MAX / 64) + k]; sum += v[k]; }
+                uint32_t run = lae::wave_incl_scan(sum) - sum;
+#pragma unroll
+                for (int k = 0; k < (int)(BK_MAX / 64); k++) { start[tid * (BK_MAX / 64) + k] = run; run += v[k]; }
+                if (tid == 63) start[BK_MAX] = run;
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < BK_MAX; k += FILL_THREADS) hist[k] = 0;         // now the fill counters
+            const uint32_t total = start[BK_MAX];
+            const bool staged = total <= STAGE_CAP;
+            __syncthreads();
+            // ---- sums + emission, sorted by partition (slot = sub-run start + arrival order inside it)
+            auto emit_cell = [&]() {
+                cell_items(cpg, [&](int c, uint32_t ci, uint32_t key, bool pair) {
+                    const uint32_t slot = start[ci] + atomicAdd(&hist[ci], 1u);
+                    V val;
+                    if constexpr (sizeof(T) == 2) { val.x = pack_half2(a0[c], a1[c]); val.y = pair ? pack_half2(a0[c + 1], a1[c + 1]) : 0u; }
+                    else { val.x = a0[c]; val.y = a1[c]; val.z = pair ? a0[c + 1] : 0.f; val.w = pair ? a1[c + 1] : 0.f; }
+                    if (staged) { s_vals[slot] = val; s_keys[slot] = (uint16_t)key; }
+                    else {          // more items than the staging area holds (split corner pairs): straight to the queue
+                        const uint32_t k = ci / NC, dst = gbase[k] + (slot - start[k * NC]);
+                        qvals[dst] = val; qkeys[dst] = (uint16_t)key;
+                    }
+                });
+#pragma unroll
+                for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
+            };
+#pragma unroll
+            for (int s_ = 0; s_ < SPT; s_++) {
+                if (!oks[s_]) continue;
+                if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
+                    if (have) emit_cell();
+                    cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float w = (((c & 1) ? frs[s_][0] : 1 - frs[s_][0]) * ((c & 2) ? frs[s_][1] : 1 - frs[s_][1])) * ((c & 4) ? frs[s_][2] : 1 - frs[s_][2]);
+                    a0[c] = fmaf(w, g0[s_], a0[c]); a1[c] = fmaf(w, g1[s_], a1[c]);
+                }
+            }
+            if (last && have) emit_cell();
+            __syncthreads();
+            if (staged) {
+                // ---- the staged runs leave for the queue, one partition at a time per wave: consecutive lanes, consecutive slots
+                const uint32_t wv = tid >> 6;
+#pragma unroll 4
+                for (uint32_t k = wv; k < P; k += FILL_THREADS / 64) {
+                    const uint32_t s0 = start[k * NC], s1 = start[(k + 1) * NC], gb = gbase[k];
+                    for (uint32_t i = s0 + lane; i < s1; i += 64) { qvals[gb + (i - s0)] = s_vals[i]; qkeys[gb + (i - s0)] = s_keys[i]; }
+                }
+            }
+            __syncthreads();                                   // staging / counters are reused by the next segment
+        }
     }
 }
 
-// per bucket: exclusive scan over the blocks' counts (in place) and bucket total.  One wavefront per (level, bucket).
-__global__ __launch_bounds__(256) void k_bin_scan_blocks(uint32_t* __restrict__ block_counts, uint32_t* __restrict__ counts,
-                                                          uint32_t L, uint32_t nb) {
+// per partition: exclusive scan over the units' counts (in place) and the partition total.  One wavefront per (level, partition).
+__global__ __launch_bounds__(256) void k_bwd_scan_units(const int32_t* __restrict__ offsets, uint32_t L, uint32_t U, BwdPlan plan) {
     const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= L * BK_MAX) return;
+    const uint32_t level = t / BK_MAX, k = t % BK_MAX;
+    const uint32_t size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t P = (size + PART - 1) >> PART_SHIFT;
     const int lane = threadIdx.x & 63;
-    const uint32_t level = t / BK_MAX, bk = t % BK_MAX;
-    uint32_t* p = block_counts + (size_t)level * nb * BK_MAX + bk;
+    if (P > BK_MAX || k >= P) { if (lane == 0) plan.totals[t] = 0; return; }
+    uint32_t* p = plan.part_cnt + (size_t)t * U;
     uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+    for (uint32_t c0 = 0; c0 < U; c0 += 64) {
         const uint32_t c = c0 + lane;
-        const uint32_t v = c < nb ? p[(size_t)c * BK_MAX] : 0u;
+        const uint32_t v = c < U ? p[c] : 0u;
         const uint32_t inc = lae::wave_incl_scan(v);
-        if (c < nb) p[(size_t)c * BK_MAX] = carry + inc - v;
+        if (c < U) p[c] = carry + inc - v;
         carry += __shfl(inc, 63, 64);
     }
-    if (lane == 0) counts[t] = carry;
+    if (lane == 0) plan.totals[t] = carry;
 }
 
-// bucket totals -> exclusive offsets (global item index).  One small block.
-__global__ __launch_bounds__(1024) void k_bin_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs, uint32_t n,
-                                                   uint32_t* __restrict__ tickets) {
+// partition totals -> first queue slot of every partition.  One block.
+__global__ __launch_bounds__(1024) void k_bwd_scan_parts(uint32_t n, BwdPlan plan) {
     __shared__ uint32_t lds[17];
-    if (threadIdx.x < 2) tickets[threadIdx.x] = 0;          // work queue of the accumulate pass starts empty-handed
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? counts[i] : 0;
+        const uint32_t v = i < n ? plan.totals[i] : 0;
         uint32_t total;
         const uint32_t ex = lae::block_excl_scan<16>(v, &total, lds);
-        if (i < n) offs[i] = carry + ex;
+        if (i < n) plan.offs[i] = carry + ex;
         carry += total;
     }
 }
 
-// fp16 bits -> value * 2^24 as a signed integer (exact: fp16 values are multiples of 2^-24, |v| * 2^24 < 2^40)
-__device__ __forceinline__ long long half_to_fix24(half_t v) {
-    const uint32_t u = (uint32_t)__builtin_bit_cast(uint16_t, v);
+// fp16 bits -> value * 2^24 as a signed integer (exact: finite fp16 values are multiples of 2^-24, |v| * 2^24 < 2^40)
+__device__ __forceinline__ long long half_to_fix24(uint32_t u) {
     const uint32_t e = (u >> 10) & 31u, m = u & 1023u;
     const unsigned long long mag = e ? ((unsigned long long)(m | 1024u) << (e - 1)) : (unsigned long long)m;
     return (u & 0x8000u) ? -(long long)mag : (long long)mag;
 }
+// value * 2^24 (signed integer) -> nearest fp16 (ties to even), ONE rounding; overflow -> infinity
+__device__ __forceinline__ uint32_t fix24_to_half(long long t) {
+    const uint32_t sign = t < 0 ? 0x8000u : 0u;
+    const unsigned long long mag = t < 0 ? (unsigned long long)(-t) : (unsigned long long)t;
+    if (mag < 1024ull) return sign | (uint32_t)mag;              // zero / subnormal: exact
+    const int msb = 63 - __builtin_clzll(mag);                   // >= 10
+    const int shift = msb - 10;
+    unsigned long long q = mag >> shift;                         // 11 bits, leading one included
+    if (shift > 0) {
+        const unsigned long long rem = mag & ((1ull << shift) - 1ull), halfway = 1ull << (shift - 1);
+        if (rem > halfway || (rem == halfway && (q & 1ull))) q++;
+    }
+    int e = msb - 9;                                             // biased exponent
+    if (q == 2048ull) { q = 1024ull; e++; }
+    if (e >= 31) return sign | 0x7c00u;
+    return sign | ((uint32_t)e << 10) | ((uint32_t)q & 1023u);
+}
+__device__ __forceinline__ bool half_nonfinite(uint32_t u) { return (u & 0x7c00u) == 0x7c00u; }
 
 template <typename T>
-__global__ __launch_bounds__(LB_THREADS) void k_bin_acc(
+__global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
-    bool align_corners, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offs,
-    const HItem<T>* __restrict__ queue, uint32_t* __restrict__ tickets) {
+    bool align_corners, BwdPlan plan, const typename BVal<T>::type* __restrict__ qvals, const uint16_t* __restrict__ qkeys,
+    unsigned long long* __restrict__ partials) {
+    using V = typename BVal<T>::type;
     constexpr bool HALF = sizeof(T) == 2;
-    constexpr uint32_t SHIFT = HShift<T>::value, PART = 1u << SHIFT;
-    __shared__ unsigned long long acc64[16384];         // 128 KiB: int64[8192][2] (fp16 grads) or float2[16384]
+    constexpr uint32_t ACCW = HALF ? 2 * PART : PART;
+    // fp16 grads: int64 acc0[PART] | acc1[PART] (channel 0 / 1, SoA: fewer bank conflicts than interleaved); fp32: float[2 * PART]
+    __shared__ unsigned long long acc64[ACCW];
+    __shared__ uint32_t poison[PART / 32];
+    __shared__ uint32_t s_cnt[MAX_LEVELS], s_sub[MAX_LEVELS], s_first[MAX_LEVELS];
+    __shared__ uint32_t s_ticket, s_arr;
     const uint32_t tid = threadIdx.x;
-    // bucket list, level-major; per-level bucket counts computed ONCE into LDS (decoding must not walk offsets[]
-    // with dependent global loads: that serial walk cost ~300 us in an earlier version)
-    __shared__ uint32_t s_cnt[MAX_LEVELS], s_sub[MAX_LEVELS];
     if (tid < L) {
-        const LevelInfo<3> li_ = level_info<3>(sc, offsets, tid, gridtype, align_corners);
-        const LevelBins lb = level_bins<T>(li_);
-        s_cnt[tid] = level_is_binned<T>(li_.hashmap_size, li_.resolution, li_.use_hash) ? lb.P * lb.SUB : 0u;
+        const LevelBins lb = level_bins_of((uint32_t)(offsets[tid + 1] - offsets[tid]));
+        s_cnt[tid] = lb.P <= BK_MAX ? lb.P * lb.SUB : 0u;
         s_sub[tid] = lb.SUB;
     }
     __syncthreads();
-    uint32_t total = 0;
-    for (uint32_t l = 0; l < L; l++) total += s_cnt[l];
-    // Buckets are handed out through one device-side counter, finest levels (the full queues) first: with the static
-    // round-robin deal 788 buckets over 256 workgroups meant 3 buckets for most and 4 for some, of very different sizes.
-    __shared__ uint32_t s_ticket;
-    for (;;) {
-        if (tid == 0) s_ticket = atomicAdd(&tickets[0], 1u);
-        __syncthreads();
-        const uint32_t t = s_ticket;
-        __syncthreads();
-        if (t >= total) break;
-        const uint32_t item = total - 1u - t;
-        uint32_t level = 0, bk = item;
-        while (bk >= s_cnt[level]) { bk -= s_cnt[level]; level++; }
-        const uint32_t SUB = s_sub[level], p = bk / SUB;
-        const LevelInfo<3> li = level_info<3>(sc, offsets, level, gridtype, align_corners);
-        const uint32_t n = counts[level * BK_MAX + bk];
-        if (n == 0) continue;                               // uniform per block
-        for (uint32_t i = tid; i < 16384; i += LB_THREADS) acc64[i] = 0ull;
-        __syncthreads();
-        const HItem<T>* __restrict__ q = queue + offs[level * BK_MAX + bk];
-        auto apply = [&](const HItem<T>& it) {
-            const uint32_t e0 = it.e & 0xffffu, e1 = it.e >> 16;
-            if constexpr (HALF) {
-                atomicAdd(&acc64[2 * e0], (unsigned long long)half_to_fix24(it.v0[0]));
-                atomicAdd(&acc64[2 * e0 + 1], (unsigned long long)half_to_fix24(it.v0[1]));
-                if (e1 != E_NONE) {
-                    atomicAdd(&acc64[2 * e1], (unsigned long long)half_to_fix24(it.v1[0]));
-                    atomicAdd(&acc64[2 * e1 + 1], (unsigned long long)half_to_fix24(it.v1[1]));
-                }
-            } else {
-                float* af = reinterpret_cast<float*>(acc64);
-                atomicAdd(af + 2 * e0, it.v0x); atomicAdd(af + 2 * e0 + 1, it.v0y);
-                if (e1 != E_NONE) { atomicAdd(af + 2 * e1, it.v1x); atomicAdd(af + 2 * e1 + 1, it.v1y); }
-            }
-        };
-        // four queue loads in flight per lane before the first LDS atomic (the loop is latency bound otherwise)
-        uint32_t i = tid;
-        for (; i + 3 * LB_THREADS < n; i += 4 * LB_THREADS) {
-            const HItem<T> i0 = q[i], i1 = q[i + LB_THREADS], i2 = q[i + 2 * LB_THREADS], i3 = q[i + 3 * LB_THREADS];
-            apply(i0); apply(i1); apply(i2); apply(i3);
-        }
-        for (; i < n; i += LB_THREADS) apply(q[i]);
-        __syncthreads();
-        const uint32_t part_lo = p << SHIFT;
-        const uint32_t n_ent = min(PART, li.hashmap_size - part_lo);
-        T* __restrict__ dst = grad_grid + ((size_t)li.table_off + part_lo) * 2;
+    if (tid == 0) { uint32_t run = 0; for (uint32_t l = 0; l < L; l++) { s_first[l] = run; run += s_cnt[l]; } s_arr = run; }
+    __syncthreads();
+    const uint32_t total_buckets = s_arr;
+    __syncthreads();
+
+    auto apply = [&](uint32_t key, const V& v) {
+        const uint32_t e0 = key & (PART - 1), code = key >> 12;
+        const uint32_t e1 = code == KEY_NEXT ? e0 + 1 : (e0 ^ ((2u << code) - 1u));
         if constexpr (HALF) {
-            half2_t* d2 = reinterpret_cast<half2_t*>(dst);
-            for (uint32_t e = tid; e < n_ent; e += LB_THREADS) {
-                const long long i0 = (long long)acc64[2 * e], i1 = (long long)acc64[2 * e + 1];
-                const float s0 = (float)i0 * 5.9604644775390625e-08f, s1 = (float)i1 * 5.9604644775390625e-08f;   // * 2^-24
-                if (SUB == 1) {      // only writer of this table slice: plain coalesced read-modify-write
-                    const half2_t o = d2[e];
-                    d2[e] = half2_t{(half_t)((float)o[0] + s0), (half_t)((float)o[1] + s1)};
-                } else if (i0 != 0 || i1 != 0) {
-                    __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) half2_t*)(d2 + e), half2_t{(half_t)s0, (half_t)s1});
+            const uint32_t w0 = v.x, w1 = v.y;
+            if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
+            else {
+                atomicAdd(&acc64[e0], (unsigned long long)half_to_fix24(w0 & 0xffffu));
+                atomicAdd(&acc64[PART + e0], (unsigned long long)half_to_fix24(w0 >> 16));
+            }
+            if (code != KEY_SINGLE) {
+                if (half_nonfinite(w1) || half_nonfinite(w1 >> 16)) atomicOr(&poison[e1 >> 5], 1u << (e1 & 31));
+                else {
+                    atomicAdd(&acc64[e1], (unsigned long long)half_to_fix24(w1 & 0xffffu));
+                    atomicAdd(&acc64[PART + e1], (unsigned long long)half_to_fix24(w1 >> 16));
                 }
             }
         } else {
+            float* af = reinterpret_cast<float*>(acc64);
+            atomicAdd(af + e0, v.x); atomicAdd(af + PART + e0, v.y);
+            if (code != KEY_SINGLE) { atomicAdd(af + e1, v.z); atomicAdd(af + PART + e1, v.w); }
+        }
+    };
+
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(&plan.tickets[0], 1u);
+        __syncthreads();
+        const uint32_t t = s_ticket;
+        if (t >= total_buckets) break;
+        const uint32_t item = t;                                // coarse levels first: their sub-ranges + merge are the longest chains
+        uint32_t level = 0;
+        while (level + 1 < L && item >= s_first[level + 1]) level++;
+        const uint32_t bk = item - s_first[level];
+        const uint32_t SUB = s_sub[level], p = bk / SUB, sub = bk % SUB;
+        const uint32_t table_off = (uint32_t)offsets[level], hashmap_size = (uint32_t)offsets[level + 1] - table_off;
+        const uint32_t n = plan.totals[level * BK_MAX + p], q0 = plan.offs[level * BK_MAX + p];
+        const uint32_t lo = (uint32_t)(((uint64_t)n * sub) / SUB), hi = (uint32_t)(((uint64_t)n * (sub + 1)) / SUB);
+        if (n == 0) { __syncthreads(); continue; }              // uniform per (level, partition): no sub-range has work
+        for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = 0ull;
+        if (tid < PART / 32) poison[tid] = 0u;
+        __syncthreads();
+        const uint32_t scale_res = (uint32_t)ceilf(sc.scale[level]) + 1;
+        const V* __restrict__ pv = qvals + q0;
+        const uint16_t* __restrict__ pk = qkeys + q0;
+        if (scale_res >= COARSE_RES) {
+            uint32_t i = lo + tid;
+            for (; i + 3 * ACC_THREADS < hi; i += 4 * ACC_THREADS) {              // four loads in flight per lane
+                V v[4]; uint32_t k[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[j] = pv[i + j * ACC_THREADS]; k[j] = pk[i + j * ACC_THREADS]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) apply(k[j], v[j]);
+            }
+            for (; i < hi; i += ACC_THREADS) { const V v = pv[i]; const uint32_t k = pk[i]; apply(k, v); }
+        } else {
+            // coarse level: a cell holds many samples of a ray and many rays, so consecutive queue items repeat the same
+            // key, and same-address LDS atomics of ONE instruction serialise (level 0: 16 workgroups x 70 k atomics at ~2
+            // cycles each = the whole pass).  Each lane takes 8 CONSECUTIVE items and sums them in registers while the key
+            // repeats: one atomic group per run, neighbouring lanes 8 items apart.
+            for (uint32_t c = lo + tid * 8u; c < hi; c += ACC_THREADS * 8u) {
+                V v[8]; uint32_t k[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const uint32_t ii = min(c + (uint32_t)j, hi - 1u); v[j] = pv[ii]; k[j] = pk[ii]; }
+                const uint32_t cnt = min(8u, hi - c);
+                if constexpr (HALF) {
+                    uint32_t ckey = k[0];
+                    long long s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+                    bool bad0 = false, bad1 = false;
+                    auto flush = [&]() {
+                        const uint32_t e0 = ckey & (PART - 1), code = ckey >> 12;
+                        const uint32_t e1 = code == KEY_NEXT ? e0 + 1 : (e0 ^ ((2u << code) - 1u));
+                        if (bad0) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
+                        else { atomicAdd(&acc64[e0], (unsigned long long)s00); atomicAdd(&acc64[PART + e0], (unsigned long long)s01); }
+                        if (code != KEY_SINGLE) {
+                            if (bad1) atomicOr(&poison[e1 >> 5], 1u << (e1 & 31));
+                            else { atomicAdd(&acc64[e1], (unsigned long long)s10); atomicAdd(&acc64[PART + e1], (unsigned long long)s11); }
+                        }
+                    };
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if ((uint32_t)j < cnt) {
+                            if (k[j] != ckey) { flush(); ckey = k[j]; s00 = s01 = s10 = s11 = 0; bad0 = bad1 = false; }
+                            const uint32_t w0 = v[j].x, w1 = v[j].y;
+                            if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) bad0 = true;
+                            else { s00 += half_to_fix24(w0 & 0xffffu); s01 += half_to_fix24(w0 >> 16); }
+                            if (half_nonfinite(w1) || half_nonfinite(w1 >> 16)) bad1 = true;
+                            else { s10 += half_to_fix24(w1 & 0xffffu); s11 += half_to_fix24(w1 >> 16); }
+                        }
+                    }
+                    flush();
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if ((uint32_t)j < cnt) apply(k[j], v[j]);
+                }
+            }
+        }
+        __syncthreads();
+        if (SUB > 1) {
+            // ---- sub-ranges of one partition: every one stores its exact partial sums (+ its non-finite marks); the LAST
+            // to arrive adds them up in a fixed order and writes the table.  Hand-off per MI355X_MICROARCH "Workgroup
+            // dispatch ... visibility", the form without fences (an agent release writes back ALL dirty lines of the
+            // XCD's L2 -- tens of MB of queue right after the fill pass: 40 us per level measured): every store of the
+            // handed-off words write-through (sc1), every wave's vmcnt(0), barrier, one lane's counter add; the last
+            // arriver (told by the value its add returned) reads them with sc1 loads.
+            unsigned long long* __restrict__ mine = partials + (size_t)(level * SUB_RECS + bk) * sub_rec_words<T>();
+            for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) __hip_atomic_store(mine + i, acc64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < PART / 32) __hip_atomic_store(reinterpret_cast<uint32_t*>(mine + ACCW) + tid, poison[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) s_arr = atomicAdd(&plan.tickets[TICKET_ARRIVALS + level * SUB_RECS + p], 1u);
+            __syncthreads();
+            if (s_arr != SUB - 1) { __syncthreads(); continue; }
+            const unsigned long long* __restrict__ first = partials + (size_t)(level * SUB_RECS + p * SUB) * sub_rec_words<T>();
+            for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) {
+                if constexpr (HALF) {
+                    long long sum = 0;
+                    for (uint32_t k = 0; k < SUB; k++) sum += (long long)__hip_atomic_load(first + (size_t)k * sub_rec_words<T>() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc64[i] = (unsigned long long)sum;
+                } else {
+                    float s0 = 0.f, s1 = 0.f;
+                    for (uint32_t k = 0; k < SUB; k++) {
+                        const unsigned long long w = __hip_atomic_load(first + (size_t)k * sub_rec_words<T>() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float2 v = __builtin_bit_cast(float2, w); s0 += v.x; s1 += v.y;
+                    }
+                    reinterpret_cast<float2*>(acc64)[i] = make_float2(s0, s1);
+                }
+            }
+            if (tid < PART / 32) {
+                uint32_t m = 0;
+                for (uint32_t k = 0; k < SUB; k++) m |= __hip_atomic_load(reinterpret_cast<const uint32_t*>(first + (size_t)k * sub_rec_words<T>() + ACCW) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                poison[tid] = m;
+            }
+            __syncthreads();
+        }
+        const uint32_t part_lo = p << PART_SHIFT;
+        const uint32_t n_ent = min(PART, hashmap_size - part_lo);
+        T* __restrict__ dst = grad_grid + ((size_t)table_off + part_lo) * 2;
+        if constexpr (HALF) {
+            uint32_t* d2 = reinterpret_cast<uint32_t*>(dst);
+            for (uint32_t e = tid; e < n_ent; e += ACC_THREADS) {
+                const long long i0 = (long long)acc64[e], i1 = (long long)acc64[PART + e];
+                const bool bad = (poison[e >> 5] >> (e & 31)) & 1u;
+                if (i0 == 0 && i1 == 0 && !bad) continue;
+                const uint32_t o = d2[e];                  // only writer of this table slice: old + exact sum, rounded ONCE
+                uint32_t r0, r1;
+                if (bad) { r0 = 0x7e00u; r1 = 0x7e00u; }
+                else {
+                    r0 = half_nonfinite(o) ? (o & 0xffffu) : fix24_to_half(i0 + half_to_fix24(o & 0xffffu));
+                    r1 = half_nonfinite(o >> 16) ? (o >> 16) : fix24_to_half(i1 + half_to_fix24(o >> 16));
+                }
+                d2[e] = r0 | (r1 << 16);
+            }
+        } else {
             const float* af = reinterpret_cast<const float*>(acc64);
-            for (uint32_t e = tid; e < 2 * n_ent; e += LB_THREADS) {
-                const float v = af[e];
-                if (SUB == 1) dst[e] += v; else if (v != 0.0f) atomicAdd(dst + e, v);
+            float2* d2 = reinterpret_cast<float2*>(dst);
+            for (uint32_t e = tid; e < n_ent; e += ACC_THREADS) {
+                const float v0 = af[e], v1 = af[PART + e];
+                if (v0 == 0.0f && v1 == 0.0f) continue;
+                float2 o = d2[e]; o.x += v0; o.y += v1; d2[e] = o;
             }
         }
         __syncthreads();
     }
-    if (tid == 0 && atomicAdd(&tickets[1], 1u) == gridDim.x - 1) { tickets[0] = 0; tickets[1] = 0; }   // last one out resets
 }
 
 // [L][B][2] -> [B][L][2] through an LDS tile: the gather kernel writes level-major (each level's block stores 256
@@ -925,13 +1088,13 @@ struct FwdArgs {
     const float* inputs; const void* emb; const int32_t* offsets; void* out; uint32_t B, L; LevelScales sc;
     void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
     const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
+    const int32_t* offsets_host = nullptr;                      // the caller's host copy of `offsets` (L + 1 ints) or NULL
 };
 
 // ---- schedule of k_grid_fwd_lean (see the kernel's header).  Relative cost of one chunk of a level, calibrated on the
 // bench batches (tools/ubench/grid_fwd_variants.hip, then a sweep with tools/grid_fwd_bench.py on one-view and 16-view
 // batches): dense 1; hashed 1.25 up to resolution ~80, rising with log2(resolution) to 2.3 at ~550 (consecutive samples of a
 // ray stop sharing cache lines) and 4.5 from ~1000 on (every corner row is its own L2 request).  Only the balance depends on it, never a result.
-static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t L, hipStream_t stream);
 static float fwd_level_cost(bool hashed, uint32_t resolution) {
     if (!hashed) return 1.0f;
     const float lr = log2f((float)resolution);
@@ -948,13 +1111,13 @@ static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // le
     }
 }
 // returns the largest number of blocks any XCD owns
-static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const std::vector<int32_t>* offs) {
+static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const int32_t* offs) {
     bool ok = offs != nullptr && L <= 32 && nb >= 64;
     float cost[MAX_LEVELS]; bool dense[MAX_LEVELS];
     if (ok) {
         for (uint32_t l = 0; l < L; l++) {
             const uint32_t res = (uint32_t)ceilf(sc.scale[l]) + 1;
-            const uint64_t size = (uint64_t)((*offs)[l + 1] - (*offs)[l]);
+            const uint64_t size = (uint64_t)(offs[l + 1] - offs[l]);
             const uint64_t full = (uint64_t)(res + 1) * (res + 1) * (res + 1);
             dense[l] = full <= size;
             cost[l] = fwd_level_cost(!dense[l], res);
@@ -1007,7 +1170,7 @@ static void launch_fwd(const FwdArgs& a) {
     if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
         if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
             FwdSched fs;
-            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? host_offsets(a.offsets, a.L, a.stream) : nullptr);
+            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr);
             k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
                                                                       fs, a.os_b, a.os_l, a.B_dev);
             return;
@@ -1042,6 +1205,7 @@ static int dispatch_fwd_d(const FwdArgs& a, uint32_t D, uint32_t C) {
 struct BwdArgs {
     const void* grad; const float* inputs; const int32_t* offsets; void* gemb; uint32_t B, L; LevelScales sc;
     uint32_t gridtype; bool align; uint32_t interp; uint64_t gs_b, gs_l; hipStream_t stream;
+    const int32_t* offsets_host = nullptr;
 };
 template <typename T, int D, int C>
 static void launch_bwd(const BwdArgs& a) {
@@ -1084,11 +1248,12 @@ static int dispatch_bwd_d(const BwdArgs& a, uint32_t D, uint32_t C) {
 static int grid_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
                         uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype,
                         int align_corners, uint32_t interp, int dtype, bool blc, void* stream, float in_shift = 0.0f,
-                        float in_scale = 1.0f) {
+                        float in_scale = 1.0f, const int32_t* offsets_host = nullptr) {
     if (B == 0) return LAE_OK;
     if (!inputs || !embeddings || !offsets || !outputs) return LAE_ENULL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
     FwdArgs a;
+    a.offsets_host = offsets_host;
     a.inputs = inputs; a.emb = embeddings; a.offsets = offsets; a.out = outputs; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1100,7 +1265,7 @@ static int grid_forward(const float* inputs, const void* embeddings, const int32
     const bool staged = blc && C == 2 && L <= 32;
     void* lbc = nullptr;
     if (staged) {
-        lbc = lae::workspace(lae::WS_GRID_OUT_T, (size_t)B * L * C * (dtype == LAE_F16 ? 2 : 4));
+        lbc = lae::workspace(lae::WS_GRID_OUT_T, (size_t)B * L * C * (dtype == LAE_F16 ? 2 : 4), a.stream);
         if (!lbc) return LAE_ELAUNCH;
         a.out = lbc;
     }
@@ -1117,78 +1282,79 @@ static int grid_forward(const float* inputs, const void* embeddings, const int32
     return lae::check_launch("grid_encode_forward");
 }
 
-// Level sizes on the host: offsets live in device memory (the reference passes a tensor), so the first call with a
-// given (pointer, L) copies the L+1 ints once, synchronously, and later calls reuse them.  First calls happen during
-// eager warm-up (workspaces are allocated there too), never inside a stream capture.
-struct HostOffsets { const int32_t* ptr; uint32_t L; std::vector<int32_t> v; };
-static const std::vector<int32_t>* host_offsets(const int32_t* offsets, uint32_t L, hipStream_t stream) {
-    static std::vector<HostOffsets> cache;
-    for (const auto& c : cache)
-        if (c.ptr == offsets && c.L == L) return &c.v;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    HostOffsets h{offsets, L, std::vector<int32_t>(L + 1)};
-    if (hipMemcpy(h.v.data(), offsets, sizeof(int32_t) * (L + 1), hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;                                    // unknown: callers take the conservative path
-    }
-    if (cache.size() > 64) cache.clear();
-    cache.push_back(std::move(h));
-    return &cache.back().v;
+// The binned backward in two halves.  PLAN (count pass + scans) reads the sample positions only and fills {tickets |
+// partition totals | partition offsets | per-unit counter rows | per-partition unit table}; EXEC (fill + accumulate) needs the
+// gradients.  A caller may run PLAN early -- e.g. right after the march, on another stream beside the forward pass
+// (lae_grid_encode_backward_plan) -- the default entry points run both back to back with the plan in the library workspace.
+// Library workspace of EXEC: {partial sums of sub-ranges | queue: values, keys}; the queue is sized for the worst case of 8
+// items per (sample, level) -- hashed levels produce 4 -- and only its front is ever touched.
+struct PlanLayout { size_t totals_off, offs_off, cnt_off, part_off, bytes; };
+static inline uint32_t bwd_units(uint32_t B) { return lae::cdiv(B, UNIT_SAMPLES * SEGS) * SEGS; }
+static inline PlanLayout plan_layout(uint32_t B, uint32_t L) {
+    const size_t U = bwd_units(B);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    PlanLayout w;
+    w.totals_off = up((size_t)TICKET_WORDS * 4);
+    w.offs_off = w.totals_off + up((size_t)L * BK_MAX * 4);
+    w.cnt_off = w.offs_off + up((size_t)L * BK_MAX * 4);
+    w.part_off = w.cnt_off + up((size_t)L * U * BK_MAX * 2);
+    w.bytes = w.part_off + up((size_t)L * BK_MAX * U * 4);
+    return w;
 }
-
-// The binned backward in two halves.  PLAN (count pass + scans) reads the sample positions only and fills
-// {bucket totals | bucket offsets | per-block exclusive counts}; EXEC (fill + accumulate) needs the gradients.  A caller
-// may run PLAN early -- e.g. right after the march, beside the forward pass (lae_grid_encode_backward_plan) -- the default
-// entry points run both back to back in the library workspace.
-static inline size_t bin_tab_bytes(uint32_t L) { return (((size_t)2 * L * BK_MAX * 4 + 255) / 256) * 256 + 256; }   // + {ticket, done} of k_bin_acc
-static inline size_t bin_plan_bytes(uint32_t B, uint32_t L) {
-    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
-    return bin_tab_bytes(L) + (((size_t)nb * L * BK_MAX * 4 + 255) / 256) * 256;
-}
-struct BinPlan { uint32_t* counts; uint32_t* offs; uint32_t* block_counts; uint32_t* tickets; };
-static inline BinPlan bin_plan_at(void* buf, uint32_t L) {
+static inline BwdPlan plan_at(void* buf, uint32_t B, uint32_t L) {
+    const PlanLayout lay = plan_layout(B, L);
     uint8_t* p = reinterpret_cast<uint8_t*>(buf);
-    BinPlan bp;
-    bp.counts = reinterpret_cast<uint32_t*>(p);
-    bp.offs = bp.counts + (size_t)L * BK_MAX;
-    bp.block_counts = reinterpret_cast<uint32_t*>(p + bin_tab_bytes(L));
-    bp.tickets = reinterpret_cast<uint32_t*>(p + bin_tab_bytes(L) - 256);
-    return bp;
+    BwdPlan plan;
+    plan.tickets = reinterpret_cast<uint32_t*>(p);
+    plan.totals = reinterpret_cast<uint32_t*>(p + lay.totals_off);
+    plan.offs = reinterpret_cast<uint32_t*>(p + lay.offs_off);
+    plan.cnt = reinterpret_cast<uint16_t*>(p + lay.cnt_off);
+    plan.part_cnt = reinterpret_cast<uint32_t*>(p + lay.part_off);
+    return plan;
+}
+template <typename T>
+static inline size_t bwd_exec_ws_bytes(uint32_t B, uint32_t L) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t cap = (size_t)L * bwd_units(B) * UNIT_SAMPLES * 8;
+    return up((size_t)L * SUB_RECS * sub_rec_words<T>() * 8) + up(cap * sizeof(typename BVal<T>::type)) + up(cap * 2);
 }
 
 template <typename T>
-static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t L, const BwdArgs& a, const BinPlan& bp) {
-    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
-    const size_t n_tab = (size_t)L * BK_MAX;
-    k_bin<T, false><<<nb * L, BIN_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
-                                                        bp.block_counts, bp.offs, nullptr);
-    k_bin_scan_blocks<<<lae::cdiv(n_tab, 4), 256, 0, a.stream>>>(bp.block_counts, bp.counts, L, nb);
-    k_bin_scan<<<1, 1024, 0, a.stream>>>(bp.counts, bp.offs, (uint32_t)n_tab, bp.tickets);
+static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t L, const BwdArgs& a, const BwdPlan& plan) {
+    const uint32_t U = bwd_units(B);
+    k_bwd_walk<T, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
+    k_bwd_scan_units<<<lae::cdiv((size_t)L * BK_MAX, 4), 256, 0, a.stream>>>(offsets, L, U, plan);
+    k_bwd_scan_parts<<<1, 1024, 0, a.stream>>>(L * BK_MAX, plan);
 }
 
 template <typename T>
-static int bwd_exec(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L, const BwdArgs& a,
-                    const BinPlan& bp, HItem<T>* queue) {
+static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L,
+                           const BwdArgs& a, const void* caller_plan = nullptr) {
+    using V = typename BVal<T>::type;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const uint32_t U = bwd_units(B);
+    const size_t plan_bytes = caller_plan ? 0 : plan_layout(B, L).bytes;
+    uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, plan_bytes + bwd_exec_ws_bytes<T>(B, L), a.stream));
+    if (!ws) return LAE_ELAUNCH;
+    const BwdPlan plan = plan_at(caller_plan ? const_cast<void*>(caller_plan) : ws, B, L);
+    uint8_t* ex = ws + plan_bytes;
+    unsigned long long* partials = reinterpret_cast<unsigned long long*>(ex);
+    const size_t cap = (size_t)L * U * UNIT_SAMPLES * 8;
+    V* qvals = reinterpret_cast<V*>(ex + up((size_t)L * SUB_RECS * sub_rec_words<T>() * 8));
+    uint16_t* qkeys = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(qvals) + up(cap * sizeof(V)));
     const T* g = (const T*)gT;
     T* ge = (T*)gemb;
-    const uint32_t nb = lae::cdiv(B, BIN_THREADS * BIN_SPT);
-    k_bin<T, true><<<nb * L, BIN_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, nb,
-                                                       bp.block_counts, bp.offs, queue);
-    k_bin_acc<T><<<(uint32_t)lae::num_cus(), LB_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, bp.counts, bp.offs, queue,
-                                                                        bp.tickets);
-    // levels with more buckets than the tables hold (fp16: T > 2^21): generic atomic kernel; skipped when the host copy of
-    // the level sizes shows that no level needs it
+    if (!caller_plan) bwd_plan<T>(inputs, offsets, B, L, a, plan);
+    k_bwd_walk<T, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
+    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials);
+    // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
+    // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
+    // (its blocks return at once for the levels the binned path has handled).
     bool need_generic = true;
-    if (const std::vector<int32_t>* ho = host_offsets(offsets, L, a.stream)) {
+    if (a.offsets_host) {
         need_generic = false;
-        for (uint32_t l = 0; l < L; l++) {
-            const uint32_t size = (uint32_t)((*ho)[l + 1] - (*ho)[l]);
-            const uint32_t res = (uint32_t)ceilf(a.sc.scale[l]) + 1;
-            const uint64_t side = a.align ? res : res + 1;
-            const bool use_hash = a.gridtype == 0 && side * side * side > size;
-            if (!level_is_binned<T>(size, res, use_hash)) need_generic = true;
-        }
+        for (uint32_t l = 0; l < L; l++)
+            if (!level_is_binned((uint32_t)(a.offsets_host[l + 1] - a.offsets_host[l]))) need_generic = true;
     }
     if (need_generic) {
         const uint32_t nbg = lae::cdiv(B, GRID_BLOCK);
@@ -1198,44 +1364,21 @@ static int bwd_exec(const void* gT, const float* inputs, const int32_t* offsets,
     return LAE_OK;
 }
 
-// queue of the fill / accumulate passes: worst case 8 items per (sample, level); library workspace
-template <typename T>
-static HItem<T>* bin_queue(uint32_t B, uint32_t L, size_t extra_bytes, uint8_t** base_out) {
-    const size_t q_bytes = (size_t)B * 8 * L * sizeof(HItem<T>);
-    uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, extra_bytes + q_bytes));
-    if (base_out) *base_out = ws;
-    return ws ? reinterpret_cast<HItem<T>*>(ws + extra_bytes) : nullptr;
-}
-
-template <typename T>
-static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* offsets, void* gemb, uint32_t B, uint32_t L,
-                           const BwdArgs& a, const void* plan = nullptr) {
-    if (plan) {                                            // counts / offsets were prepared by lae_grid_encode_backward_plan
-        HItem<T>* queue = bin_queue<T>(B, L, 0, nullptr);
-        if (!queue) return LAE_ELAUNCH;
-        return bwd_exec<T>(gT, inputs, offsets, gemb, B, L, a, bin_plan_at(const_cast<void*>(plan), L), queue);
-    }
-    uint8_t* ws = nullptr;
-    HItem<T>* queue = bin_queue<T>(B, L, bin_plan_bytes(B, L), &ws);
-    if (!queue) return LAE_ELAUNCH;
-    const BinPlan bp = bin_plan_at(ws, L);
-    bwd_plan<T>(inputs, offsets, B, L, a, bp);
-    return bwd_exec<T>(gT, inputs, offsets, gemb, B, L, a, bp, queue);
-}
-
 // 0 = binned LDS pipeline where available (default), 1 = always the generic global-atomic kernel
 static int g_force_atomic_bwd = 0;
 
 static int grid_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                          const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
-                         int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f, const void* plan = nullptr) {
+                         int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f,
+                         const int32_t* offsets_host = nullptr, const void* plan = nullptr) {
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
     if (plan && !(D == 3 && C == 2 && L <= 32 && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
     BwdArgs a;
+    a.offsets_host = offsets_host;
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1246,11 +1389,11 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     a.stream = reinterpret_cast<hipStream_t>(stream);
     if (dtype != LAE_F32 && dtype != LAE_F16) return LAE_EINVAL;
     if (D == 3 && C == 2 && L <= 32 && !g_force_atomic_bwd) {
-        // LDS-partitioned path (see k_grid_bwd_lds); [B, L*2] grads are transposed into the workspace first
+        // binned path (k_bwd_fill / k_bwd_acc); [B, L*2] grads are transposed into the workspace first
         const size_t esz = dtype == LAE_F16 ? 2 : 4;
         const void* gT = grad;
         if (blc) {
-            void* ws = lae::workspace(lae::WS_GRID_GRAD_T, (size_t)B * L * 2 * esz);
+            void* ws = lae::workspace(lae::WS_GRID_GRAD_T, (size_t)B * L * 2 * esz, a.stream);
             if (!ws) return LAE_ELAUNCH;
             if (dtype == LAE_F16) k_grad_transpose<half_t><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const half_t*)grad, (half_t*)ws, B, L);
             else k_grad_transpose<float><<<lae::cdiv(B, 256), 256, 0, a.stream>>>((const float*)grad, (float*)ws, B, L);
@@ -1295,9 +1438,11 @@ static int tv_c(const float* inputs, const float* emb, float* grad, const int32_
 // *B_dev are not touched.  B_launch = host upper bound of *B_dev (sizes the launch only).
 int lae::grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
                             uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
-                            int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream) {
+                            int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
+                            const int32_t* offsets_host) {
     if (B_launch == 0) return LAE_OK;
     FwdArgs a;
+    a.offsets_host = offsets_host;
     a.inputs = inputs; a.emb = embeddings; a.offsets = offsets; a.out = outputs; a.B = B_cap; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1317,13 +1462,6 @@ int lae_grid_encode_forward(const float* inputs, const void* embeddings, const i
     return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
                         dtype, false, stream);
 }
-int lae_grid_encode_forward_blc(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
-                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float in_shift,
-                                float in_scale, void* stream) {
-    return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
-                        dtype, true, stream, in_shift, in_scale);
-}
 int lae_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
@@ -1331,32 +1469,28 @@ int lae_grid_encode_backward(const void* grad, const float* inputs, const void* 
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, dtype, false, stream);
 }
-int lae_grid_encode_backward_blc(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
-                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
-                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                                 int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                 void* stream) {
-    return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, dtype, true, stream, in_shift, in_scale);
-}
 
 int lae_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, int blc, float in_shift,
-                               float in_scale, void* stream) {
+                               float in_scale, const int32_t* offsets_host, void* stream) {
     return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
-                        dtype, blc != 0, stream, in_shift, in_scale);
+                        dtype, blc != 0, stream, in_shift, in_scale, offsets_host);
 }
 int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                void* stream) {
+                                const int32_t* offsets_host, void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale);
+                         gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale, offsets_host);
 }
 
-uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L) { return bin_plan_bytes(B, L); }
+uint64_t lae_grid_backward_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
+    return plan_layout(B, L).bytes + (dtype == LAE_F16 ? bwd_exec_ws_bytes<half_t>(B, L) : bwd_exec_ws_bytes<float>(B, L));
+}
+
+uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L) { return plan_layout(B, L).bytes; }
 
 int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                   uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float in_shift,
@@ -1372,17 +1506,18 @@ int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, u
     a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
     a.gs_b = C; a.gs_l = (uint64_t)B * C;
     a.stream = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == LAE_F16) bwd_plan<half_t>(inputs, offsets, B, L, a, bin_plan_at(plan, L));
-    else bwd_plan<float>(inputs, offsets, B, L, a, bin_plan_at(plan, L));
+    if (dtype == LAE_F16) bwd_plan<half_t>(inputs, offsets, B, L, a, plan_at(plan, B, L));
+    else bwd_plan<float>(inputs, offsets, B, L, a, plan_at(plan, B, L));
     return lae::check_launch("grid_encode_backward_plan");
 }
 
 int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                     uint32_t interp, int dtype, float in_shift, float in_scale, const void* plan, void* stream) {
+                                     uint32_t interp, int dtype, float in_shift, float in_scale, const int32_t* offsets_host,
+                                     const void* plan, void* stream) {
     if (!plan) return LAE_ENULL;
     return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
-                         interp, dtype, false, stream, in_shift, in_scale, plan);
+                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan);
 }
 
 int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks, uint32_t* nseg_out,
@@ -1390,9 +1525,8 @@ int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, 
     if (!offsets_host || !nseg_out || !segs_out) return LAE_ENULL;
     LevelScales sc;
     if (fill_scales(sc, L, S, H) != LAE_OK || L > 8 * FWD_MAX_SEG) return LAE_EINVAL;
-    const std::vector<int32_t> offs(offsets_host, offsets_host + L + 1);
     FwdSched fs;
-    const uint32_t per_xcd = fwd_sched_build(fs, L, n_chunks, sc, &offs);
+    const uint32_t per_xcd = fwd_sched_build(fs, L, n_chunks, sc, offsets_host);
     for (int x = 0; x < 8; x++) {
         nseg_out[x] = fs.nseg[x];
         for (uint32_t q = 0; q < fs.nseg[x]; q++) {

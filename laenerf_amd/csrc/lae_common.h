@@ -11,10 +11,12 @@ namespace lae {
 void set_last_error(const char* what, hipError_t e);
 
 // Library-owned, grow-only device workspaces (the counterpart of the reference's process-global split-K
-// streams + CUTLASS workspace, ffmlp.cu:711-740, cutlass_matmul.h:335-352).  Returns nullptr on failure
-// (error string set).  Growing synchronises the device once; steady state is allocation free.
+// streams + CUTLASS workspace, ffmlp.cu:711-740, cutlass_matmul.h:335-352), one set per device.  Returns nullptr on
+// failure (error string set).  Steady state is allocation free; growth allocates a new buffer WITHOUT freeing the old
+// one (queued kernels and captured graphs may still use it) and is refused while `stream` is being captured.
 enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_GRID_OUT_T = 2, WS_GRID_BINS = 3, WS_SLOTS = 4 };
-void* workspace(WsSlot slot, size_t bytes);
+void* workspace(WsSlot slot, size_t bytes, hipStream_t stream);
+size_t workspace_bytes(bool retired);
 void free_workspaces();
 int num_cus();
 void set_last_error_str(const char* what);
@@ -23,7 +25,8 @@ void set_last_error_str(const char* what);
 // raymarching.hip): same kernels as the C ABI, live row count read from device memory
 int grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
                        uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
-                       int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream);
+                       int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
+                       const int32_t* offsets_host);
 int nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
                             uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
                             float* rgbs, hipStream_t stream);

@@ -1414,7 +1414,8 @@ int lae_render_frame_set_overlap(int on) { g_frame_overlap = on ? 1 : 0; return 
 
 int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
                      const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
-                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, uint32_t L, float S,
+                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,
+                     uint32_t L, float S,
                      uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp,
                      const void* sigma_weights, const void* color_weights, float density_scale, float T_thresh,
                      uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
@@ -1549,7 +1550,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
             look_pending = true;
         }
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
-                                     gridtype, align_corners, interp, in_shift, in_scale, s);
+                                     gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
         if (rc == LAE_OK)
             rc = lae::nerf_head_forward_frame(feats, dirs, sigma_weights, color_weights, (uint32_t)cap, rows_launch, &cur->n_rows,
                                               density_scale, sigmas, rgbs, s);

@@ -33,15 +33,15 @@ class _nerf_field(Function):
         S, H = np.log2(enc.per_level_scale), enc.base_resolution
         feats = torch.empty(L, M, 2, device=x.device, dtype=torch.half)                 # level-major
         _grid.grid_encode_forward(x, table, enc.offsets, feats, M, 3, 2, L, S, H, None, enc.gridtype_id, enc.align_corners,
-                                  enc.interp_id, blc=False, in_map=in_map)
+                                  enc.interp_id, blc=False, in_map=in_map, offsets_host=enc.offsets_host)
         h = torch.empty(M, 16, device=x.device, dtype=torch.half)
         sigmas = torch.empty(M, device=x.device, dtype=torch.float32)
         rgbs = torch.empty(M, 3, device=x.device, dtype=torch.float32)
         _mlp.nerf_head_forward(feats, dirs, ws, wc, M, density_scale, h, sigmas, rgbs, level_major=True)
         ctx.save_for_backward(x, dirs, table, ws, wc, feats, h, rgbs)
         ctx.enc, ctx.shadows, ctx.in_map, ctx.geom = enc, shadows, in_map, (M, L, S, H)
-        ctx.plan = plan
         ctx.density_scale = density_scale
+        ctx.plan = plan
         ctx.wdtypes = (sigma_weights.dtype, color_weights.dtype)
         return sigmas, rgbs
 
@@ -63,7 +63,7 @@ class _nerf_field(Function):
                                 gws, gwc, accumulate=ctx.shadows is not None, level_major=True)
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
-                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, plan=ctx.plan)
+                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, offsets_host=enc.offsets_host, plan=ctx.plan)
         return (None, None, None if enc.shadow is not None else grad_table,
                 None if ctx.shadows is not None else gws.to(ctx.wdtypes[0]),
                 None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None, None)

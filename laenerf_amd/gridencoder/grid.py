@@ -23,7 +23,7 @@ class _grid_encode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
-                align_corners=False, interpolation=0, shadow=None, in_map=(0.0, 1.0)):
+                align_corners=False, interpolation=0, shadow=None, in_map=(0.0, 1.0), offsets_host=None):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -41,7 +41,8 @@ class _grid_encode(Function):
         outputs = torch.empty(B, L * C, device=inputs.device, dtype=embeddings.dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                     align_corners, interpolation, blc=True, in_map=in_map)
+                                     align_corners, interpolation, blc=True, in_map=in_map, offsets_host=offsets_host)
+        ctx.offsets_host = offsets_host
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
         ctx.in_map = in_map
@@ -61,13 +62,14 @@ class _grid_encode(Function):
         grad_embeddings = ctx.shadow.grad_half if ctx.shadow is not None else torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                      grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True, in_map=ctx.in_map)
+                                      grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True, in_map=ctx.in_map,
+                                      offsets_host=ctx.offsets_host)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
             if ctx.in_map[1] != 1.0:
                 grad_inputs = grad_inputs * ctx.in_map[1]          # chain rule of the folded affine map
         return (grad_inputs, (None if ctx.shadow is not None else grad_embeddings), None, None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 class TableShadow:
@@ -128,6 +130,10 @@ class GridEncoder(nn.Module):
 
         offsets = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
         self.register_buffer("offsets", torch.from_numpy(offsets))
+        # the same numbers on the host: handed to the library with every call (balances the forward's level -> XCD
+        # schedule, lets the backward skip an idle launch; include/laenerf.h `offsets_host`).  The sizes are fixed by the
+        # constructor arguments (grid.py:118-127), so this copy cannot go stale.
+        self.offsets_host = offsets.copy()
         self.n_params = int(offsets[-1]) * level_dim
         self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
         self.shadow = None                                 # TableShadow once a FusedAdam owns the table
@@ -150,7 +156,8 @@ class GridEncoder(nn.Module):
         inputs = inputs.view(-1, self.input_dim)
         in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
         outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, self.shadow, in_map)
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, self.shadow, in_map,
+                              self.offsets_host)
         return outputs.view(prefix_shape + [self.output_dim])
 
     def attach_shadow(self):

@@ -396,7 +396,7 @@ def compact_rays_alive(rays_alive, n_alive=None):
 def render_frame(rays_o, rays_d, aabb, min_near, density_bitfield, bound, C, H, table_half, offsets, per_level_scale,
                  base_resolution, sigma_weights_half, color_weights_half, edit_bitfield=None, gridtype_id=0, align_corners=False,
                  interp_id=0, density_scale=1.0, dt_gamma=0, max_steps=1024, T_thresh=1e-4, max_n_step=8, row_budget=0,
-                 noises=None, bg_color=None, scale_depth=True, want_stats=False):
+                 noises=None, bg_color=None, scale_depth=True, want_stats=False, offsets_host=None):
     """MI355X-native: the inference loop of NeRFRenderer.run_cuda (nerf/renderer.py:335-387; run_cuda_distill :394-480
     when `edit_bitfield` is given) as ONE backend call -- loop state on the device, no host sync per iteration.
     Same per-ray arithmetic and iteration schedule as march_rays / network / composite_rays called in the Python loop.
@@ -427,7 +427,7 @@ def render_frame(rays_o, rays_d, aabb, min_near, density_bitfield, bound, C, H, 
                                   sigma_weights_half, color_weights_half, density_scale, T_thresh, max_n_step, row_budget,
                                   None if noises is None else _gpu(noises).float().contiguous(), bg_rays, bg_rgb,
                                   bg_color is not None, scale_depth, weights_sum, depth, image, weights_edit, depth_edit,
-                                  want_stats)
+                                  want_stats, offsets_host=offsets_host)
     out = {"image": image, "depth": depth, "weights_sum": weights_sum}
     if edit_bitfield is not None:
         out["weights_edit"], out["depth_edit"] = weights_edit, depth_edit

@@ -196,9 +196,9 @@ class NeRFRenderer(nn.Module):
                     plan_backward=False):
         """first half of the training render: ray/box intersection and the occupancy march (renderer.py:285-311).  It
         reads no network weight, so it can run for step k+1 while step k is still in its backward (bench.py replays it
-        as its own graph on a side stream: 0.575 -> 0.530 ms/step; a forked branch inside ONE captured graph did not
-        overlap on this stack).  plan_backward=True additionally runs the position-only half of the hash-grid
-        backward (counting pass + scans) here and returns the plan as a 7th element for shade_train."""
+        as its own graph on a side stream; a forked branch inside ONE captured graph did not overlap on this stack).
+        plan_backward=True additionally runs the position-only half of the hash-grid backward (counting pass + scans)
+        here and returns the plan as a 7th element for shade_train."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         grid = self.density_bitfield if dens_grid is None else dens_grid
@@ -258,7 +258,8 @@ class NeRFRenderer(nn.Module):
                                         edit_bitfield=edit_bitfield, gridtype_id=enc.gridtype_id, align_corners=enc.align_corners,
                                         interp_id=enc.interp_id, density_scale=self.density_scale, dt_gamma=dt_gamma,
                                         max_steps=max_steps, T_thresh=T_thresh, row_budget=row_budget, noises=noises,
-                                        bg_color=bg_color, scale_depth=scale_depth, want_stats=want_stats)
+                                        bg_color=bg_color, scale_depth=scale_depth, want_stats=want_stats,
+                                        offsets_host=getattr(enc, "offsets_host", None))
 
     _tile_perm_cache = {}
 

@@ -38,6 +38,10 @@ def test_version_and_no_compute_needed(hip_lib):
     # scratch-size helpers are pure host functions
     assert hip_lib.lae_march_rays_train_scratch_bytes(4096) >= 4 * 2 * 4096
     assert hip_lib.lae_compact_scratch_bytes(1000) >= 4000
+    # binned grid backward: one region per (level, 1024 samples), worst case 8 items x 10 bytes per sample (fp16 gradients)
+    assert hip_lib.lae_grid_backward_workspace_bytes(4096, 16, 1) >= 16 * 4096 * 8 * 10
+    assert hip_lib.lae_workspace_bytes(0) == 0 and hip_lib.lae_workspace_bytes(1) == 0     # nothing allocated without a GPU call
+    assert hip_lib.lae_free_workspaces() == 0
 
 
 def test_invalid_arguments_are_rejected_before_any_launch(hip_lib):

@@ -1,4 +1,4 @@
-"""hash-grid backward (fill + accumulate, planned) alone on the samples of one 4096-ray batch (event-timed)"""
+"""hash-grid backward (fill + accumulate) alone on the samples of one 4096-ray batch (event-timed)"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from laenerf_amd import synthetic as S
@@ -17,9 +17,8 @@ M = xyzs.shape[0]
 grad = (torch.randn(16, M, 2, device=dev) * 1e-2).half()
 ge = torch.zeros(enc.embeddings.shape, dtype=torch.half, device=dev)
 S_ = np.log2(enc.per_level_scale)
-plan = G.grid_backward_plan(xyzs, enc.offsets, M, 3, 2, 16, S_, 16, 0, False, 0, True, in_map=(1.0, 0.5))
 def run():
-    G.grid_encode_backward(grad, xyzs, None, enc.offsets, ge, M, 3, 2, 16, S_, 16, None, None, 0, False, 0, blc=False, in_map=(1.0, 0.5), plan=plan)
+    G.grid_encode_backward(grad, xyzs, None, enc.offsets, ge, M, 3, 2, 16, S_, 16, None, None, 0, False, 0, blc=False, in_map=(1.0, 0.5), offsets_host=enc.offsets_host)
 for rep in range(2):
     for _ in range(5): run()
     torch.cuda.synchronize()
