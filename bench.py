@@ -128,16 +128,31 @@ def cpu_baseline(n_rays_hint, n_threads):
                       f"without optimizer, oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
 
 
-def eval_frame(net, r, dev, H=800, W=800):
+def eval_model(dev, bound=1, seed=4321):
+    """the model every inference number of this file is quoted on: fixed seed, default initialisation, analytic occupancy
+    -- independent of --steps (round 1 rendered with the network as trained by the timed steps, so the frame time moved
+    with K)"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(seed)
+    net = NeRFNetwork(bound=bound).to(dev).eval()
+    r = NeRFRenderer(net, bound=bound, min_near=0.2).to(dev).eval()
+    C = r.cascade
+    grid = S.sphere_density_grid(cascade=C, bound=float(bound)) if bound == 1 else S.flower_density_grid()
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(grid, 10.0)).to(dev)
+    return net, r
+
+
+def eval_frame(dev, H=800, W=800):
     """whole-frame inference render (the march_rays / composite_rays loop of run_cuda, renderer.py:335-387) of one 800x800
-    view with the network as trained by the timed steps; median of 5 frames after one warm-up.  `ms_per_frame`: the loop as
+    view with the fixed model of eval_model(); median of 5 frames after one warm-up.  `ms_per_frame`: the loop as
     ONE backend call with its state on the device (lae_render_frame, reference schedule); `operator_loop_ms`: the same
     kernels driven operator by operator from Python like the reference's loop (one host read of n_alive per iteration)."""
     from laenerf_amd import synthetic as S
+    net, r = eval_model(dev)
     o, d = S.frame_rays(H, W)
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-    was_training = net.training
-    net.eval(); r.eval()
 
     def timed(**kw):
         times, res = [], None
@@ -150,13 +165,14 @@ def eval_frame(net, r, dev, H=800, W=800):
         return sorted(times[1:])[2], res
     t, res = timed(frame_loop=True, want_stats=True)
     t_op, res_op = timed(frame_loop=False)
-    net.train(was_training); r.train(was_training)
     return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
+            "Msamples_per_s": round(res["stats"]["rows"] / t / 1e6, 1),
             "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
             "iterations": res["stats"]["iterations"], "samples_through_network": res["stats"]["rows"],
             "operator_loop_ms": round(t_op * 1e3, 2),
             "max_abs_image_diff_vs_operator_loop": float((res["image"] - res_op["image"]).abs().max()),
-            "note": "800x800 inference render, T_thresh 1e-4, device-resident loop (lookahead marcher on a side stream)"}
+            "note": "800x800 inference render of the fixed eval model (seed 4321, default init: independent of --steps), T_thresh 1e-4, "
+                    "device-resident loop (lookahead marcher on a side stream)"}
 
 
 def frame_workload(args, world, rank, dev, backend_name):
@@ -167,12 +183,13 @@ def frame_workload(args, world, rank, dev, backend_name):
     from laenerf_amd.dist import render_frame_sharded
     from laenerf_amd.network import NeRFNetwork
     from laenerf_amd.renderer import NeRFRenderer
-    torch.manual_seed(1234)                                   # identical replicas
-    net = NeRFNetwork(bound=1).to(dev).eval()
-    r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev).eval()
-    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    # configs[3] is mip360/bonsai: scripts/configs_mip360/bonsai.sh has bound=2 -> 2 cascades (renderer.py:74), a 512 KiB
+    # bitfield and a 6 328 848-entry table (finest resolution 4096); the camera orbits INSIDE the bound-2 box
+    net, r = eval_model(dev, bound=2, seed=1234)              # identical replicas on every rank
+    from laenerf_amd.dist import broadcast_model_state
+    broadcast_model_state(r, src=0)                           # replicate table / MLPs / bitfield at load
     H, W = 1080, 1920
-    o, d = S.frame_rays(H, W, focal=1111.1 * H / 800)
+    o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 
     def render(ro, rd):
@@ -203,7 +220,8 @@ def frame_workload(args, world, rank, dev, backend_name):
             "metric": "Mrays/s, 1920x1080 whole-frame inference render", "value": round(H * W * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
-            "config": {"workload": "configs[3]-style: 1920x1080 rays of one view, L=16 T=2^19 hash grid + 2x64 / 3x64 ffmlp, cascade 1, "
+            "config": {"workload": "configs[3]-shaped (mip360/bonsai: bound 2, 2 cascades, 512 KiB bitfield, 6 328 848-entry table): "
+                                   "1920x1080 rays of one view from inside the box, L=16 T=2^19 hash grid + 2x64 / 3x64 ffmlp, "
                                    "analytic occupancy, device-resident inference loop per rank",
                        "rays_per_frame": H * W, "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
                        "parallelism": f"rays in 128-ray tiles dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}}),
@@ -278,6 +296,108 @@ def style_step(dev, P=100000, steps=30):
     dt = (time.perf_counter() - t0) / steps
     return {"ms_per_step": round(dt * 1e3, 4), "points": P, "Mpoints_per_s": round(P / dt / 1e6, 2),
             "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam, HIP-graph replay"}
+
+
+def flower_step(dev, steps=30, n_rays=4096):
+    """configs[2] (llff/flower: scripts/configs_llff/flower.sh -- bound 2 -> 2 cascades, offset (0, 0, 1.5): cameras inside
+    the box, min_near 0.2, table of 6 328 848 entries with finest resolution 4096): the same train step as the headline
+    (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam) on forward-facing synthetic rays, one captured HIP
+    graph replayed (no side-stream pipelining).  Extra field, not `value`."""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(99)
+    net = NeRFNetwork(bound=2).to(dev)
+    r = NeRFRenderer(net, bound=2, min_near=0.2).to(dev)
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.flower_density_grid(), 10.0)).to(dev)
+    opt = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    o, d = S.flower_like_rays(n_rays, seed=5)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    gt = torch.rand(n_rays, 3, device=dev)
+    net.train()
+
+    def body():
+        with torch.autocast("cuda", dtype=torch.float16):
+            res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024, gt=gt, scaler=opt)
+        opt.backward(res["loss"])
+        opt.step()
+        return res["n_samples"]
+    for i in range(17):                                       # mean_count mode needs 16 sized steps (renderer.py:644-647)
+        body()
+    r.update_mean_count()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        n_samples = body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 4), "Mrays_per_s": round(n_rays / dt / 1e6, 3), "rays": n_rays, "samples_per_step": int(n_samples),
+            "note": "configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box, one graph per step (not pipelined)"}
+
+
+def cpu_baseline_cfg1(n_threads, budget_s=8.0):
+    """the cfg1 train step -- `run()` path (renderer.py:128-256), 1024 rays x 512 uniform steps, L=4 hash grid,
+    nn.Linear-shaped nets (network.py:95-124) -- on the host cores: the oracle's operators + numpy, forward + backward,
+    whole steps repeated until the budget is spent."""
+    from oracle import oracle as O
+    from laenerf_amd import synthetic as S
+    offsets, pls = O.grid_offsets(num_levels=4, desired_resolution=2048)
+    rng = np.random.default_rng(0)
+    table = rng.uniform(-1e-4, 1e-4, (int(offsets[-1]), 2)).astype(np.float32)
+    W = [rng.uniform(-0.3, 0.3, sh).astype(np.float32) for sh in ((64, 8), (16, 64), (64, 31), (64, 64), (3, 64))]
+    o, d = S.lego_like_rays(1024, H=64, W=64, focal=1111.1 * 64 / 800, seed=3)
+    N, T = 1024, 512
+
+    def step():
+        nears, fars = O.near_far_from_aabb(o, d, [-1, -1, -1, 1, 1, 1], 0.2)
+        z = nears[:, None] + (fars - nears)[:, None] * np.linspace(0, 1, T, dtype=np.float32)[None]
+        xyz = np.clip(o[:, None] + d[:, None] * z[..., None], -1, 1).astype(np.float32).reshape(-1, 3)
+        x01 = ((xyz + 1) / 2).astype(np.float32)
+        enc, _ = O.grid_encode_forward(x01, table, offsets, pls, 16, out_blc=True)
+        h1 = np.maximum(enc @ W[0].T, 0); h = h1 @ W[1].T
+        sigma = np.exp(h[:, 0]).reshape(N, T)
+        deltas = np.concatenate([z[:, 1:] - z[:, :-1], ((fars - nears) / T)[:, None]], 1)
+        alphas = 1 - np.exp(-deltas * sigma)
+        trans = np.cumprod(np.concatenate([np.ones((N, 1), np.float32), 1 - alphas + 1e-15], 1), 1)[:, :-1]
+        w = alphas * trans
+        sh, _ = O.sh_encode_forward(np.repeat(d, T, axis=0), 4)
+        cin = np.concatenate([sh, h[:, 1:]], 1)
+        c1 = np.maximum(cin @ W[2].T, 0); c2 = np.maximum(c1 @ W[3].T, 0); c3 = c2 @ W[4].T
+        rgb = (1 / (1 + np.exp(-c3))).reshape(N, T, 3)
+        image = (w[..., None] * rgb).sum(1) + (1 - w.sum(1))[:, None]
+        # backward (MSE against 0.5): image -> rgb, w -> sigma (reverse cumulative sums) -> nets -> table
+        gimg = (2 * (image - 0.5) / image.size).astype(np.float32)
+        grgb = (w[..., None] * gimg[:, None]).reshape(-1, 3)
+        gw = ((rgb - 1.0) * gimg[:, None]).sum(-1)
+        sfx = np.cumsum((gw * w)[:, ::-1], 1)[:, ::-1] - gw * w
+        gsigma = (deltas * (gw * trans * (1 - alphas) - sfx)).astype(np.float32).reshape(-1)
+        gc3 = grgb * (rgb.reshape(-1, 3) * (1 - rgb.reshape(-1, 3)))
+        gc2 = (gc3 @ W[4]) * (c2 > 0); gc1 = (gc2 @ W[3]) * (c1 > 0); gcin = gc1 @ W[2]
+        gh = np.concatenate([(gsigma * sigma.reshape(-1))[:, None], gcin[:, 16:]], 1).astype(np.float32)
+        genc = ((gh @ W[1]) * (h1 > 0)) @ W[0]
+        O.grid_encode_backward(genc.astype(np.float32), x01, table.shape, offsets, pls, 16, grad_blc=True)
+        return N
+    torch.set_num_threads(n_threads)
+    step()                                                    # warm-up (page-in, BLAS threads)
+    t0 = time.perf_counter(); n = 0; k = 0
+    while time.perf_counter() - t0 < budget_s or k < 2:
+        n += step(); k += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt / 1e6, 6), "unit": "Mrays/s", "ms_per_step": round(dt / k * 1e3, 1), "steps": k,
+            "sample": f"{k} cfg1 train steps (run() path: 1024 rays x 512 steps = 524288 points, L=4 grid, nn.Linear-shaped nets), forward + "
+                      f"backward, oracle operators + numpy BLAS ({n_threads} host threads available), {dt:.1f} s"}
 
 
 def main():
@@ -572,6 +692,16 @@ def main():
         samples.append(step(n_warm + i))
     sync_all()
     dt = time.perf_counter() - t0
+    # spread: four more windows of the same K steps right after the timed one (a 9 ms window drifts by a few % on a box);
+    # `value` stays the first window, as the contract says (exactly K steps between the barriers)
+    windows = [dt]
+    for wdw in range(1, 5):
+        sync_all()
+        tw = time.perf_counter()
+        for i in range(args.steps):
+            step(n_warm + wdw * args.steps + i)
+        sync_all()
+        windows.append(time.perf_counter() - tw)
     timing_grid = backend.collect_kernel_timing() if not graph else {}
     # diagnostic (outside the timed region): per-operator device time of 20 eager steps (HIP events around each
     # operator on the launch stream); with graph replay this is also where the roofline kernel is timed, because
@@ -615,6 +745,7 @@ def main():
                                    "steady-state train step incl. backward + Adam",
                        "rays_per_step": args.rays, "samples_per_step": int(np.mean(samples)),
                        "optimizer_in_timed_region": not args.no_optimizer,
+                       "occupancy_grid_maintenance_in_timed_region": False,
                        "hip_graph_replay": bool(graph),
                        "march_pipelined_on_side_stream": bool(pipelined), "steps_per_graph_replay": (G if pipelined else 1),
                        "parallelism": (f"{world} data-parallel ranks, one flat gradient all-reduce per dtype per step" if args.dp else
@@ -624,16 +755,27 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_sample": GRID_FWD_BYTES_FP16,
                          "samples_per_launch": int(gf["units"] / max(gf["calls"], 1)),
-                         "avg_launch_us": round(gf["ms"] / max(gf["calls"], 1) * 1e3, 2)},
+                         "avg_launch_us": round(gf["ms"] / max(gf["calls"], 1) * 1e3, 2),
+                         "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                         "frac_of_peak_on_measured_bytes": (round(traffic / (gf["ms"] / max(gf["calls"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                            if traffic and gf["calls"] else None),
+                         "limiter": "on-chip: the 2 MiB level tables stay in the XCDs' L2s (measured traffic < algorithmic bytes); fine "
+                                    "levels run at the L2 request rate, coarse levels at vector-memory issue (DESIGN.md 4)",
+                         "timed": "HIP events on the launch stream around the call in 20 eager steps after the timed region"},
+            "windows": {"ms_per_step": [round(wd / args.steps * 1e3, 4) for wd in windows],
+                        "min": round(min(windows) / args.steps * 1e3, 4), "median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
+                        "max": round(max(windows) / args.steps * 1e3, 4), "note": "5 consecutive windows of K steps; `value` is the first"},
             "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
         }
         if world == 1 and not args.no_frame:
-            out["eval_frame"] = eval_frame(net, r, dev)        # the "ms/frame" half of BASELINE.json's metric (not `value`)
+            out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
         if world == 1 and not args.no_style:
             out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
             out["grid_update"] = grid_update(dev)
+            out["flower_step"] = flower_step(dev)              # configs[2]-shaped train step (not `value`)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
+            out["cpu_baseline"]["cfg1_run_path"] = cpu_baseline_cfg1(os.cpu_count() or 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

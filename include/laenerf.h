@@ -492,6 +492,12 @@ LAE_API int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float
                          const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs,
                          const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* torch_ema.ExponentialMovingAverage.update() of the reference's trainer (nerf/utils.py:407-408 construct, :1502-1503 update once per
+ * epoch; decay 0.95, main_nerf.py:244): shadow -= one_minus_decay * (shadow - param) for up to 8 fp32 tensors in one launch.  The
+ * caller computes one_minus_decay = 1 - min(decay, (1 + num_updates) / (10 + num_updates)) like torch_ema does. */
+LAE_API int lae_ema_update_multi(uint32_t n_tensors, float* const* shadows, const float* const* params, const uint64_t* sizes,
+                         float one_minus_decay, void* stream);
+
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads), dW tiles divided among the waves of
  * a workgroup; 1 = always the three-kernel path that fills both buffers exactly like the reference; 2 = fused backward

@@ -79,6 +79,7 @@ SIGNATURES = {
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],
     "lae_adam_apply_multi": [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp],
     "lae_adam_begin": [vp, f32, f32, i32, f32, f32, i32, vp],
+    "lae_ema_update_multi": [u32, vp, vp, vp, f32, vp],
     "lae_adam_apply": [vp, vp, vp, vp, i32, vp, u64, vp, vp, f32, f32, f32, f32, vp],
     "lae_ffmlp_set_mode": [i32],
     "lae_allocate_splitk": [u64],

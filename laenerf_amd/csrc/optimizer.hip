@@ -236,6 +236,26 @@ __global__ __launch_bounds__(256) void k_apply_multi(ApplySegs sg, const OptStat
     }
 }
 
+// torch_ema.ExponentialMovingAverage.update() (the trainer's `ema`, nerf/utils.py:407-408, 1502-1503):
+// shadow -= (1 - decay) * (shadow - param), every parameter tensor in one launch
+struct EmaSegs { float* shadow[MAX_SEGS]; const float* param[MAX_SEGS]; size_t n[MAX_SEGS]; int count; };
+__global__ __launch_bounds__(256) void k_ema_multi(EmaSegs sg, float one_minus_decay) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (int s = 0; s < sg.count; s++) {
+        float* __restrict__ sh = sg.shadow[s];
+        const float* __restrict__ p = sg.param[s];
+        const size_t n = sg.n[s], n4 = n & ~(size_t)3;
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += stride) {
+            float4 a = *reinterpret_cast<const float4*>(sh + i);
+            const float4 b = *reinterpret_cast<const float4*>(p + i);
+            a.x -= (a.x - b.x) * one_minus_decay; a.y -= (a.y - b.y) * one_minus_decay;
+            a.z -= (a.z - b.z) * one_minus_decay; a.w -= (a.w - b.w) * one_minus_decay;
+            *reinterpret_cast<float4*>(sh + i) = a;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < n - n4) { const size_t j = n4 + threadIdx.x; sh[j] -= (sh[j] - p[j]) * one_minus_decay; }
+    }
+}
+
 uint32_t stream_blocks(size_t n, int per_thread) {
     const size_t want = (n + 256ull * per_thread - 1) / (256ull * per_thread);
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(want, (size_t)lae::num_cus() * 16));
@@ -271,6 +291,24 @@ int lae_adam_check_multi(uint32_t n_tensors, const void* const* grads, const int
     sg.count = (int)n_tensors;
     k_check_multi<<<stream_blocks(biggest, 8), 256, 0, STREAM(stream)>>>(sg, reinterpret_cast<OptState*>(state));
     return lae::check_launch("adam_check_multi");
+}
+
+int lae_ema_update_multi(uint32_t n_tensors, float* const* shadows, const float* const* params, const uint64_t* sizes, float one_minus_decay,
+                         void* stream) {
+    if (n_tensors == 0) return LAE_OK;
+    if (!shadows || !params || !sizes) return LAE_ENULL;
+    if (n_tensors > (uint32_t)MAX_SEGS) return LAE_EINVAL;
+    EmaSegs sg{};
+    size_t biggest = 0;
+    for (uint32_t i = 0; i < n_tensors; i++) {
+        if (sizes[i] && (!shadows[i] || !params[i])) return LAE_ENULL;
+        if ((reinterpret_cast<uintptr_t>(shadows[i]) | reinterpret_cast<uintptr_t>(params[i])) & 15) return LAE_EINVAL;
+        sg.shadow[i] = shadows[i]; sg.param[i] = params[i]; sg.n[i] = sizes[i];
+        biggest = std::max(biggest, (size_t)sizes[i]);
+    }
+    sg.count = (int)n_tensors;
+    k_ema_multi<<<stream_blocks(biggest, 4), 256, 0, STREAM(stream)>>>(sg, one_minus_decay);
+    return lae::check_launch("ema_update_multi");
 }
 
 int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, void* const* grads,

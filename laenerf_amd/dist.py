@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 TILE = 128
+RS_AG_MIN_ELEMS = 1 << 20      # gradients at least this large go out as reduce-scatter + all-gather (RCCL only)
 
 
 def shard_indices(n_rays, rank, world_size, tile=TILE):
@@ -22,36 +23,82 @@ def shard_indices(n_rays, rank, world_size, tile=TILE):
     return idx
 
 
+_shard_cache = {}
+
+
+def shard_indices_device(n_rays, rank, world_size, device, tile=TILE):
+    """`shard_indices` clamped to valid ray ids, resident on `device`, computed once per (frame size, rank, world)"""
+    key = (n_rays, rank, world_size, tile, str(device))
+    idx = _shard_cache.get(key)
+    if idx is None:
+        if len(_shard_cache) > 64:
+            _shard_cache.clear()
+        idx = shard_indices(n_rays, rank, world_size, tile).clamp(min=0).to(device)
+        _shard_cache[key] = idx
+    return idx
+
+
+def deinterleave(gathered, n_rays, world_size, tile=TILE):
+    """[W, n_shard, K] (rank-major, as all_gather_into_tensor lays it out) -> [n_rays, K] in ray order.  Rank r holds tiles
+    r, r + W, r + 2W, ...: as a [W, tiles_per_rank, tile, K] array the frame is the transpose of the first two axes -- a
+    pure permute + reshape (one strided copy), no index tensors; the padding rows (ray id >= n_rays) are the tail."""
+    W, n_shard, K = gathered.shape
+    assert W == world_size and n_shard % tile == 0
+    return gathered.view(W, n_shard // tile, tile, K).permute(1, 0, 2, 3).reshape(-1, K)[:n_rays]
+
+
 def gather_frame(local_block, n_rays, rank, world_size, tile=TILE, group=None):
-    """local_block [n_shard, K] (rows in shard_indices order) -> full [n_rays, K] on every rank"""
+    """local_block [n_shard, K] (rows in shard_indices order) -> full [n_rays, K] on every rank: ONE all_gather_into_tensor
+    (RCCL over xGMI: every rank ships its block to its 7 peers over 7 links) + the de-interleave."""
     local_block = local_block.contiguous()
     if world_size == 1:
-        gathered = [local_block]
-    else:
-        dev = local_block.device
-        if local_block.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
-            local_block = local_block.cpu()
-        gathered = [torch.empty_like(local_block) for _ in range(world_size)]
-        dist.all_gather(gathered, local_block, group=group)
-        gathered = [g.to(dev) for g in gathered]
-        local_block = local_block.to(dev)
-    out = torch.zeros(n_rays, local_block.shape[1], dtype=local_block.dtype, device=local_block.device)
-    for r in range(world_size):
-        idx = shard_indices(n_rays, r, world_size, tile).to(local_block.device)
-        ok = idx >= 0
-        out[idx[ok]] = gathered[r][ok]
-    return out
+        return deinterleave(local_block.unsqueeze(0), n_rays, 1, tile)
+    dev = local_block.device
+    rehearsal = local_block.is_cuda and dist.get_backend(group) == "gloo"    # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
+    src = local_block.cpu() if rehearsal else local_block
+    out = torch.empty((world_size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)   # rank-major
+    dist.all_gather_into_tensor(out, src, group=group)
+    out = out.view((world_size,) + tuple(src.shape))
+    return deinterleave(out.to(dev) if rehearsal else out, n_rays, world_size, tile)
 
 
 def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None):
     """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict"""
     n = rays_o.shape[0]
-    idx = shard_indices(n, rank, world_size).to(rays_o.device)
-    safe = idx.clamp(min=0)
-    res = render_fn(rays_o[safe], rays_d[safe])
+    idx = shard_indices_device(n, rank, world_size, rays_o.device)          # cached on the device: no host work per frame
+    res = render_fn(rays_o[idx], rays_d[idx])
     block = torch.cat([res["image"].float(), res["depth"].float()[:, None], res["weights_sum"].float()[:, None]], dim=1)
     full = gather_frame(block, n, rank, world_size, group=group)
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
+
+
+@torch.no_grad()
+def broadcast_model_state(module, src=0, group=None):
+    """SURVEY.md 8e "replicate model state ... by one ncclBroadcast at load": every parameter and buffer of `module`
+    (hash table, MLP weights, density grid / bitfield, aabb) goes out from rank `src` as ONE flat broadcast per dtype;
+    the fp16 shadow tables a FusedAdam keeps are refreshed lazily through the parameters' version counters."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return module
+    tensors = [p.data for p in module.parameters()] + [b for b in module.buffers()]
+    attrs = [getattr(module, n) for n in ("density_bitfield", "density_grid") if isinstance(getattr(module, n, None), torch.Tensor)]
+    seen, uniq = set(), []
+    for t in tensors + attrs:
+        if t.data_ptr() not in seen and t.numel():
+            seen.add(t.data_ptr()); uniq.append(t)
+    by_dtype = {}
+    for t in uniq:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), ts in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        rehearsal = flat.is_cuda and dist.get_backend(group) == "gloo"
+        buf = flat.cpu() if rehearsal else flat
+        dist.broadcast(buf, src=src, group=group)
+        if rehearsal:
+            flat = buf.to(dev)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()      # copy_ bumps the version -> shadows refresh
+    return module
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -61,6 +108,8 @@ def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None
 # parameters = 24.5 MB in the fp16 accumulator FusedAdam owns), so it goes out as ONE flat all-reduce per dtype: on
 # 8 MI355X, RCCL runs a ring/tree over the xGMI links (7 x ~153 GB/s per GPU): 2 * 7/8 * 24.5 MB / link rate ~ 0.3 ms,
 # i.e. comparable to the 0.5 ms step itself -- which is why the default bench mode keeps independent replicas.
+# NOTE: the RCCL branches of this file have never executed (no multi-GPU node was available to any round; the CPU tests
+# rehearse the control flow over gloo, whose all-reduce stands in for reduce-scatter + all-gather).
 def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20):
     """in place: every tensor becomes the mean over the ranks.  Tensors are packed by dtype into flat buckets of at most
     `bucket_bytes` (one all-reduce each); fp16 payloads are reduced in fp16 (sum of W values scaled by 1/W first, so the
@@ -84,11 +133,24 @@ def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20)
         for b in buckets:
             flat = torch.cat([t.reshape(-1) for t in b]) if len(b) > 1 else b[0].reshape(-1)
             flat.mul_(1.0 / world_size)
-            rehearsal = flat.is_cuda and dist.get_backend(group) == "gloo"        # CPU rehearsal of the RCCL path
-            buf = flat.cpu() if rehearsal else flat
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            if rehearsal:
-                flat.copy_(buf)
+            backend = dist.get_backend(group)
+            rehearsal = flat.is_cuda and backend == "gloo"        # CPU rehearsal of the RCCL path
+            if backend == "nccl" and flat.numel() >= RS_AG_MIN_ELEMS:
+                # the table gradient: reduce-scatter, then all-gather -- every rank owns 1/W of the sum in
+                # between (where a sharded optimizer step would sit); each phase moves (W-1)/W of the payload over the 7
+                # xGMI links at once.  Padded to a multiple of W; smaller payloads stay one all-reduce (latency bound).
+                pad = (-flat.numel()) % world_size
+                work = torch.cat([flat, flat.new_zeros(pad)]) if pad else flat
+                shard = torch.empty(work.numel() // world_size, dtype=work.dtype, device=work.device)
+                dist.reduce_scatter_tensor(shard, work, op=dist.ReduceOp.SUM, group=group)
+                dist.all_gather_into_tensor(work, shard, group=group)
+                if pad:
+                    flat.copy_(work[:flat.numel()])
+            else:
+                buf = flat.cpu() if rehearsal else flat
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                if rehearsal:
+                    flat.copy_(buf)
             if len(b) > 1:
                 off = 0
                 for t in b:

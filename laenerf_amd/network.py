@@ -88,8 +88,10 @@ class NeRFNetwork(nn.Module):
         return torch.sigmoid(self.color_net(h))
 
     def get_params(self, lr):
-        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
-                {"params": self.color_net.parameters(), "lr": lr}]
+        """network_ff.py:142-154: four groups, the third one (direction encoder) without parameters -- kept so that group
+        indices line up with a checkpoint of the reference's optimizer"""
+        return [{"params": list(self.encoder.parameters()), "lr": lr}, {"params": list(self.sigma_net.parameters()), "lr": lr},
+                {"params": list(self.encoder_dir.parameters()), "lr": lr}, {"params": list(self.color_net.parameters()), "lr": lr}]
 
 
 def _masked_color(net, d, mask, geo_feat):
@@ -147,5 +149,6 @@ class NeRFNetworkLinear(nn.Module):
         return _masked_color(self, d, mask, geo_feat)
 
     def get_params(self, lr):
-        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
-                {"params": self.color_net.parameters(), "lr": lr}]
+        """network.py:182-195 (same four groups as network_ff.py)"""
+        return [{"params": list(self.encoder.parameters()), "lr": lr}, {"params": list(self.sigma_net.parameters()), "lr": lr},
+                {"params": list(self.encoder_dir.parameters()), "lr": lr}, {"params": list(self.color_net.parameters()), "lr": lr}]

@@ -1,15 +1,19 @@
-"""Fused Adam + GradScaler for the NeRF parameters.
+"""Fused Adam + GradScaler (+ EMA) for the NeRF parameters.
 
 The reference's step is `scaler.scale(loss).backward(); scaler.step(Adam); scaler.update()` (nerf/utils.py:1474-1482)
-with `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` (main_nerf.py:223).  `FusedAdam` reproduces exactly that
+with `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` (main_nerf.py:223), a per-step `LambdaLR` (main_nerf.py:239-245)
+and a `torch_ema.ExponentialMovingAverage` of the parameters (nerf/utils.py:407-408).  `FusedAdam` reproduces exactly that
 arithmetic (same formulas, same skip / backoff / growth rules) in three kernels of csrc/optimizer.hip, keeps all state
 on the device (HIP-graph capturable) and owns, for every `GridEncoder` table, the fp16 shadow the encoder gathers from
 and the fp16 gradient accumulator the encoder's backward adds into:
 
     opt = FusedAdam(model, lr=1e-2)                    # or FusedAdam(model, param_groups=model.get_params(lr))
-    loss = ...; opt.scale(loss).backward(); opt.step()  # no zero_grad needed: gradients are consumed and zeroed
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / iters, 1))
+    loss = ...; opt.scale(loss).backward(); opt.step(); sched.step()    # no zero_grad needed: gradients are consumed and zeroed
 
-`state_dict()` / `load_state_dict()` use torch.optim.Adam's layout (`exp_avg`, `exp_avg_sq`, `step`).
+It IS a `torch.optim.Optimizer`: schedulers mutate `param_groups[i]["lr"]` and `step()` pushes a changed value to the
+device; `state_dict()` / `load_state_dict()` are torch.optim.Adam's (`state[i] = {step, exp_avg, exp_avg_sq}`,
+`param_groups[i]["params"]`), so a checkpoint of the reference's optimizer loads (plus a `scaler` entry).
 """
 import ctypes
 
@@ -20,22 +24,23 @@ from .ffmlp import FFMLP
 from .gridencoder import GridEncoder
 
 
-class FusedAdam:
+class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, param_groups=None,
                  grad_scaler=True, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         groups = param_groups if param_groups is not None else [{"params": [p for p in model.parameters() if p.requires_grad], "lr": lr}]
+        # empty groups stay (the reference's get_params has one for the parameter-free direction encoder, network_ff.py:147):
+        # group indices must line up with a torch.optim.Adam checkpoint
+        groups = [{**g, "params": [p for p in g["params"] if p.requires_grad]} for g in groups]
+        super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.use_scaler = bool(grad_scaler)
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         tables = {id(m.embeddings): m for m in model.modules() if isinstance(m, GridEncoder) and m.level_dim % 2 == 0}
         tables.update({id(m.weights): m for m in model.modules() if isinstance(m, FFMLP)})
-        self.param_groups = []
         self.items = []                                   # (param, exp_avg, exp_avg_sq, shadow or None, group index)
         dev = None
-        for gi, g in enumerate(groups):
-            params = [p for p in g["params"] if p.requires_grad]
-            self.param_groups.append({"params": params, "lr": float(g.get("lr", lr))})
-            for p in params:
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU (no CPU fallback)")
                 dev = p.device
@@ -45,12 +50,17 @@ class FusedAdam:
                     shadow = owner.attach_shadow()         # fp16 copy + fp16 gradient accumulator next to the parameter
                 else:
                     p.grad = torch.zeros_like(p)           # persistent fp32 gradient (stable address for graph replay)
-                self.items.append((p, torch.zeros_like(p), torch.zeros_like(p), shadow, gi))
+                m, v = torch.zeros_like(p), torch.zeros_like(p)
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}      # torch.optim.Adam's layout
+                self.items.append((p, m, v, shadow, gi))
+        if dev is None:
+            raise ValueError("FusedAdam: no parameter to optimise")
         # device state block (include/laenerf.h): scale | tracker | found_inf | skip | step | 1/bc1 | sqrt(bc2) | 1/scale | skipped
-        self.state = torch.zeros(16, dtype=torch.int32, device=dev)
-        self._scale_view = self.state.view(torch.float32)
+        self.dev_state = torch.zeros(16, dtype=torch.int32, device=dev)
+        self._scale_view = self.dev_state.view(torch.float32)
         self._scale_view[0] = init_scale if self.use_scaler else 1.0
-        self.lrs = torch.tensor([g["lr"] for g in self.param_groups], dtype=torch.float32, device=dev)
+        self._lr_host = [float(g["lr"]) for g in self.param_groups]
+        self.lrs = torch.tensor(self._lr_host, dtype=torch.float32, device=dev)
         if len(self.items) > 8:
             raise RuntimeError("FusedAdam: at most 8 parameter tensors (one multi-tensor launch)")
         self._args = None                                  # ctypes pointer tables of the multi-tensor kernels
@@ -75,18 +85,29 @@ class FusedAdam:
 
     @property
     def steps_taken(self):
-        return int(self.state[4].item())
+        return int(self.dev_state[4].item())
 
     @property
     def steps_skipped(self):
-        return int(self.state[8].item())
+        return int(self.dev_state[8].item())
 
     def set_lr(self, lr, group=None):
         """learning-rate schedule hook: writes device memory, so a captured graph picks the new value up"""
         for gi, g in enumerate(self.param_groups):
             if group is None or gi == group:
                 g["lr"] = float(lr)
-                self.lrs[gi] = float(lr)
+        self.sync_lr()
+
+    def sync_lr(self):
+        """push `param_groups[i]["lr"]` (what torch's schedulers mutate) to the device copy the kernels read.  step() does
+        it by itself when a value changed; a caller that REPLAYS a captured step calls this between replays (the graph
+        reads the device copy, so the new rate takes effect without re-capturing)."""
+        cur = [float(g["lr"]) for g in self.param_groups]
+        if cur != self._lr_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdam: a learning rate changed inside a stream capture; call sync_lr() outside the capture")
+            self.lrs.copy_(torch.tensor(cur, dtype=torch.float32))
+            self._lr_host = cur
 
     def sync_shadows(self):
         """re-derive every fp16 shadow table from its fp32 parameter.  In-place writes to a parameter (load_state_dict,
@@ -138,9 +159,12 @@ class FusedAdam:
         return self._args
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
         """check (any non-finite gradient?) -> begin (skip / step decision, scale update) -> apply: three launches"""
-        lib, st, s = _lib.load(), self.state.data_ptr(), _lib.stream()
+        if closure is not None:
+            raise RuntimeError("FusedAdam.step: closures are not supported")
+        self.sync_lr()
+        lib, st, s = _lib.load(), self.dev_state.data_ptr(), _lib.stream()
         a = self._tables()
         if self.use_scaler:
             _lib.check(lib.lae_adam_check_multi(a["n"], a["grads"], a["is_half"], a["sizes"], st, s), "adam_check")
@@ -152,20 +176,94 @@ class FusedAdam:
 
     # ---- torch.optim.Adam-compatible checkpoints
     def state_dict(self):
-        step = self.steps_taken
-        return {"state": {i: {"step": torch.tensor(float(step)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
-                          for i, (_, m, v, _, _) in enumerate(self.items)},
-                "param_groups": [{"lr": g["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
-                                 for g in self.param_groups],
-                "scaler": {"scale": self.get_scale(), "growth_tracker": int(self.state[1].item())}}
+        """torch.optim.Optimizer.state_dict() (Adam layout: state[i] = {step, exp_avg, exp_avg_sq}, param_groups with their
+        `params` indices) + the GradScaler's state under "scaler" """
+        step = float(self.steps_taken)
+        for p, *_ in self.items:
+            self.state[p]["step"] = torch.tensor(step)
+        sd = super().state_dict()
+        sd["scaler"] = {"scale": self.get_scale(), "growth_tracker": int(self.dev_state[1].item())}
+        return sd
 
     def load_state_dict(self, sd):
-        for i, (_, m, v, _, _) in enumerate(self.items):
-            e = sd["state"][i]
-            m.copy_(e["exp_avg"]); v.copy_(e["exp_avg_sq"])
-            self.state[4] = int(e["step"])
-        for gi, g in enumerate(sd.get("param_groups", [])):
-            self.set_lr(g["lr"], gi)
-        if "scaler" in sd:
-            self._scale_view[0] = sd["scaler"]["scale"]
-            self.state[1] = sd["scaler"]["growth_tracker"]
+        sd = dict(sd)
+        scaler = sd.pop("scaler", None)
+        keep = {id(p): (m, v) for p, m, v, _, _ in self.items}
+        super().load_state_dict(sd)
+        step = 0
+        for p, m, v, _, _ in self.items:                     # keep the tensors the kernels' pointer tables refer to
+            e = self.state[p]
+            step = int(float(e["step"]))
+            m.copy_(e["exp_avg"].to(m.device)); v.copy_(e["exp_avg_sq"].to(v.device))
+            e["exp_avg"], e["exp_avg_sq"] = keep[id(p)]
+        self.dev_state[4] = step
+        self._lr_host = None                                  # group learning rates came with the checkpoint
+        self.sync_lr()
+        if scaler is not None:
+            self._scale_view[0] = scaler["scale"]
+            self.dev_state[1] = scaler["growth_tracker"]
+
+
+class EMA:
+    """`torch_ema.ExponentialMovingAverage(parameters, decay)` of the reference's trainer (nerf/utils.py:407-408; `update()`
+    once per epoch :1502-1503; `store()` / `copy_to()` / `restore()` around evaluation :1205-1215, :1252-1266) with the
+    update of every tensor as ONE launch (csrc/optimizer.hip k_ema_multi).  Same arithmetic: decay_t = min(decay,
+    (1 + n) / (10 + n)), shadow -= (1 - decay_t) * (shadow - param)."""
+
+    def __init__(self, parameters, decay=0.95, use_num_updates=True):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError("decay must be between 0 and 1")
+        self.params = [p for p in parameters if p.requires_grad]
+        for p in self.params:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("EMA: parameters must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+        if len(self.params) > 8:
+            raise RuntimeError("EMA: at most 8 parameter tensors (one multi-tensor launch)")
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow_params = [p.detach().clone() for p in self.params]
+        self.collected_params = None
+        n = len(self.params)
+        self._n = n
+        self._shadows = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self.shadow_params])
+        self._params = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        self._sizes = (ctypes.c_uint64 * n)(*[p.numel() for p in self.params])
+
+    @torch.no_grad()
+    def update(self):
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        if [p.data_ptr() for p in self.params] != list(self._params):
+            self._params = (ctypes.c_void_p * self._n)(*[p.data_ptr() for p in self.params])
+        _lib.check(_lib.load().lae_ema_update_multi(self._n, self._shadows, self._params, self._sizes, float(1.0 - decay), _lib.stream()),
+                   "ema_update")
+
+    @torch.no_grad()
+    def store(self):
+        self.collected_params = [p.detach().clone() for p in self.params]
+
+    @torch.no_grad()
+    def copy_to(self):
+        for s_, p in zip(self.shadow_params, self.params):
+            p.copy_(s_)                                       # in place on the parameter: bumps its version, fp16 shadow tables follow
+
+    @torch.no_grad()
+    def restore(self):
+        if self.collected_params is None:
+            raise RuntimeError("EMA.restore() without a store()")
+        for c, p in zip(self.collected_params, self.params):
+            p.copy_(c)
+        self.collected_params = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": [t.clone() for t in self.shadow_params],
+                "collected_params": None if self.collected_params is None else [t.clone() for t in self.collected_params]}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        for t, src in zip(self.shadow_params, sd["shadow_params"]):
+            t.copy_(src.to(t.device))
+        cp = sd.get("collected_params")
+        self.collected_params = None if cp is None else [c.to(p.device).clone() for c, p in zip(cp, self.params)]

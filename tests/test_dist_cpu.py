@@ -49,6 +49,53 @@ def test_shard_indices_partition():
         assert real.numel() == n and torch.equal(torch.sort(real).values, torch.arange(n))
 
 
+def test_deinterleave_is_a_pure_reshape():
+    """gather_frame's de-interleave of the rank-major all-gather buffer == scattering every rank's rows by shard_indices"""
+    from laenerf_amd.dist import deinterleave, shard_indices
+    for n, w in ((1000, 2), (128 * 6, 2), (77, 4), (2073600, 8), (5000, 3)):
+        blocks = []
+        for r in range(w):
+            idx = shard_indices(n, r, w)
+            blk = torch.stack([idx.float(), idx.float() * 2 + 1], 1)            # row content = its ray id (padding: -1)
+            blocks.append(blk)
+        full = deinterleave(torch.stack(blocks), n, w)
+        assert full.shape == (n, 2)
+        assert torch.equal(full[:, 0], torch.arange(n).float()) and torch.equal(full[:, 1], torch.arange(n).float() * 2 + 1)
+
+
+def _bcast_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from laenerf_amd.dist import broadcast_model_state
+    torch.manual_seed(100 + rank)                                # different weights on every rank before the broadcast
+    m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    m.register_buffer("bits", torch.randint(0, 255, (64,), dtype=torch.uint8))
+    m.density_bitfield = torch.randint(0, 255, (32,), dtype=torch.uint8)
+    broadcast_model_state(m, src=0)
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref_bits = torch.randint(0, 255, (64,), dtype=torch.uint8)
+    ref_field = torch.randint(0, 255, (32,), dtype=torch.uint8)
+    ok = all(torch.equal(a, b) for a, b in zip(m.parameters(), ref.parameters()))
+    ok &= bool(torch.equal(m.bits, ref_bits)) and bool(torch.equal(m.density_bitfield, ref_field))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_broadcast_model_state_gloo():
+    world = 2
+    port = 29500 + (os.getpid() + 333) % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0] and ret[1]
+
+
 def _dp_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -360,3 +360,48 @@ def test_fused_adam_backward_helper_equals_loss_backward():
     assert float(grads[0][0].float().abs().sum()) > 0
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_library_workspace_growth_never_invalidates_a_captured_graph(O):
+    """a graph captured at one size bakes the library's scratch pointers in; a later, larger eager call must not
+    free that memory (buffers are retired, not freed), growth inside a capture is refused, and a replay stays correct"""
+    from laenerf_amd import _lib
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, B=8192)
+    L, C = offsets.shape[0] - 1, 2
+    S_ = np.log2(pls)
+    g_small = half_from_bits(O.to_f16_bits((np.random.default_rng(1).standard_normal((L, 8192, C)) * 1e-2).astype(np.float32)))
+    tx, toff = T(x), T(offsets)
+    lib = _lib.load()
+    lib.lae_free_workspaces()
+    out = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        G.grid_encode_backward(g_small, tx, None, toff, out, 8192, 3, C, L, S_, 16, None, None, 0, False, 0)      # eager warm-up
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref = out.clone()
+    out.zero_()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        G.grid_encode_backward(g_small, tx, None, toff, out, 8192, 3, C, L, S_, 16, None, None, 0, False, 0)
+    live0 = lib.lae_workspace_bytes(0)
+    # a much larger eager call grows the workspace ...
+    xb = T(np.random.default_rng(2).random((200000, 3)).astype(np.float32))
+    gb = torch.zeros(L, 200000, C, device=DEV, dtype=torch.half)
+    big = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    G.grid_encode_backward(gb, xb, None, toff, big, 200000, 3, C, L, S_, 16, None, None, 0, False, 0)
+    torch.cuda.synchronize()
+    assert lib.lae_workspace_bytes(0) > live0 and lib.lae_workspace_bytes(1) >= live0       # ... and the old buffer is retired, not freed
+    out.zero_()
+    gph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)                                     # the replay still writes through the retired buffer
+    # growth inside a capture is refused with a message that says what to do
+    lib.lae_free_workspaces()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="warm-up"):
+        with torch.cuda.graph(g2):
+            G.grid_encode_backward(g_small, tx, None, toff, out, 8192, 3, C, L, S_, 16, None, None, 0, False, 0)
+    torch.cuda.synchronize()

@@ -148,3 +148,82 @@ def test_mse_loss_scaled_matches_torch():
     assert torch.allclose(loss.unscaled, torch.nn.MSELoss(reduction="none")(p2, gt).mean(-1).mean(), rtol=1e-6)
     plain = mse_loss_scaled(pred.detach(), gt)                        # no scaler
     assert torch.allclose(plain, ref, rtol=1e-6)
+
+
+def test_fused_adam_is_a_torch_optimizer_lambda_lr_and_reference_checkpoint_layout():
+    """the reference steps a LambdaLR every iteration (main_nerf.py:239-245, scheduler_update_every_step) and checkpoints
+    `optimizer.state_dict()` of torch.optim.Adam over get_params' FOUR groups (network_ff.py:142-154): both must work"""
+    from laenerf_amd.optim import FusedAdam
+    a, b = small_net(3), small_net(3)
+    fa = FusedAdam(a, param_groups=a.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, init_scale=1024.0, growth_interval=1000)
+    tb = torch.optim.Adam(b.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    sc = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1000)
+    assert isinstance(fa, torch.optim.Optimizer) and len(fa.param_groups) == 4 and fa.param_groups[2]["params"] == []
+    lam = lambda it: 0.1 ** min(it / 5, 1)
+    sa, sb = torch.optim.lr_scheduler.LambdaLR(fa, lam), torch.optim.lr_scheduler.LambdaLR(tb, lam)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    pa, pb = [p for g in a.get_params(0) for p in g["params"]], [p for g in b.get_params(0) for p in g["params"]]
+    for it in range(7):
+        sc.scale(torch.zeros((), device=DEV))                        # lazily creates the scale tensor
+        for x, y in zip(pa, pb):
+            g = (torch.randn(x.shape, device=DEV, generator=gen) * 1e-3 * 1024.0).half().float()    # scaled, fp16-representable
+            x.grad = g.clone(); y.grad = g.clone()                   # plain autograd gradients (folded into the accumulators)
+        fa.step()
+        sc.step(tb); sc.update()
+        sa.step(); sb.step()
+        assert fa.param_groups[0]["lr"] == pytest.approx(tb.param_groups[0]["lr"])
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x.detach(), y.detach(), rtol=2e-6, atol=3e-8), (it, float((x.detach() - y.detach()).abs().max()))
+    assert float(fa.lrs[0]) == pytest.approx(1e-2 * 0.1, rel=1e-6)    # the device copy followed the schedule
+    # checkpoint: torch's own layout, and torch.optim.Adam's checkpoint loads
+    sd, ref = fa.state_dict(), tb.state_dict()
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in ref["param_groups"]] == [[0], [1], [], [2]]
+    assert set(sd["state"].keys()) == set(ref["state"].keys()) == {0, 1, 2}
+    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 7
+    c = small_net(3)
+    fc = FusedAdam(c, param_groups=c.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    fc.load_state_dict(ref)                                           # the reference's optimizer checkpoint
+    assert fc.steps_taken == 7 and fc.param_groups[3]["lr"] == pytest.approx(tb.param_groups[3]["lr"])
+    for (p, m, v, _, _), y in zip(fc.items, pb):
+        assert torch.equal(m, tb.state[y]["exp_avg"]) and torch.equal(v, tb.state[y]["exp_avg_sq"])
+    assert float(fc.lrs[3]) == pytest.approx(tb.param_groups[3]["lr"], rel=1e-6)
+
+
+def test_ema_matches_torch_ema_semantics():
+    """torch_ema.ExponentialMovingAverage (nerf/utils.py:407-408, 1502-1503, 1205-1215) restated in numpy: warm-up decay
+    min(decay, (1 + n) / (10 + n)), shadow -= (1 - decay) * (shadow - param); store / copy_to / restore"""
+    from laenerf_amd.optim import EMA, FusedAdam
+    net = small_net(4)
+    fa = FusedAdam(net, param_groups=net.get_params(1e-2), grad_scaler=False)
+    ema = EMA(net.parameters(), decay=0.95)
+    params = [p for p in net.parameters()]
+    shadow = [N(p).astype(np.float32).copy() for p in params]
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    for n_upd in range(1, 6):
+        with torch.no_grad():
+            for p in params:
+                p.add_(torch.randn(p.shape, device=DEV, generator=gen) * 1e-2)
+        ema.update()
+        decay = min(0.95, (1 + n_upd) / (10 + n_upd))
+        omd = np.float32(1.0 - decay)
+        for s_, p in zip(shadow, params):
+            s_ -= (s_ - N(p)) * omd
+        for s_, t in zip(shadow, ema.shadow_params):
+            assert np.allclose(N(t), s_, rtol=1e-6, atol=1e-8)
+    x = torch.rand(256, 3, device=DEV) * 2 - 1
+    live = [p.detach().clone() for p in params]
+    ema.store(); ema.copy_to()
+    for p, t in zip(params, ema.shadow_params):
+        assert torch.equal(p.detach(), t)
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        y_ema = net.encoder(x)                                         # the fp16 shadow table followed the swap (version counter)
+    assert torch.equal(net.encoder.shadow.half, ema.shadow_params[0].half())
+    ema.restore()
+    for p, t in zip(params, live):
+        assert torch.equal(p.detach(), t)
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        y_live = net.encoder(x)
+    assert torch.equal(net.encoder.shadow.half, live[0].half()) and not torch.equal(y_live, y_ema)
+    sd = ema.state_dict()
+    e2 = EMA(net.parameters(), decay=0.5); e2.load_state_dict(sd)
+    assert e2.num_updates == 5 and all(torch.equal(a_, b_) for a_, b_ in zip(e2.shadow_params, ema.shadow_params))
