@@ -178,9 +178,11 @@ def test_frame_loop_vs_reference_capture(tag):
     with torch.autocast("cuda", dtype=torch.float16):
         ev = r.render_eval(o, d, bg_color=1, max_steps=256, frame_loop=True)
         ds = r.render_distill(o, d, T(g["edit_bitfield"]), max_steps=256, frame_loop=True)
-    assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 2e-3
+    # north_star tolerance 1e-4; measured 2.0e-5 / 1.8e-5 (tools/fp16_table_delta.py: the fixture tables are fp16-representable,
+    # so what differs from the capture is the half accumulate of the encoder and the fp16 MLP arithmetic)
+    assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 1e-4
     for k, ref in (("image", "dist_image"), ("weights", "dist_weights"), ("weights_edit", "dist_weights_edit")):
-        assert np.abs(N(ds[k]) - g[ref]).max() < 2e-3, k
+        assert np.abs(N(ds[k]) - g[ref]).max() < 1e-4, k
 
 
 def test_frame_loop_refuses_capture_and_cpu():
