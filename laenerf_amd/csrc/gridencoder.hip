@@ -19,6 +19,8 @@
 #include <type_traits>
 #include "lae_common.h"
 #include <vector>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -472,8 +474,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_bwd(
 //                independent, deterministic.  A non-finite contribution (overflowed loss scale) marks its entry, which is
 //                written as NaN so that the optimizer's non-finite scan sees it (an integer accumulator would otherwise
 //                silently turn Inf into a finite number).  fp32 gradients use ds_add_f32.
-// Levels with few partitions are split into SUB sub-ranges so that ~16 workgroups share every level; each stores its exact
-// partial sums and the last to arrive adds them in a fixed order (no float atomics: same bits whatever the order).
+// Levels with few partitions are split into SUB sub-ranges so that ~16 workgroups share every level; each adds its exact
+// partial sums (int64: the adds commute) into the partition's merge record with device-scope atomics and the last to arrive
+// takes them out (no float atomics: same bits whatever the order).
 // Levels with more than BK_MAX partitions (T > 2^21) are left to k_grid_bwd.
 template <typename T> struct BVal;
 template <> struct BVal<half_t> { using type = uint2; };       // {half2 of corner x, half2 of corner x+1}
@@ -486,7 +489,7 @@ constexpr uint32_t STAGE_CAP = 4096;                           // items staged i
 constexpr uint32_t KEY_SINGLE = 15u, KEY_NEXT = 14u;           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1); 14 -> e0 + 1
 constexpr int ACC_THREADS = 1024;
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
-constexpr uint32_t SUB_RECS = 32;                              // sub-range records per level (P * SUB < 32 whenever SUB > 1)
+constexpr uint32_t SUB_RECS = 16;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
 constexpr uint32_t TICKET_WORDS = TICKET_ARRIVALS + MAX_LEVELS * SUB_RECS;
 template <typename T> constexpr uint32_t sub_rec_words() { return (sizeof(T) == 2 ? 2 * PART : PART) + PART / 64; }
@@ -904,40 +907,30 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         }
         __syncthreads();
         if (SUB > 1) {
-            // ---- sub-ranges of one partition: every one stores its exact partial sums (+ its non-finite marks); the LAST
-            // to arrive adds them up in a fixed order and writes the table.  Hand-off per MI355X_MICROARCH "Workgroup
-            // dispatch ... visibility", the form without fences (an agent release writes back ALL dirty lines of the
-            // XCD's L2 -- tens of MB of queue right after the fill pass: 40 us per level measured): every store of the
-            // handed-off words write-through (sc1), every wave's vmcnt(0), barrier, one lane's counter add; the last
-            // arriver (told by the value its add returned) reads them with sc1 loads.
-            unsigned long long* __restrict__ mine = partials + (size_t)(level * SUB_RECS + bk) * sub_rec_words<T>();
-            for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) __hip_atomic_store(mine + i, acc64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid < PART / 32) __hip_atomic_store(reinterpret_cast<uint32_t*>(mine + ACCW) + tid, poison[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- sub-ranges of one partition: every one ADDS its exact partial sums (int64: the adds commute, so the
+            // result has the same bits whatever the order) into the partition's merge record with device-scope atomics;
+            // the last to arrive (told by the value its counter add returned) takes the sums out with atomic exchanges,
+            // which also leaves the record zero for the next launch.  Every access to the record is an atomic, so no
+            // fence and no cache maintenance is needed (an agent-scope release here writes back ALL dirty lines of the
+            // XCD's L2 -- tens of MB of queue right after the fill pass: 40 us per level measured; storing 64 KB partials
+            // write-through and letting the last arriver add SUB of them: 16 us on its critical path).
+            unsigned long long* __restrict__ rec = partials + (size_t)(level * SUB_RECS + p) * sub_rec_words<T>();
+            uint32_t* __restrict__ rec_poison = reinterpret_cast<uint32_t*>(rec + ACCW);
+            if constexpr (HALF) {
+                for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) { const unsigned long long v = acc64[i]; if (v) atomicAdd(rec + i, v); }
+            } else {
+                const float* af = reinterpret_cast<const float*>(acc64);
+                float* rf = reinterpret_cast<float*>(rec);
+                for (uint32_t i = tid; i < 2 * PART; i += ACC_THREADS) { const float v = af[i]; if (v != 0.0f) atomicAdd(rf + i, v); }
+            }
+            if (tid < PART / 32 && poison[tid]) atomicOr(rec_poison + tid, poison[tid]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) s_arr = atomicAdd(&plan.tickets[TICKET_ARRIVALS + level * SUB_RECS + p], 1u);
             __syncthreads();
             if (s_arr != SUB - 1) { __syncthreads(); continue; }
-            const unsigned long long* __restrict__ first = partials + (size_t)(level * SUB_RECS + p * SUB) * sub_rec_words<T>();
-            for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) {
-                if constexpr (HALF) {
-                    long long sum = 0;
-                    for (uint32_t k = 0; k < SUB; k++) sum += (long long)__hip_atomic_load(first + (size_t)k * sub_rec_words<T>() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc64[i] = (unsigned long long)sum;
-                } else {
-                    float s0 = 0.f, s1 = 0.f;
-                    for (uint32_t k = 0; k < SUB; k++) {
-                        const unsigned long long w = __hip_atomic_load(first + (size_t)k * sub_rec_words<T>() + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const float2 v = __builtin_bit_cast(float2, w); s0 += v.x; s1 += v.y;
-                    }
-                    reinterpret_cast<float2*>(acc64)[i] = make_float2(s0, s1);
-                }
-            }
-            if (tid < PART / 32) {
-                uint32_t m = 0;
-                for (uint32_t k = 0; k < SUB; k++) m |= __hip_atomic_load(reinterpret_cast<const uint32_t*>(first + (size_t)k * sub_rec_words<T>() + ACCW) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                poison[tid] = m;
-            }
+            for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = atomicExch(rec + i, 0ull);
+            if (tid < PART / 32) poison[tid] = atomicExch(rec_poison + tid, 0u);
             __syncthreads();
         }
         const uint32_t part_lo = p << PART_SHIFT;
@@ -1312,11 +1305,14 @@ static inline BwdPlan plan_at(void* buf, uint32_t B, uint32_t L) {
     plan.part_cnt = reinterpret_cast<uint32_t*>(p + lay.part_off);
     return plan;
 }
+// merge records of split partitions: at the START of the workspace, sized for MAX_LEVELS whatever the call (their place
+// must not move with B or L: they are zeroed once per buffer and every launch leaves them zero)
+static inline size_t merge_bytes() { return ((size_t)MAX_LEVELS * SUB_RECS * sub_rec_words<half_t>() * 8 + 255) / 256 * 256; }
 template <typename T>
 static inline size_t bwd_exec_ws_bytes(uint32_t B, uint32_t L) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t cap = (size_t)L * bwd_units(B) * UNIT_SAMPLES * 8;
-    return up((size_t)L * SUB_RECS * sub_rec_words<T>() * 8) + up(cap * sizeof(typename BVal<T>::type)) + up(cap * 2);
+    return merge_bytes() + up(cap * sizeof(typename BVal<T>::type)) + up(cap * 2);
 }
 
 template <typename T>
@@ -1336,12 +1332,28 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     const size_t plan_bytes = caller_plan ? 0 : plan_layout(B, L).bytes;
     uint8_t* ws = reinterpret_cast<uint8_t*>(lae::workspace(lae::WS_GRID_BINS, plan_bytes + bwd_exec_ws_bytes<T>(B, L), a.stream));
     if (!ws) return LAE_ELAUNCH;
-    const BwdPlan plan = plan_at(caller_plan ? const_cast<void*>(caller_plan) : ws, B, L);
-    uint8_t* ex = ws + plan_bytes;
-    unsigned long long* partials = reinterpret_cast<unsigned long long*>(ex);
+    unsigned long long* partials = reinterpret_cast<unsigned long long*>(ws);
+    {   // the merge records must start at zero (afterwards every launch leaves them zero): once per buffer
+        static std::mutex mtx;
+        static std::vector<void*> zeroed;
+        static uint64_t epoch = 0;
+        std::lock_guard<std::mutex> lk(mtx);
+        if (epoch != lae::workspace_epoch()) { zeroed.clear(); epoch = lae::workspace_epoch(); }
+        if (std::find(zeroed.begin(), zeroed.end(), (void*)ws) == zeroed.end()) {
+            if (hipMemsetAsync(ws, 0, merge_bytes(), a.stream) != hipSuccess) {
+                (void)hipGetLastError();
+                lae::set_last_error_str("grid backward: could not zero the merge records (first call inside a capture? warm up eagerly)");
+                return LAE_ELAUNCH;
+            }
+            if (zeroed.size() > 64) zeroed.clear();
+            zeroed.push_back((void*)ws);
+        }
+    }
+    const BwdPlan plan = plan_at(caller_plan ? const_cast<void*>(caller_plan) : ws + merge_bytes(), B, L);
+    uint8_t* ex = ws + merge_bytes() + plan_bytes;
     const size_t cap = (size_t)L * U * UNIT_SAMPLES * 8;
-    V* qvals = reinterpret_cast<V*>(ex + up((size_t)L * SUB_RECS * sub_rec_words<T>() * 8));
-    uint16_t* qkeys = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(qvals) + up(cap * sizeof(V)));
+    V* qvals = reinterpret_cast<V*>(ex);
+    uint16_t* qkeys = reinterpret_cast<uint16_t*>(ex + up(cap * sizeof(V)));
     const T* g = (const T*)gT;
     T* ge = (T*)gemb;
     if (!caller_plan) bwd_plan<T>(inputs, offsets, B, L, a, plan);

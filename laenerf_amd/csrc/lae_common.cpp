@@ -23,6 +23,7 @@ static std::mutex g_ws_mutex;
 struct WsBuf { void* p = nullptr; size_t bytes = 0; };
 static std::map<std::pair<int, int>, WsBuf> g_ws;
 static std::vector<std::pair<int, WsBuf>> g_retired;
+static uint64_t g_ws_epoch = 1;                     // bumped by free_workspaces(): addresses seen before may be handed out again
 
 void* workspace(WsSlot slot, size_t bytes, hipStream_t stream) {
     int dev = 0;
@@ -46,6 +47,8 @@ void* workspace(WsSlot slot, size_t bytes, hipStream_t stream) {
     b.p = np; b.bytes = want;
     return np;
 }
+
+uint64_t workspace_epoch() { std::lock_guard<std::mutex> lk(g_ws_mutex); return g_ws_epoch; }
 
 size_t workspace_bytes(bool retired) {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
@@ -71,6 +74,7 @@ void free_workspaces() {
     for (auto& r : g_retired) drop(r.first, r.second.p);
     g_ws.clear();
     g_retired.clear();
+    g_ws_epoch++;
     (void)hipSetDevice(cur);
 }
 

@@ -17,6 +17,7 @@ void set_last_error(const char* what, hipError_t e);
 enum WsSlot { WS_FFMLP_SLABS = 0, WS_GRID_GRAD_T = 1, WS_GRID_OUT_T = 2, WS_GRID_BINS = 3, WS_SLOTS = 4 };
 void* workspace(WsSlot slot, size_t bytes, hipStream_t stream);
 size_t workspace_bytes(bool retired);
+uint64_t workspace_epoch();      // changes whenever free_workspaces() ran (a workspace address may then be a new allocation)
 void free_workspaces();
 int num_cus();
 void set_last_error_str(const char* what);
