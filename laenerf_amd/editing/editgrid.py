@@ -56,6 +56,73 @@ class EditGrid:
     def get_grid(self):
         return self.grid
 
+    # ---- whole-grid helpers of the reference (editgrid.py:60-78, 145-164, 204-230, 343-369)
+    def save_grid_as_torch(self, f):
+        torch.save(self.grid.cpu(), f)
+
+    def load_grid_as_torch(self, f):
+        self.grid = torch.load(f).to("cuda")
+
+    def xor(self, negative_grid):
+        """remove `negative_grid` from the selection: grid & (grid ^ negative) (editgrid.py:66-68)"""
+        self.grid = torch.bitwise_and(self.grid, torch.bitwise_xor(self.grid, negative_grid))
+
+    def and_(self, negative_grid):
+        """the reference's `and_` is a union (bitwise_or, editgrid.py:70-71); kept under its name"""
+        self.grid = torch.bitwise_or(self.grid, negative_grid)
+
+    def bw_and(self, other_grid):
+        torch.bitwise_and(self.grid, other_grid, out=self.grid)
+
+    @staticmethod
+    def _block_coords(xs, ys, zs):
+        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+        return torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+
+    def add_neighbors(self, coords_hit, grid):
+        """editgrid.py:204-230: select the in-bounds face neighbours of `coords_hit` (cascade level 0).  Every neighbour's
+        bit is set; the reference's indexed byte assignment keeps one of several bits that share a byte in one call."""
+        nb = torch.tensor(_NEIGHBOURS, dtype=torch.int32, device=coords_hit.device)
+        c = (coords_hit[:, None, :].to(torch.int32) + nb[None]).reshape(-1, 3)
+        c = c[((c >= 0) & (c < GRIDSIZE)).all(-1)]
+        idx = raymarching.morton3D(c.contiguous()).long()
+        set_bits(grid, idx % GRIDVOLUME, idx // GRIDVOLUME)
+
+    def morphological(self):
+        """editgrid.py:145-164: one dilation of the level-0 selection by the 6-neighbourhood, walked in the reference's
+        64^3 blocks in its order (a block sees the bits earlier blocks have just added, as in the reference)"""
+        dev = self.grid.device
+        parts = torch.arange(GRIDSIZE, dtype=torch.int32, device=dev).split(64)
+        for xs in parts:
+            for ys in parts:
+                for zs in parts:
+                    coords = self._block_coords(xs, ys, zs)
+                    idx = raymarching.morton3D(coords.contiguous()).long()
+                    bits = get_bitfield_at(idx % GRIDVOLUME, idx // GRIDVOLUME, self.grid)
+                    hit = bits.nonzero(as_tuple=True)[0]
+                    if hit.numel():
+                        self.add_neighbors(coords[hit], self.grid)
+
+    def get_selection_points(self):
+        """editgrid.py:343-369: centres of the selected level-0 cells in [0, 1]^3 (numpy [n, 3]); `pts` if it was set"""
+        if self.pts is not None:
+            return self.pts
+        dev = self.grid.device
+        out = []
+        parts = torch.arange(GRIDSIZE, dtype=torch.int32, device=dev).split(32)
+        for xs in parts:
+            for ys in parts:
+                for zs in parts:
+                    coords = self._block_coords(xs, ys, zs)
+                    idx = raymarching.morton3D(coords.contiguous()).long()
+                    level, pos = idx // GRIDVOLUME, idx % GRIDVOLUME
+                    hit = get_bitfield_at(pos, level, self.grid).nonzero(as_tuple=True)[0]
+                    if hit.numel():
+                        c = raymarching.morton3D_invert(pos[hit].to(torch.int32).contiguous()).float()
+                        out.append(((c + 0.5) / GRIDSIZE - 0.5) * torch.pow(2.0, level[hit].float())[:, None] + 0.5)
+        import numpy as np
+        return np.concatenate([o.cpu().numpy() for o in out]) if out else np.zeros((0, 3), np.float32)
+
     # ---- the deque of the reference, as seen from Python
     @property
     def growing_queue(self):

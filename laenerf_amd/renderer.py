@@ -65,6 +65,37 @@ class NeRFRenderer(nn.Module):
         self.mean_count = 0
         self.local_step = 0
 
+    # ---- checkpoints of the reference: there NeRFNetwork IS the renderer (class NeRFNetwork(NeRFRenderer)), so its
+    # state_dict has `encoder.embeddings`, `sigma_net.weights`, ... next to `density_grid`, `aabb_train`, ...; here the network
+    # is the attribute `model`.  load_state_dict accepts both layouts; state_dict(reference_layout=True) writes the reference's.
+    def _to_local_keys(self, sd):
+        own = {k for k, _ in self.named_buffers(recurse=False)} | {k for k, _ in self.named_parameters(recurse=False)}
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("model.") or k.split(".")[0] in own:
+                out[k] = v
+            else:
+                out["model." + k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        if "model" in state_dict and isinstance(state_dict["model"], dict):       # Trainer checkpoint (nerf/utils.py:1587): {'model': ...}
+            state_dict = state_dict["model"]
+        res = super().load_state_dict(self._to_local_keys(state_dict), strict=strict, assign=assign)
+        for m in self.modules():                                                  # fp16 shadow tables follow the loaded parameters
+            sh = getattr(m, "shadow", None)
+            if sh is not None and hasattr(sh, "half"):
+                p = getattr(m, "embeddings", None) if hasattr(m, "embeddings") else getattr(m, "weights", None)
+                if p is not None:
+                    sh.half.copy_(p.detach()); sh.version = p._version
+        return res
+
+    def state_dict(self, *args, reference_layout=False, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if not reference_layout:
+            return sd
+        return type(sd)((k[len("model."):] if k.startswith("model.") else k, v) for k, v in sd.items())
+
     def reset_extra_state(self):
         """renderer.py:115-126"""
         self.density_grid.zero_()

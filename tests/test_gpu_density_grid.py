@@ -184,3 +184,28 @@ def test_density_head_equals_full_head():
         s2, _ = nerf_head(torch.cat([enc, enc.new_zeros(8, 32)]), d, ws, wc)
     assert torch.equal(sig, s2[:M]) and h.shape == (M, 16)
     assert torch.equal(nerf_density(enc, ws, 2.0, want_geo_feat=False)[0], 2.0 * sig)
+
+
+def test_renderer_loads_reference_layout_checkpoints():
+    """the reference's NeRFNetwork IS its renderer, so its checkpoints name `encoder.embeddings`, `sigma_net.weights`, ... next to
+    `density_grid`, `density_bitfield`, `aabb_*`, `step_counter` (nerf/utils.py:1587 saves {'model': state_dict}); both that
+    layout and this repo's (`model.` prefix) load, and state_dict(reference_layout=True) writes the reference's"""
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(0)
+    a = NeRFRenderer(NeRFNetwork(bound=1, log2_hashmap_size=12), bound=1).to(DEV)
+    a.model.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    a.density_grid.uniform_(0, 20); a.density_bitfield.random_(0, 255); a.step_counter.random_(0, 1000)
+    ref_sd = a.state_dict(reference_layout=True)
+    assert {"encoder.embeddings", "encoder.offsets", "sigma_net.weights", "color_net.weights", "density_grid", "density_bitfield",
+            "aabb_train", "aabb_infer", "step_counter"} <= set(ref_sd.keys()) and not any(k.startswith("model.") for k in ref_sd)
+    for payload in (ref_sd, {"model": ref_sd, "epoch": 3}, a.state_dict()):
+        torch.manual_seed(1)
+        b = NeRFRenderer(NeRFNetwork(bound=1, log2_hashmap_size=12), bound=1).to(DEV)
+        opt = FusedAdam(b.model, param_groups=b.model.get_params(1e-2))          # fp16 shadows exist before the load
+        b.load_state_dict(payload)
+        for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
+        assert torch.equal(b.model.encoder.shadow.half, a.model.encoder.embeddings.detach().half())    # shadow followed the load
+        del opt
