@@ -57,28 +57,16 @@ def _crop_terms(h, w, mask, pred_w8s, target, d_mask, dist_factor=None):
 
 
 @torch.no_grad()
-def extract_view(renderer, pose, intrinsics, H, W, edit_grid, image, depth_diff=0.5, grow_grid=None, max_dist=0.1,
-                 num_steps=1024, to_cpu=False):
-    """One iteration of the loop at edit_dataset.py:74-234.
-
-    renderer: laenerf_amd.renderer.NeRFRenderer (eval mode); pose [4,4] or [1,4,4]; edit_grid / grow_grid: uint8 bitfields;
-    image [H,W,3|4] ground truth of the view.  Returns None when the region is occluded in this view (:103-108), else a
-    dict with the reference's per-view entries (w8s, targets, x_term, dirs, depths, indices, weights_densitygrid,
-    weights_editgrid, pred_imgs, cut_*, depth_factor and, with a grow grid, indices_interp / dist_weights)."""
-    pose = pose.reshape(1, 4, 4)
-    rays = get_rays(pose, intrinsics, H, W, -1, aabb=renderer.aabb_infer, min_near=renderer.min_near)
-    rays_o, rays_d = rays["rays_o"].view(-1, 3), rays["rays_d"].view(-1, 3)
-    with torch.autocast("cuda", dtype=torch.float16):
-        out = renderer.render_distill(rays_o, rays_d, edit_grid, perturb=True, nears=rays["nears"].view(-1))
+def _pack_view(out, g, rays_d, H, W, image, depth_diff, max_dist, num_steps, to_cpu):
+    """selection rules + crop terms of ONE view (edit_dataset.py:89-234) on the slices of a (possibly batched) distill render:
+    `out` = render of the edit grid, `g` = render of the grow grid or None; every tensor covers this view's H*W rays"""
     w_density, w_edit, depth, min_near = out["weights"], out["weights_edit"], out["depth"], out["min_near"]
     pred_w8s, mask = select_edit_pixels(w_density, w_edit, depth, min_near, depth_diff)
     if mask.numel() == 0:
         return None
     res = {"weights_densitygrid": w_density, "weights_editgrid": pred_w8s, "pred_imgs": out["image"]}
     dist_factor = None
-    if grow_grid is not None:                                                 # :122-146 smooth transition weights
-        with torch.autocast("cuda", dtype=torch.float16):
-            g = renderer.render_distill(rays_o, rays_d, grow_grid, perturb=True, grow_grid=True, nears=rays["nears"].view(-1))
+    if g is not None:                                                         # :122-146 smooth transition weights
         x_grow = g["x_term"][g["weights_edit"] > .99]
         if x_grow.shape[0]:
             pts = out["x_term"][mask]
@@ -89,7 +77,7 @@ def extract_view(renderer, pose, intrinsics, H, W, edit_grid, image, depth_diff=
             dist_factor = torch.zeros_like(pred_w8s[mask])
         md = dist_factor.nonzero(as_tuple=True)[0]
         res["indices_interp"], res["dist_weights"] = md, dist_factor[md]
-    target = image.to(rays_o.device)
+    target = image.to(rays_d.device)
     if target.shape[-1] == 4:
         target = target[..., :3] * target[..., -1][..., None]
     target = target.reshape(-1, 3)[mask]
@@ -103,15 +91,53 @@ def extract_view(renderer, pose, intrinsics, H, W, edit_grid, image, depth_diff=
     return res
 
 
+def _render_views(renderer, poses, intrinsics, H, W, edit_grid, grow_grid):
+    """rays of ALL given views in one get_rays launch and ONE device-resident distill render over them (+ one for the grow
+    grid): the frame loop takes any number of rays, so V views cost one loop instead of V (the reference renders view by
+    view, edit_dataset.py:74-87)"""
+    V = poses.shape[0]
+    rays = get_rays(poses.reshape(V, 4, 4), intrinsics, H, W, -1, aabb=renderer.aabb_infer, min_near=renderer.min_near)
+    rays_o, rays_d, nears = rays["rays_o"].reshape(-1, 3), rays["rays_d"].reshape(-1, 3), rays["nears"].reshape(-1)
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = renderer.render_distill(rays_o, rays_d, edit_grid, perturb=True, nears=nears)
+        g = renderer.render_distill(rays_o, rays_d, grow_grid, perturb=True, grow_grid=True, nears=nears) if grow_grid is not None else None
+    n = H * W
+
+    def view_of(d, v):
+        if d is None:
+            return None
+        o = {k: (t[v * n:(v + 1) * n] if torch.is_tensor(t) and t.shape[:1] == (V * n,) else t) for k, t in d.items()}
+        o["min_near"] = nears[v * n:(v + 1) * n].min()            # per view, like the reference (renderer.py:478)
+        return o
+    return [(view_of(out, v), view_of(g, v), rays_d[v * n:(v + 1) * n]) for v in range(V)]
+
+
+def extract_view(renderer, pose, intrinsics, H, W, edit_grid, image, depth_diff=0.5, grow_grid=None, max_dist=0.1,
+                 num_steps=1024, to_cpu=False):
+    """One iteration of the loop at edit_dataset.py:74-234.
+
+    renderer: laenerf_amd.renderer.NeRFRenderer (eval mode); pose [4,4] or [1,4,4]; edit_grid / grow_grid: uint8 bitfields;
+    image [H,W,3|4] ground truth of the view.  Returns None when the region is occluded in this view (:103-108), else a
+    dict with the reference's per-view entries (w8s, targets, x_term, dirs, depths, indices, weights_densitygrid,
+    weights_editgrid, pred_imgs, cut_*, depth_factor and, with a grow grid, indices_interp / dist_weights)."""
+    (out, g, rays_d), = _render_views(renderer, pose.reshape(1, 4, 4), intrinsics, H, W, edit_grid, grow_grid)
+    return _pack_view(out, g, rays_d, H, W, image, depth_diff, max_dist, num_steps, to_cpu)
+
+
 @torch.no_grad()
-def extract_views(renderer, poses, intrinsics, H, W, edit_grid, images, **kw):
-    """the whole loop: returns (list of per-view dicts, list of occluded pose indices) (edit_dataset.py:74, 107)"""
+def extract_views(renderer, poses, intrinsics, H, W, edit_grid, images, batch_views=4, depth_diff=0.5, grow_grid=None, max_dist=0.1,
+                  num_steps=1024, to_cpu=False):
+    """the whole loop: returns (list of per-view dicts, list of occluded pose indices) (edit_dataset.py:74, 107).
+    `batch_views` views share one ray-generation launch and one distill render (SURVEY 8f-3 "batched multi-view distill
+    render"); the selection rules run per view on slices of the batch."""
     views, occluded = [], []
-    for i in range(poses.shape[0]):
-        v = extract_view(renderer, poses[i], intrinsics, H, W, edit_grid, images[i], **kw)
-        if v is None:
-            occluded.append(i)
-        else:
-            v["pose_idx"] = i
-            views.append(v)
+    for i0 in range(0, poses.shape[0], max(1, int(batch_views))):
+        batch = poses[i0:i0 + max(1, int(batch_views))]
+        for j, (out, g, rays_d) in enumerate(_render_views(renderer, batch, intrinsics, H, W, edit_grid, grow_grid)):
+            v = _pack_view(out, g, rays_d, H, W, images[i0 + j], depth_diff, max_dist, num_steps, to_cpu)
+            if v is None:
+                occluded.append(i0 + j)
+            else:
+                v["pose_idx"] = i0 + j
+                views.append(v)
     return views, occluded

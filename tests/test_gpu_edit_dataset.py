@@ -109,3 +109,28 @@ def test_extract_views_end_to_end(O):
     assert len(views) == 3 and occluded == [] and all(not t.is_cuda for t in views[0].values() if torch.is_tensor(t))
     views, occluded = extract_views(r, poses, intr, H, W, torch.zeros_like(edit), images)
     assert views == [] and occluded == [0, 1, 2]
+
+
+def test_batched_views_equal_single_views_up_to_the_jitter(O):
+    """extract_views(batch_views=3): one ray-generation launch and one distill render for three views; per view the same
+    entries as the view-by-view loop (the jittered march start differs per call, so pixel sets agree to a few edge pixels)"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.editing import extract_views
+    net, r = make(bound=1, seed=2)
+    H = W = 96
+    intr = np.array([133.3, 133.3, 48.0, 48.0], np.float32)
+    poses = T(poses_looking_at_origin(3, 3.2, seed=1))
+    r.density_scale = 30.0
+    dens = S.sphere_density_grid()
+    coords = O.morton3D_invert(np.arange(128 ** 3, dtype=np.int32))
+    edit = T(S.pack_bits_np(np.where(coords[:, 0] >= 64, dens[0], 0)[None], 10.0))
+    images = torch.rand(3, H, W, 3, device=DEV)
+    single, occ1 = extract_views(r, poses, intr, H, W, edit, images, batch_views=1)
+    batched, occ3 = extract_views(r, poses, intr, H, W, edit, images, batch_views=3)
+    assert occ1 == occ3 == [] and [v["pose_idx"] for v in batched] == [0, 1, 2]
+    for a, b in zip(single, batched):
+        ia, ib = set(N(a["indices"]).tolist()), set(N(b["indices"]).tolist())
+        assert len(ia ^ ib) <= max(3, 0.03 * max(len(ia), len(ib))) and len(ia) > 10
+        assert a["weights_densitygrid"].shape == b["weights_densitygrid"].shape == (H * W,)
+        assert np.abs(N(a["weights_densitygrid"]) - N(b["weights_densitygrid"])).mean() < 5e-3
+        assert set(a.keys()) == set(b.keys())
