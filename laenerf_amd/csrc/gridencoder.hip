@@ -488,6 +488,7 @@ constexpr uint32_t UNIT_SAMPLES = FILL_THREADS * SPT;          // 512
 constexpr uint32_t STAGE_CAP = 4096;                           // items staged in LDS (all of a unit unless corner pairs split)
 constexpr uint32_t KEY_SINGLE = 15u, KEY_NEXT = 14u;           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1); 14 -> e0 + 1
 constexpr int ACC_THREADS = 1024;
+constexpr uint32_t BWD_MAX_SAMPLES = 1u << 28;                  // byte offsets of the walk's buffer loads stay below 2^32
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
 constexpr uint32_t SUB_RECS = 16;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
@@ -532,8 +533,6 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     // Coarse levels keep arrival order instead: the accumulate pass merges neighbouring repeats.
     const uint32_t NC = (P <= BK_MAX / 8 && li.resolution >= COARSE_RES) ? 8u : 1u;
     const T* __restrict__ g_lvl = gradT + (size_t)level * B * 2;
-    const bool wide_ok = (reinterpret_cast<uintptr_t>(inputs) & 15) == 0;
-    const bool gwide = FILL && ((size_t)level * B * 2 * sizeof(T)) % 16 == 0 && (reinterpret_cast<uintptr_t>(gradT) & 15) == 0;
 
     uint32_t cpg[3] = {0, 0, 0};
     bool have = false;
@@ -576,53 +575,50 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
         const uint32_t u = chunk * SEGS + seg, unit = level * U + u;
         const uint32_t bs = b0 + seg * SPT;
         const bool last = seg == SEGS - 1;
+        // every global read of the unit is issued before the first one is consumed: one memory latency, not three
+        static_assert(BK_MAX / 2 == FILL_THREADS && BK_MAX == 2 * FILL_THREADS, "one counter word and two partitions per lane");
+        uint32_t w_cnt = 0, gb_off[2] = {0, 0}, gb_cnt[2] = {0, 0};
         if (!FILL) { for (uint32_t k = tid; k < BK_MAX; k += FILL_THREADS) hist[k] = 0; }
         else {
             // the unit's own counters (from the count pass) and where its run of every partition starts in the queue
-            for (uint32_t k = tid; k < BK_MAX / 2; k += FILL_THREADS) {
-                const uint32_t w = reinterpret_cast<const uint32_t*>(plan.cnt + (size_t)unit * BK_MAX)[k];
-                hist[2 * k] = w & 0xffffu; hist[2 * k + 1] = w >> 16;
+            w_cnt = reinterpret_cast<const uint32_t*>(plan.cnt + (size_t)unit * BK_MAX)[tid];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t k = tid + i * FILL_THREADS;
+                if (k < P) { gb_off[i] = plan.offs[level * BK_MAX + k]; gb_cnt[i] = plan.part_cnt[((size_t)level * BK_MAX + k) * U + u]; }
             }
-            for (uint32_t k = tid; k < P; k += FILL_THREADS)
-                gbase[k] = plan.offs[level * BK_MAX + k] + plan.part_cnt[((size_t)level * BK_MAX + k) * U + u];
         }
-        // ---- positions (and gradients) of SPT consecutive samples
+        // ---- positions (and gradients) of SPT consecutive samples: 16-byte buffer loads, the hardware range check
+        // returns zeros past the end of the batch (no ragged-tail path for the compiler to blend into the wide one)
+        static_assert(SPT == 4, "the wide reads below take 4 samples per lane");
         float xs[SPT][3], g0[SPT], g1[SPT];
-        if (bs + SPT <= B && wide_ok) {
-            const float4* src = reinterpret_cast<const float4*>(inputs + (size_t)bs * 3);            // 48 B per lane
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
-            xs[0][0] = v0.x; xs[0][1] = v0.y; xs[0][2] = v0.z; xs[1][0] = v0.w; xs[1][1] = v1.x; xs[1][2] = v1.y;
-            xs[2][0] = v1.z; xs[2][1] = v1.w; xs[2][2] = v2.x; xs[3][0] = v2.y; xs[3][1] = v2.z; xs[3][2] = v2.w;
-        } else {
+        {
+            using u4 = __attribute__((__vector_size__(16))) uint32_t;
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inputs), 0, (int)(B * 12u), 0x00020000);
+            const u4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u), 0, 0);
+            const u4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u + 16u), 0, 0);
+            const u4 x2 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u + 32u), 0, 0);
+            u4 ga = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+            if constexpr (FILL) {
+                const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g_lvl), 0, (int)(B * 2u * (uint32_t)sizeof(T)), 0x00020000);
+                ga = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)(bs * 2u * (uint32_t)sizeof(T)), 0, 0);
+                if constexpr (sizeof(T) == 4) gb = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)(bs * 8u + 16u), 0, 0);
+            }
+            const uint32_t t[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+            const uint32_t gw[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
 #pragma unroll
             for (int s_ = 0; s_ < SPT; s_++) {
-                const uint32_t b = min(bs + s_, B - 1);
-                xs[s_][0] = inputs[(size_t)b * 3]; xs[s_][1] = inputs[(size_t)b * 3 + 1]; xs[s_][2] = inputs[(size_t)b * 3 + 2];
+#pragma unroll
+                for (int d = 0; d < 3; d++) xs[s_][d] = __builtin_bit_cast(float, t[3 * s_ + d]);
+                if constexpr (FILL && sizeof(T) == 2) { const half2_t h = __builtin_bit_cast(half2_t, gw[s_]); g0[s_] = (float)h[0]; g1[s_] = (float)h[1]; }
+                else if constexpr (FILL) { g0[s_] = __builtin_bit_cast(float, gw[2 * s_]); g1[s_] = __builtin_bit_cast(float, gw[2 * s_ + 1]); }
+                else { g0[s_] = 0.f; g1[s_] = 0.f; }
             }
         }
         if constexpr (FILL) {
-            if (bs + SPT <= B && gwide) {
-                if constexpr (sizeof(T) == 2) {
-                    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const half2_t*>(g_lvl) + bs);
-                    const uint32_t w[4] = {gv.x, gv.y, gv.z, gv.w};
+            hist[2 * tid] = w_cnt & 0xffffu; hist[2 * tid + 1] = w_cnt >> 16;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const half2_t h = __builtin_bit_cast(half2_t, w[k]); g0[k] = (float)h[0]; g1[k] = (float)h[1]; }
-                } else {
-                    const float4* gs = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(g_lvl) + bs);
-                    const float4 ga = gs[0], gb = gs[1];
-                    g0[0] = ga.x; g1[0] = ga.y; g0[1] = ga.z; g1[1] = ga.w; g0[2] = gb.x; g1[2] = gb.y; g0[3] = gb.z; g1[3] = gb.w;
-                }
-            } else {
-#pragma unroll
-                for (int s_ = 0; s_ < SPT; s_++) {
-                    const uint32_t b = min(bs + s_, B - 1);
-                    if constexpr (sizeof(T) == 2) { const half2_t gv = reinterpret_cast<const half2_t*>(g_lvl)[b]; g0[s_] = (float)gv[0]; g1[s_] = (float)gv[1]; }
-                    else { const float2 gv = reinterpret_cast<const float2*>(g_lvl)[b]; g0[s_] = gv.x; g1[s_] = gv.y; }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s_ = 0; s_ < SPT; s_++) { g0[s_] = 0.f; g1[s_] = 0.f; }
+            for (int i = 0; i < 2; i++) { const uint32_t k = tid + i * FILL_THREADS; if (k < P) gbase[k] = gb_off[i] + gb_cnt[i]; }
         }
         uint32_t pgs[SPT][3]; float frs[SPT][3]; bool oks[SPT];
 #pragma unroll
@@ -1387,7 +1383,7 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
-    if (plan && !(D == 3 && C == 2 && L <= 32 && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
+    if (plan && !(D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
     BwdArgs a;
     a.offsets_host = offsets_host;
@@ -1400,7 +1396,7 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     a.gs_l = blc ? C : (uint64_t)B * C;
     a.stream = reinterpret_cast<hipStream_t>(stream);
     if (dtype != LAE_F32 && dtype != LAE_F16) return LAE_EINVAL;
-    if (D == 3 && C == 2 && L <= 32 && !g_force_atomic_bwd) {
+    if (D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !g_force_atomic_bwd) {
         // binned path (k_bwd_fill / k_bwd_acc); [B, L*2] grads are transposed into the workspace first
         const size_t esz = dtype == LAE_F16 ? 2 : 4;
         const void* gT = grad;
@@ -1509,7 +1505,7 @@ int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, u
                                   float in_scale, void* plan, void* stream) {
     if (B == 0) return LAE_OK;
     if (!inputs || !offsets || !plan) return LAE_ENULL;
-    if (D != 3 || C != 2 || L > 32 || gridtype > 1 || interp > 1 || (dtype != LAE_F32 && dtype != LAE_F16)) return LAE_EINVAL;
+    if (D != 3 || C != 2 || L > 32 || B > BWD_MAX_SAMPLES || gridtype > 1 || interp > 1 || (dtype != LAE_F32 && dtype != LAE_F16)) return LAE_EINVAL;
     BwdArgs a;
     a.grad = nullptr; a.inputs = inputs; a.offsets = offsets; a.gemb = nullptr; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
