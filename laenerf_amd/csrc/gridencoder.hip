@@ -488,7 +488,7 @@ constexpr uint32_t UNIT_SAMPLES = FILL_THREADS * SPT;          // 512
 constexpr uint32_t STAGE_CAP = 4096;                           // items staged in LDS (all of a unit unless corner pairs split)
 constexpr uint32_t KEY_SINGLE = 15u, KEY_NEXT = 14u;           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1); 14 -> e0 + 1
 constexpr int ACC_THREADS = 1024;
-constexpr uint32_t BWD_MAX_SAMPLES = 1u << 28;                  // byte offsets of the walk's buffer loads stay below 2^32
+constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
 constexpr uint32_t SUB_RECS = 16;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
@@ -594,18 +594,31 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
         float xs[SPT][3], g0[SPT], g1[SPT];
         {
             using u4 = __attribute__((__vector_size__(16))) uint32_t;
-            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inputs), 0, (int)(B * 12u), 0x00020000);
+            // (the range check is all-or-nothing per 16-byte load: the records end with the last whole group of 4 samples,
+            // the one lane that holds the batch's last 1-3 samples reads them with plain loads below)
+            const uint32_t B4 = B & ~3u;
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inputs), 0, (int)(B4 * 12u), 0x00020000);
             const u4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u), 0, 0);
             const u4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u + 16u), 0, 0);
             const u4 x2 = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(bs * 12u + 32u), 0, 0);
             u4 ga = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
             if constexpr (FILL) {
-                const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g_lvl), 0, (int)(B * 2u * (uint32_t)sizeof(T)), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(g_lvl), 0, (int)(B4 * 2u * (uint32_t)sizeof(T)), 0x00020000);
                 ga = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)(bs * 2u * (uint32_t)sizeof(T)), 0, 0);
                 if constexpr (sizeof(T) == 4) gb = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)(bs * 8u + 16u), 0, 0);
             }
-            const uint32_t t[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
-            const uint32_t gw[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+            uint32_t t[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+            uint32_t gw[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+            if (bs == B4 && B4 != B) {
+#pragma unroll
+                for (int s_ = 0; s_ < 3; s_++) {
+                    if (bs + s_ >= B) break;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) t[3 * s_ + d] = __builtin_bit_cast(uint32_t, inputs[(size_t)(bs + s_) * 3 + d]);
+                    if constexpr (FILL && sizeof(T) == 2) gw[s_] = reinterpret_cast<const uint32_t*>(g_lvl)[bs + s_];
+                    else if constexpr (FILL) { gw[2 * s_] = reinterpret_cast<const uint32_t*>(g_lvl)[2 * (bs + s_)]; gw[2 * s_ + 1] = reinterpret_cast<const uint32_t*>(g_lvl)[2 * (bs + s_) + 1]; }
+                }
+            }
 #pragma unroll
             for (int s_ = 0; s_ < SPT; s_++) {
 #pragma unroll
@@ -829,18 +842,23 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         }
     };
 
+    // the first task of every workgroup is its own index (gridDim.x same-address atomics at launch would queue up behind one
+    // another); later tasks are drawn from the ticket counter, which therefore counts from gridDim.x
+    bool first_task = true;
     for (;;) {
-        if (tid == 0) s_ticket = atomicAdd(&plan.tickets[0], 1u);
+        if (tid == 0) s_ticket = first_task ? blockIdx.x : atomicAdd(&plan.tickets[0], 1u) + gridDim.x;
+        first_task = false;
         __syncthreads();
-        const uint32_t t = s_ticket;
+        const uint32_t t = __builtin_amdgcn_readfirstlane(s_ticket);       // scalar: everything derived from it is wave-uniform
         if (t >= total_buckets) break;
         const uint32_t item = t;                                // coarse levels first: their sub-ranges + merge are the longest chains
         uint32_t level = 0;
         while (level + 1 < L && item >= s_first[level + 1]) level++;
-        const uint32_t bk = item - s_first[level];
-        const uint32_t SUB = s_sub[level], p = bk / SUB, sub = bk % SUB;
+        level = __builtin_amdgcn_readfirstlane(level);
+        const uint32_t bk = item - __builtin_amdgcn_readfirstlane(s_first[level]);
+        const uint32_t SUB = __builtin_amdgcn_readfirstlane(s_sub[level]), p = bk / SUB, sub = bk % SUB;
         const uint32_t table_off = (uint32_t)offsets[level], hashmap_size = (uint32_t)offsets[level + 1] - table_off;
-        const uint32_t n = plan.totals[level * BK_MAX + p], q0 = plan.offs[level * BK_MAX + p];
+        const uint32_t n = __builtin_amdgcn_readfirstlane(plan.totals[level * BK_MAX + p]), q0 = __builtin_amdgcn_readfirstlane(plan.offs[level * BK_MAX + p]);
         const uint32_t lo = (uint32_t)(((uint64_t)n * sub) / SUB), hi = (uint32_t)(((uint64_t)n * (sub + 1)) / SUB);
         if (n == 0) { __syncthreads(); continue; }              // uniform per (level, partition): no sub-range has work
         for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = 0ull;
@@ -864,15 +882,31 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
             // key, and same-address LDS atomics of ONE instruction serialise (level 0: 16 workgroups x 70 k atomics at ~2
             // cycles each = the whole pass).  Each lane takes 8 CONSECUTIVE items and sums them in registers while the key
             // repeats: one atomic group per run, neighbouring lanes 8 items apart.
-            for (uint32_t c = lo + tid * 8u; c < hi; c += ACC_THREADS * 8u) {
-                V v[8]; uint32_t k[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) { const uint32_t ii = min(c + (uint32_t)j, hi - 1u); v[j] = pv[ii]; k[j] = pk[ii]; }
-                const uint32_t cnt = min(8u, hi - c);
-                if constexpr (HALF) {
-                    uint32_t ckey = k[0];
+            if constexpr (HALF) {
+                // groups of 8 items on ABSOLUTE 8-item boundaries of the queue: a lane reads one 64-byte line of values and
+                // 16 bytes of keys with five 16-byte buffer loads;
+                // items of the neighbouring sub-range in the first / last group are masked.  Neighbouring LANES take groups
+                // 128 items apart (another ray, usually another cell): lanes 8 items apart sit in the same cell and their
+                // atomics to the same 8 entries serialise.
+                using u4 = __attribute__((__vector_size__(16))) uint32_t;
+                const uint32_t abs_lo = q0 + lo, abs_hi = q0 + hi, A0 = abs_lo & ~7u;
+                const uint32_t n_groups = (abs_hi - A0 + 7u) >> 3;
+                // whole groups are always inside the queue (its capacity is a multiple of 8 items); the range check of a
+                // 16-byte buffer load is all-or-nothing, so the records cover whole groups
+                const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<V*>(qvals + A0), 0, (int)(n_groups * 64u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkeys + A0), 0, (int)(n_groups * 16u), 0x00020000);
+                for (uint32_t gq = (tid & 63u) * (ACC_THREADS / 64) + (tid >> 6); gq < n_groups; gq += ACC_THREADS) {
+                    const u4 va = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u), 0, 0);
+                    const u4 vb = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u + 16u), 0, 0);
+                    const u4 vc = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u + 32u), 0, 0);
+                    const u4 vd = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u + 48u), 0, 0);
+                    const u4 kk = __builtin_amdgcn_raw_buffer_load_b128(rs_k, (int)(gq * 16u), 0, 0);
+                    const uint32_t w[16] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3], vc[0], vc[1], vc[2], vc[3], vd[0], vd[1], vd[2], vd[3]};
+                    const uint32_t a0 = A0 + gq * 8u;
+                    const uint32_t first = a0 < abs_lo ? abs_lo - a0 : 0u, last = min(8u, abs_hi - a0);
+                    uint32_t ckey = 0;
                     long long s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-                    bool bad0 = false, bad1 = false;
+                    bool bad0 = false, bad1 = false, started = false;
                     auto flush = [&]() {
                         const uint32_t e0 = ckey & (PART - 1), code = ckey >> 12;
                         const uint32_t e1 = code == KEY_NEXT ? e0 + 1 : (e0 ^ ((2u << code) - 1u));
@@ -885,17 +919,27 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                     };
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        if ((uint32_t)j < cnt) {
-                            if (k[j] != ckey) { flush(); ckey = k[j]; s00 = s01 = s10 = s11 = 0; bad0 = bad1 = false; }
-                            const uint32_t w0 = v[j].x, w1 = v[j].y;
+                        if ((uint32_t)j >= first && (uint32_t)j < last) {
+                            const uint32_t kj = (kk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                            if (!started || kj != ckey) {
+                                if (started) flush();
+                                ckey = kj; s00 = s01 = s10 = s11 = 0; bad0 = bad1 = false; started = true;
+                            }
+                            const uint32_t w0 = w[2 * j], w1 = w[2 * j + 1];
                             if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) bad0 = true;
                             else { s00 += half_to_fix24(w0 & 0xffffu); s01 += half_to_fix24(w0 >> 16); }
                             if (half_nonfinite(w1) || half_nonfinite(w1 >> 16)) bad1 = true;
                             else { s10 += half_to_fix24(w1 & 0xffffu); s11 += half_to_fix24(w1 >> 16); }
                         }
                     }
-                    flush();
-                } else {
+                    if (started) flush();
+                }
+            } else {
+                for (uint32_t c = lo + tid * 8u; c < hi; c += ACC_THREADS * 8u) {
+                    V v[8]; uint32_t k[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { const uint32_t ii = min(c + (uint32_t)j, hi - 1u); v[j] = pv[ii]; k[j] = pk[ii]; }
+                    const uint32_t cnt = min(8u, hi - c);
 #pragma unroll
                     for (int j = 0; j < 8; j++) if ((uint32_t)j < cnt) apply(k[j], v[j]);
                 }

@@ -109,7 +109,8 @@ def test_grid_backward_fp32(O, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(B=20000), dict(L=8, T_log2=12, desired=512, B=6000), dict(gridtype=1, T_log2=15, desired=1024),
-                                dict(L=8, T_log2=16, desired=32768, B=8000), dict(L=4, T_log2=22, desired=4096, B=6000)])
+                                dict(L=8, T_log2=16, desired=32768, B=8000), dict(L=4, T_log2=22, desired=4096, B=6000),
+                                dict(B=20001), dict(B=4098, L=4), dict(B=1027, L=4), dict(B=7, L=2), dict(B=5, L=2)])
 def test_grid_backward_modes_agree(O, kw):
     """binned LDS pipeline vs generic global-atomic kernel vs oracle (fp32), incl. hashed levels smaller than a partition,
     (desired=32768) levels finer than a partition, whose x-corner pairs may straddle partitions (two single-corner items),
@@ -134,12 +135,14 @@ def test_grid_backward_modes_agree(O, kw):
     G.grid_encode_backward(T(g), T(x), T(table), T(offsets), ge, B, D, C, L, np.log2(pls), 16, None, None, gt, False, 0)
 
 
-def test_grid_backward_fp16_exact_sum(O):
+@pytest.mark.parametrize("B", [30000, 30001, 29999, 1022])
+def test_grid_backward_fp16_exact_sum(O, B):
     """fp16 mode of the binned pipeline = correctly rounded exact sum of the fp16-rounded contributions (int64 fixed point):
-    compare with a float64 accumulation of the same rounded contributions; also deterministic across runs"""
+    compare with a float64 accumulation of the same rounded contributions; also deterministic across runs.  Batch sizes that
+    are not a multiple of the 4 samples a lane reads at once: the last lane's 1-3 samples must not be lost."""
     from laenerf_amd.backend import gridencoder_backend as G
-    offsets, pls, table, x = grid_case(O, B=30000)
-    B, L, C = 30000, 16, 2
+    offsets, pls, table, x = grid_case(O, B=B)
+    L, C = 16, 2
     g = (np.random.default_rng(2).standard_normal((L, B, C)) * 1e-1).astype(np.float32)
     gh = O.to_f16_bits(g)
     ge = torch.zeros(table.shape, device=DEV, dtype=torch.half)
