@@ -867,7 +867,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         const uint32_t scale_res = (uint32_t)ceilf(sc.scale[level]) + 1;
         const V* __restrict__ pv = qvals + q0;
         const uint16_t* __restrict__ pk = qkeys + q0;
-        if (scale_res >= COARSE_RES) {
+        if (!HALF && scale_res >= COARSE_RES) {
             uint32_t i = lo + tid;
             for (; i + 3 * ACC_THREADS < hi; i += 4 * ACC_THREADS) {              // four loads in flight per lane
                 V v[4]; uint32_t k[4];
@@ -884,10 +884,10 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
             // repeats: one atomic group per run, neighbouring lanes 8 items apart.
             if constexpr (HALF) {
                 // groups of 8 items on ABSOLUTE 8-item boundaries of the queue: a lane reads one 64-byte line of values and
-                // 16 bytes of keys with five 16-byte buffer loads;
-                // items of the neighbouring sub-range in the first / last group are masked.  Neighbouring LANES take groups
-                // 128 items apart (another ray, usually another cell): lanes 8 items apart sit in the same cell and their
-                // atomics to the same 8 entries serialise.
+                // 16 bytes of keys with five 16-byte buffer loads (a partition of a fine level is one round of loads);
+                // items of the neighbouring sub-range in the first / last group are masked.  On the coarse levels
+                // neighbouring LANES take groups 128 items apart (another ray, usually another cell): lanes 8 items apart sit
+                // in the same cell and their atomics to the same 8 entries serialise.
                 using u4 = __attribute__((__vector_size__(16))) uint32_t;
                 const uint32_t abs_lo = q0 + lo, abs_hi = q0 + hi, A0 = abs_lo & ~7u;
                 const uint32_t n_groups = (abs_hi - A0 + 7u) >> 3;
@@ -895,7 +895,8 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 // 16-byte buffer load is all-or-nothing, so the records cover whole groups
                 const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<V*>(qvals + A0), 0, (int)(n_groups * 64u), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(qkeys + A0), 0, (int)(n_groups * 16u), 0x00020000);
-                for (uint32_t gq = (tid & 63u) * (ACC_THREADS / 64) + (tid >> 6); gq < n_groups; gq += ACC_THREADS) {
+                const bool coarse = scale_res < COARSE_RES;
+                for (uint32_t gq = coarse ? (tid & 63u) * (ACC_THREADS / 64) + (tid >> 6) : tid; gq < n_groups; gq += ACC_THREADS) {
                     const u4 va = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u), 0, 0);
                     const u4 vb = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u + 16u), 0, 0);
                     const u4 vc = __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(gq * 64u + 32u), 0, 0);
@@ -904,6 +905,12 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                     const uint32_t w[16] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3], vc[0], vc[1], vc[2], vc[3], vd[0], vd[1], vd[2], vd[3]};
                     const uint32_t a0 = A0 + gq * 8u;
                     const uint32_t first = a0 < abs_lo ? abs_lo - a0 : 0u, last = min(8u, abs_hi - a0);
+                    if (!coarse) {             // finer levels: neighbouring items are unrelated, one atomic group per item
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if ((uint32_t)j >= first && (uint32_t)j < last) { V v; v.x = w[2 * j]; v.y = w[2 * j + 1]; apply((kk[j >> 1] >> (16 * (j & 1))) & 0xffffu, v); }
+                        continue;
+                    }
                     uint32_t ckey = 0;
                     long long s00 = 0, s01 = 0, s10 = 0, s11 = 0;
                     bool bad0 = false, bad1 = false, started = false;
