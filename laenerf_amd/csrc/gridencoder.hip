@@ -486,7 +486,7 @@ constexpr int SPT = 4;                                         // consecutive sa
 constexpr int SEGS = 1;                                        // segments per block: a lane walks SPT * SEGS consecutive samples
 constexpr uint32_t UNIT_SAMPLES = FILL_THREADS * SPT;          // 512
 constexpr uint32_t STAGE_CAP = 4096;                           // items staged in LDS (all of a unit unless corner pairs split)
-constexpr uint32_t KEY_SINGLE = 15u, KEY_NEXT = 14u;           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1); 14 -> e0 + 1
+constexpr uint32_t KEY_SINGLE = 15u;                           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1) (e0 + 1 is such an xor too: the trailing ones of e0 and the zero above them flip)
 constexpr int ACC_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
@@ -562,8 +562,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             const uint32_t e0 = i0 & (PART - 1), e1 = i1 & (PART - 1), d = e0 ^ e1;
             const bool same_part = (i0 >> PART_SHIFT) == (i1 >> PART_SHIFT) && d != 0;
             const uint32_t c0 = (i0 >> PART_SHIFT) * NC + (lane & (NC - 1)), c1 = (i1 >> PART_SHIFT) * NC + (lane & (NC - 1));
-            if (same_part && e1 == e0 + 1) visit(2 * yz, c0, e0 | (KEY_NEXT << 12), true);
-            else if (same_part && (d & (d + 1)) == 0) visit(2 * yz, c0, e0 | ((uint32_t)(__builtin_popcount(d) - 1) << 12), true);
+            if (same_part && (d & (d + 1)) == 0) visit(2 * yz, c0, e0 | ((uint32_t)(__builtin_popcount(d) - 1) << 12), true);
             else {
                 visit(2 * yz, c0, e0 | (KEY_SINGLE << 12), false);
                 visit(2 * yz + 1, c1, e1 | (KEY_SINGLE << 12), false);
@@ -770,9 +769,12 @@ __global__ __launch_bounds__(1024) void k_bwd_scan_parts(uint32_t n, BwdPlan pla
 
 // fp16 bits -> value * 2^24 as a signed integer (exact: finite fp16 values are multiples of 2^-24, |v| * 2^24 < 2^40)
 __device__ __forceinline__ long long half_to_fix24(uint32_t u) {
-    const uint32_t e = (u >> 10) & 31u, m = u & 1023u;
-    const unsigned long long mag = e ? ((unsigned long long)(m | 1024u) << (e - 1)) : (unsigned long long)m;
-    return (u & 0x8000u) ? -(long long)mag : (long long)mag;
+    // branch-free, sign applied to the 11-bit mantissa in 32 bits: (+-mantissa) << (max(e, 1) - 1), subnormals have no hidden bit
+    const uint32_t e = (u >> 10) & 31u;
+    const int32_t smask = (int32_t)(u << 16) >> 31;
+    const uint32_t mant = (u & 1023u) | (min(e, 1u) << 10);
+    const int32_t sm = (int32_t)(mant ^ (uint32_t)smask) - smask;
+    return (long long)sm << (max(e, 1u) - 1u);
 }
 // value * 2^24 (signed integer) -> nearest fp16 (ties to even), ONE rounding; overflow -> infinity
 __device__ __forceinline__ uint32_t fix24_to_half(long long t) {
@@ -820,19 +822,30 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
 
     auto apply = [&](uint32_t key, const V& v) {
         const uint32_t e0 = key & (PART - 1), code = key >> 12;
-        const uint32_t e1 = code == KEY_NEXT ? e0 + 1 : (e0 ^ ((2u << code) - 1u));
+        const uint32_t e1 = e0 ^ ((2u << code) - 1u);
         if constexpr (HALF) {
             const uint32_t w0 = v.x, w1 = v.y;
-            if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
-            else {
+            // one test for the item's four halves: a half is non-finite iff adding one to its exponent field carries out of it
+            const uint32_t carry = (((w0 & 0x7c007c00u) + 0x04000400u) | ((w1 & 0x7c007c00u) + 0x04000400u)) & 0x80008000u;
+            if (carry == 0) {
                 atomicAdd(&acc64[e0], (unsigned long long)half_to_fix24(w0 & 0xffffu));
                 atomicAdd(&acc64[PART + e0], (unsigned long long)half_to_fix24(w0 >> 16));
-            }
-            if (code != KEY_SINGLE) {
-                if (half_nonfinite(w1) || half_nonfinite(w1 >> 16)) atomicOr(&poison[e1 >> 5], 1u << (e1 & 31));
-                else {
+                if (code != KEY_SINGLE) {
                     atomicAdd(&acc64[e1], (unsigned long long)half_to_fix24(w1 & 0xffffu));
                     atomicAdd(&acc64[PART + e1], (unsigned long long)half_to_fix24(w1 >> 16));
+                }
+            } else {
+                if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
+                else {
+                    atomicAdd(&acc64[e0], (unsigned long long)half_to_fix24(w0 & 0xffffu));
+                    atomicAdd(&acc64[PART + e0], (unsigned long long)half_to_fix24(w0 >> 16));
+                }
+                if (code != KEY_SINGLE) {
+                    if (half_nonfinite(w1) || half_nonfinite(w1 >> 16)) atomicOr(&poison[e1 >> 5], 1u << (e1 & 31));
+                    else {
+                        atomicAdd(&acc64[e1], (unsigned long long)half_to_fix24(w1 & 0xffffu));
+                        atomicAdd(&acc64[PART + e1], (unsigned long long)half_to_fix24(w1 >> 16));
+                    }
                 }
             }
         } else {
@@ -916,7 +929,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                     bool bad0 = false, bad1 = false, started = false;
                     auto flush = [&]() {
                         const uint32_t e0 = ckey & (PART - 1), code = ckey >> 12;
-                        const uint32_t e1 = code == KEY_NEXT ? e0 + 1 : (e0 ^ ((2u << code) - 1u));
+                        const uint32_t e1 = e0 ^ ((2u << code) - 1u);
                         if (bad0) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
                         else { atomicAdd(&acc64[e0], (unsigned long long)s00); atomicAdd(&acc64[PART + e0], (unsigned long long)s01); }
                         if (code != KEY_SINGLE) {
