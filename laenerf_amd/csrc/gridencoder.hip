@@ -540,8 +540,10 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
 #pragma unroll
     for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
 
-    // items of the cell cp: visit(corner slot of the x corner, counter index, key, pair?) per corner row
-    auto cell_items = [&](const uint32_t (&cp)[3], auto&& visit) {
+    // items of the cell cp, one row of x-neighbours (y, z corner) at a time: a PAIR item {counter c0, key k0} when both
+    // entries sit in one partition a low-bit xor apart, else two single items {c0, k0}, {c1, k1}
+    struct Rows { uint32_t c0[4], k0[4], c1[4], k1[4]; bool pair[4]; };
+    auto cell_rows = [&](const uint32_t (&cp)[3], Rows& r) {
         uint32_t hy0 = 0, hy1 = 0, hz0 = 0, hz1 = 0, key0 = 0;
         if (li.use_hash) {
             hy0 = cp[1] * 2654435761u; hy1 = hy0 + 2654435761u;
@@ -561,12 +563,10 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             else if (li.use_hash || !li.nowrap) { i0 %= li.hashmap_size; i1 %= li.hashmap_size; }
             const uint32_t e0 = i0 & (PART - 1), e1 = i1 & (PART - 1), d = e0 ^ e1;
             const bool same_part = (i0 >> PART_SHIFT) == (i1 >> PART_SHIFT) && d != 0;
-            const uint32_t c0 = (i0 >> PART_SHIFT) * NC + (lane & (NC - 1)), c1 = (i1 >> PART_SHIFT) * NC + (lane & (NC - 1));
-            if (same_part && (d & (d + 1)) == 0) visit(2 * yz, c0, e0 | ((uint32_t)(__builtin_popcount(d) - 1) << 12), true);
-            else {
-                visit(2 * yz, c0, e0 | (KEY_SINGLE << 12), false);
-                visit(2 * yz + 1, c1, e1 | (KEY_SINGLE << 12), false);
-            }
+            r.c0[yz] = (i0 >> PART_SHIFT) * NC + (lane & (NC - 1)); r.c1[yz] = (i1 >> PART_SHIFT) * NC + (lane & (NC - 1));
+            r.pair[yz] = same_part && (d & (d + 1)) == 0;
+            r.k0[yz] = e0 | ((r.pair[yz] ? (uint32_t)(__builtin_popcount(d) - 1) : KEY_SINGLE) << 12);
+            r.k1[yz] = e1 | (KEY_SINGLE << 12);
         }
     };
 
@@ -652,7 +652,12 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
         __syncthreads();
         if constexpr (!FILL) {
             // ---- how many items does each (partition, copy) counter get from this unit
-            auto count_cell = [&]() { cell_items(cpg, [&](int, uint32_t ci, uint32_t, bool) { atomicAdd(&hist[ci], 1u); }); };
+            auto count_cell = [&]() {
+                Rows r;
+                cell_rows(cpg, r);
+#pragma unroll
+                for (int yz = 0; yz < 4; yz++) { atomicAdd(&hist[r.c0[yz]], 1u); if (!r.pair[yz]) atomicAdd(&hist[r.c1[yz]], 1u); }
+            };
 #pragma unroll
             for (int s_ = 0; s_ < SPT; s_++) {
                 if (!oks[s_]) continue;
@@ -679,18 +684,25 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 for (int k = 0; k < (int)(BK_MAX / 64); k++) { v[k] = hist[tid * (BK_MAX / 64) + k]; sum += v[k]; }
                 uint32_t run = lae::wave_incl_scan(sum) - sum;
 #pragma unroll
-                for (int k = 0; k < (int)(BK_MAX / 64); k++) { start[tid * (BK_MAX / 64) + k] = run; run += v[k]; }
+                for (int k = 0; k < (int)(BK_MAX / 64); k++) {     // hist becomes the running slot of its sub-run
+                    start[tid * (BK_MAX / 64) + k] = run; hist[tid * (BK_MAX / 64) + k] = run; run += v[k];
+                }
                 if (tid == 63) start[BK_MAX] = run;
             }
             __syncthreads();
-            for (uint32_t k = tid; k < BK_MAX; k += FILL_THREADS) hist[k] = 0;         // now the fill counters
             const uint32_t total = start[BK_MAX];
             const bool staged = total <= STAGE_CAP;
-            __syncthreads();
             // ---- sums + emission, sorted by partition (slot = sub-run start + arrival order inside it)
             auto emit_cell = [&]() {
-                cell_items(cpg, [&](int c, uint32_t ci, uint32_t key, bool pair) {
-                    const uint32_t slot = start[ci] + atomicAdd(&hist[ci], 1u);
+                Rows r;
+                cell_rows(cpg, r);
+                // the slots of all rows first (independent LDS atomics in flight together), then the writes
+                uint32_t sl0[4], sl1[4];
+#pragma unroll
+                for (int yz = 0; yz < 4; yz++) sl0[yz] = atomicAdd(&hist[r.c0[yz]], 1u);
+#pragma unroll
+                for (int yz = 0; yz < 4; yz++) sl1[yz] = r.pair[yz] ? 0u : atomicAdd(&hist[r.c1[yz]], 1u);
+                auto put = [&](uint32_t slot, uint32_t ci, uint32_t key, int c, bool pair) {
                     V val;
                     if constexpr (sizeof(T) == 2) { val.x = pack_half2(a0[c], a1[c]); val.y = pair ? pack_half2(a0[c + 1], a1[c + 1]) : 0u; }
                     else { val.x = a0[c]; val.y = a1[c]; val.z = pair ? a0[c + 1] : 0.f; val.w = pair ? a1[c + 1] : 0.f; }
@@ -699,7 +711,12 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                         const uint32_t k = ci / NC, dst = gbase[k] + (slot - start[k * NC]);
                         qvals[dst] = val; qkeys[dst] = (uint16_t)key;
                     }
-                });
+                };
+#pragma unroll
+                for (int yz = 0; yz < 4; yz++) {
+                    put(sl0[yz], r.c0[yz], r.k0[yz], 2 * yz, r.pair[yz]);
+                    if (!r.pair[yz]) put(sl1[yz], r.c1[yz], r.k1[yz], 2 * yz + 1, false);
+                }
 #pragma unroll
                 for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
             };
@@ -720,11 +737,24 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             __syncthreads();
             if (staged) {
                 // ---- the staged runs leave for the queue, one partition at a time per wave: consecutive lanes, consecutive slots
-                const uint32_t wv = tid >> 6;
+                // a wave owns a contiguous range of partitions; the (start, end, queue base) triples of up to 64 of them are
+                // read by the lanes at once and handed round through SGPRs, so the copies of consecutive runs do not wait
+                // for one another's LDS reads
+                const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const uint32_t per = (P + FILL_THREADS / 64 - 1) / (FILL_THREADS / 64);
+                const uint32_t kend = min(P, (wv + 1) * per);
+                for (uint32_t kb = wv * per; kb < kend; kb += 64) {
+                    const uint32_t k = kb + lane;
+                    uint32_t s0v = 0, s1v = 0, gbv = 0;
+                    if (k < kend) { s0v = start[k * NC]; s1v = start[(k + 1) * NC]; gbv = gbase[k]; }
+                    const uint32_t np = min(64u, kend - kb);
+                    // two runs at a time, one per half of the wave (a run of a fine level holds ~32 items)
 #pragma unroll 4
-                for (uint32_t k = wv; k < P; k += FILL_THREADS / 64) {
-                    const uint32_t s0 = start[k * NC], s1 = start[(k + 1) * NC], gb = gbase[k];
-                    for (uint32_t i = s0 + lane; i < s1; i += 64) { qvals[gb + (i - s0)] = s_vals[i]; qkeys[gb + (i - s0)] = s_keys[i]; }
+                    for (uint32_t q = 0; q < np; q += 2) {
+                        const int src = (int)(q + (lane >> 5));                  // lanes past np hold zeros: an empty run
+                        const uint32_t s0 = __shfl(s0v, src, 64), s1 = __shfl(s1v, src, 64), gb = __shfl(gbv, src, 64);
+                        for (uint32_t i = s0 + (lane & 31u); i < s1; i += 32) { qvals[gb + (i - s0)] = s_vals[i]; qkeys[gb + (i - s0)] = s_keys[i]; }
+                    }
                 }
             }
             __syncthreads();                                   // staging / counters are reused by the next segment
