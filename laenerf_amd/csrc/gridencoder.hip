@@ -904,6 +904,16 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         const uint32_t n = __builtin_amdgcn_readfirstlane(plan.totals[level * BK_MAX + p]), q0 = __builtin_amdgcn_readfirstlane(plan.offs[level * BK_MAX + p]);
         const uint32_t lo = (uint32_t)(((uint64_t)n * sub) / SUB), hi = (uint32_t)(((uint64_t)n * (sub + 1)) / SUB);
         if (n == 0) { __syncthreads(); continue; }              // uniform per (level, partition): no sub-range has work
+        // the old values of the lane's table entries: requested now, consumed after the items (their latency hides behind
+        // the partition's whole accumulate phase)
+        const uint32_t part_lo = p << PART_SHIFT;
+        const uint32_t n_ent = min(PART, hashmap_size - part_lo);
+        T* __restrict__ dst = grad_grid + ((size_t)table_off + part_lo) * 2;
+        uint32_t oldv[HALF ? PART / ACC_THREADS : 1];
+        if constexpr (HALF) {
+#pragma unroll
+            for (int it = 0; it < (int)(PART / ACC_THREADS); it++) { const uint32_t e = tid + it * ACC_THREADS; oldv[it] = e < n_ent ? reinterpret_cast<const uint32_t*>(dst)[e] : 0u; }
+        }
         for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = 0ull;
         if (tid < PART / 32) poison[tid] = 0u;
         __syncthreads();
@@ -1023,16 +1033,18 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
             if (tid < PART / 32) poison[tid] = atomicExch(rec_poison + tid, 0u);
             __syncthreads();
         }
-        const uint32_t part_lo = p << PART_SHIFT;
-        const uint32_t n_ent = min(PART, hashmap_size - part_lo);
-        T* __restrict__ dst = grad_grid + ((size_t)table_off + part_lo) * 2;
         if constexpr (HALF) {
             uint32_t* d2 = reinterpret_cast<uint32_t*>(dst);
-            for (uint32_t e = tid; e < n_ent; e += ACC_THREADS) {
+            // the old values of the lane's entries first, all in flight together (a load per touched entry inside the loop
+            // below made every round wait for its own memory latency)
+#pragma unroll
+            for (int it = 0; it < (int)(PART / ACC_THREADS); it++) {
+                const uint32_t e = tid + it * ACC_THREADS;
+                if (e >= n_ent) break;
                 const long long i0 = (long long)acc64[e], i1 = (long long)acc64[PART + e];
                 const bool bad = (poison[e >> 5] >> (e & 31)) & 1u;
                 if (i0 == 0 && i1 == 0 && !bad) continue;
-                const uint32_t o = d2[e];                  // only writer of this table slice: old + exact sum, rounded ONCE
+                const uint32_t o = oldv[it];               // only writer of this table slice: old + exact sum, rounded ONCE
                 uint32_t r0, r1;
                 if (bad) { r0 = 0x7e00u; r1 = 0x7e00u; }
                 else {
