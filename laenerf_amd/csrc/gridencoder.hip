@@ -544,6 +544,26 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     // entries sit in one partition a low-bit xor apart, else two single items {c0, k0}, {c1, k1}
     struct Rows { uint32_t c0[4], k0[4], c1[4], k1[4]; bool pair[4]; };
     auto cell_rows = [&](const uint32_t (&cp)[3], Rows& r) {
+        const uint32_t lane_copy = lane & (NC - 1);
+        if (li.use_hash && li.pow2) {
+            // hashed level with a power-of-two table: the x-neighbour is i1 = i0 ^ dx on EVERY row, dx = the low-bit mask
+            // (x ^ (x + 1)) & (size - 1), so whether the row is a pair item and its key code are decided once per cell
+            // (the pass is bound by its instruction count: ~30 instructions per row -> ~9)
+            const uint32_t m = li.hashmap_size - 1u;
+            const uint32_t dx = (cp[0] ^ (cp[0] + 1u)) & m;
+            const bool pr = dx != 0u && dx < PART;
+            const uint32_t code = (pr ? (uint32_t)(__builtin_popcount(dx) - 1) : KEY_SINGLE) << 12;
+            const uint32_t hy0 = cp[1] * 2654435761u, hy1 = hy0 + 2654435761u, hz0 = cp[2] * 805459861u, hz1 = hz0 + 805459861u;
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                const uint32_t i0 = (cp[0] ^ ((yz & 1) ? hy1 : hy0) ^ ((yz & 2) ? hz1 : hz0)) & m, i1 = i0 ^ dx;
+                r.c0[yz] = (i0 >> PART_SHIFT) * NC + lane_copy; r.c1[yz] = (i1 >> PART_SHIFT) * NC + lane_copy;
+                r.pair[yz] = pr;
+                r.k0[yz] = (i0 & (PART - 1)) | code;
+                r.k1[yz] = (i1 & (PART - 1)) | (KEY_SINGLE << 12);
+            }
+            return;
+        }
         uint32_t hy0 = 0, hy1 = 0, hz0 = 0, hz1 = 0, key0 = 0;
         if (li.use_hash) {
             hy0 = cp[1] * 2654435761u; hy1 = hy0 + 2654435761u;
@@ -563,7 +583,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             else if (li.use_hash || !li.nowrap) { i0 %= li.hashmap_size; i1 %= li.hashmap_size; }
             const uint32_t e0 = i0 & (PART - 1), e1 = i1 & (PART - 1), d = e0 ^ e1;
             const bool same_part = (i0 >> PART_SHIFT) == (i1 >> PART_SHIFT) && d != 0;
-            r.c0[yz] = (i0 >> PART_SHIFT) * NC + (lane & (NC - 1)); r.c1[yz] = (i1 >> PART_SHIFT) * NC + (lane & (NC - 1));
+            r.c0[yz] = (i0 >> PART_SHIFT) * NC + lane_copy; r.c1[yz] = (i1 >> PART_SHIFT) * NC + lane_copy;
             r.pair[yz] = same_part && (d & (d + 1)) == 0;
             r.k0[yz] = e0 | ((r.pair[yz] ? (uint32_t)(__builtin_popcount(d) - 1) : KEY_SINGLE) << 12);
             r.k1[yz] = e1 | (KEY_SINGLE << 12);
