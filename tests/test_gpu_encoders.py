@@ -135,15 +135,17 @@ def test_grid_backward_modes_agree(O, kw):
     G.grid_encode_backward(T(g), T(x), T(table), T(offsets), ge, B, D, C, L, np.log2(pls), 16, None, None, gt, False, 0)
 
 
-@pytest.mark.parametrize("B", [30000, 30001, 29999, 1022])
-def test_grid_backward_fp16_exact_sum(O, B):
+@pytest.mark.parametrize("B,gscale", [(30000, 1e-1), (30001, 1e-1), (29999, 1e-1), (1022, 1e-1), (30000, 60.0), (20000, 2e-6)])
+def test_grid_backward_fp16_exact_sum(O, B, gscale):
     """fp16 mode of the binned pipeline = correctly rounded exact sum of the fp16-rounded contributions (int64 fixed point):
     compare with a float64 accumulation of the same rounded contributions; also deterministic across runs.  Batch sizes that
     are not a multiple of the 4 samples a lane reads at once: the last lane's 1-3 samples must not be lost."""
     from laenerf_amd.backend import gridencoder_backend as G
     offsets, pls, table, x = grid_case(O, B=B)
     L, C = 16, 2
-    g = (np.random.default_rng(2).standard_normal((L, B, C)) * 1e-1).astype(np.float32)
+    # gscale 60: many contributions at or above 128 in magnitude (the accumulate pass converts those on its integer path,
+    # smaller ones through the float pipeline); 2e-6: fp16 subnormals
+    g = (np.random.default_rng(2).standard_normal((L, B, C)) * gscale).astype(np.float32)
     gh = O.to_f16_bits(g)
     ge = torch.zeros(table.shape, device=DEV, dtype=torch.half)
     G.grid_encode_backward(half_from_bits(gh), T(x), T(table).half(), T(offsets), ge, B, 3, C, L, np.log2(pls), 16, None, None, 0, False, 0)
@@ -153,6 +155,37 @@ def test_grid_backward_fp16_exact_sum(O, B):
     assert torch.equal(ge, ge2)                    # every level: exact sums, rounded once, independent of any order
     err = np.abs(N(ge) - ref32)
     assert err.max() < 2e-3 * np.abs(ref32).max() + 1e-6        # one fp16 rounding of the sum (+ per-contribution rounding)
+
+
+@pytest.mark.parametrize("B", [50000, 4099])
+def test_grid_backward_fp16_bit_exact_on_lattice_points(O, B):
+    """samples ON the vertices of a level whose scale is a power of two (resolution 17 -> scale 16, x = (k + 0.5) / 16):
+    the interpolation weights are exactly 1 and 0, so every queue item is one of the fp16 gradients itself and the table
+    entry must be RN_half(exact sum) BIT for bit.  The gradients mix subnormals, ordinary values, values at or above 128
+    (the accumulate pass's integer path) and zeros; the expectation is computed in integers (value * 2^24)."""
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, _, table, _ = grid_case(O, L=2, base=17, desired=34, B=8)
+    offsets, table, pls = offsets[:2].copy(), table[:offsets[1]], 1.0      # the first level alone: resolution 17, scale 16
+    rng = np.random.default_rng(7)
+    k = rng.integers(0, 16, (B, 3))
+    x = ((k + 0.5) / 16.0).astype(np.float32)
+    assert np.array_equal(x.astype(np.float64) * 16 + 0.5, k + 1.0)
+    kinds = rng.integers(0, 4, (1, B, 2))
+    mag = np.where(kinds == 0, 3e-6, np.where(kinds == 1, 0.05, np.where(kinds == 2, 700.0, 0.0)))
+    gh = (rng.standard_normal((1, B, 2)) * mag).astype(np.float16)
+    ge = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    G.grid_encode_backward(T(gh), T(x), T(table).half(), T(offsets), ge, B, 3, 2, 1, np.log2(pls), 17, None, None, 0, False, 0)
+    stride = 18                                                      # (resolution + 1) vertices per axis, x fastest (gridencoder.cu:66-84)
+    idx = (k[:, 0] + 1) + (k[:, 1] + 1) * stride + (k[:, 2] + 1) * stride * stride
+    fix = np.round(gh[0].astype(np.float64) * 2.0 ** 24).astype(np.int64)
+    assert np.array_equal(fix / 2.0 ** 24, gh[0].astype(np.float64))   # every fp16 value is a multiple of 2^-24
+    acc = np.zeros((table.shape[0], 2), dtype=np.int64)
+    np.add.at(acc, idx, fix)
+    want = (acc.astype(np.float64) / 2.0 ** 24).astype(np.float16)    # one rounding, ties to even
+    got_bits, want_bits = bits_from_half(ge), want.view(np.uint16)
+    zero = ((got_bits & 0x7fff) == 0) & ((want_bits & 0x7fff) == 0)               # +0 and -0 are the same gradient
+    assert np.array_equal(np.where(zero, 0, got_bits), np.where(zero, 0, want_bits))
+    assert (np.abs(want.astype(np.float64)) >= 128).any() and (np.abs(fix) < 1024).any()    # both conversion paths and subnormals were in play
 
 
 def test_grid_backward_fp16(O):
