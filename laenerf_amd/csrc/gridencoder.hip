@@ -509,11 +509,15 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
     return __builtin_bit_cast(uint32_t, h);
 }
 
-template <typename T, bool FILL>
+// PLAIN: linear interpolation, align_corners = false, hash grid type (every shipped config) as compile-time facts -- the pass
+// is bound by its instruction count
+template <typename T, bool FILL, bool PLAIN>
 __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
-    uint32_t L, LevelScales sc, uint32_t gridtype, bool align_corners, uint32_t interp, uint32_t U, BwdPlan plan,
+    uint32_t L, LevelScales sc, uint32_t gridtype_, bool align_corners_, uint32_t interp_, uint32_t U, BwdPlan plan,
     typename BVal<T>::type* __restrict__ qvals, uint16_t* __restrict__ qkeys) {
+    const uint32_t gridtype = PLAIN ? 0u : gridtype_, interp = PLAIN ? 0u : interp_;
+    const bool align_corners = PLAIN ? false : align_corners_;
     using V = typename BVal<T>::type;
     const uint32_t NBLK = U / SEGS;                           // U is a multiple of SEGS
     const uint32_t level = blockIdx.x / NBLK, chunk = blockIdx.x % NBLK;
@@ -1459,7 +1463,10 @@ static inline size_t bwd_exec_ws_bytes(uint32_t B, uint32_t L) {
 template <typename T>
 static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t L, const BwdArgs& a, const BwdPlan& plan) {
     const uint32_t U = bwd_units(B);
-    k_bwd_walk<T, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
+    if (a.gridtype == 0 && !a.align && a.interp == 0)
+        k_bwd_walk<T, false, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
+    else
+        k_bwd_walk<T, false, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
     k_bwd_scan_units<<<lae::cdiv((size_t)L * BK_MAX, 4), 256, 0, a.stream>>>(offsets, L, U, plan);
     k_bwd_scan_parts<<<1, 1024, 0, a.stream>>>(L * BK_MAX, plan);
 }
@@ -1498,7 +1505,10 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     const T* g = (const T*)gT;
     T* ge = (T*)gemb;
     if (!caller_plan) bwd_plan<T>(inputs, offsets, B, L, a, plan);
-    k_bwd_walk<T, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
+    if (a.gridtype == 0 && !a.align && a.interp == 0)
+        k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
+    else
+        k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
     k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
