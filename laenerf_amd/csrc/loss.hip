@@ -18,10 +18,23 @@ __global__ __launch_bounds__(1024) void k_mse_fwd(const float* __restrict__ pred
     const float s = scale ? scale[0] : 1.0f;
     const float gk = 2.0f / (float)n;
     float acc = 0.0f;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const float d = pred[i] - target[i];
-        acc = fmaf(d, d, acc);
-        grad[i] = (d * gk) * s;
+    // rounds of 4 elements per thread, every load of a round in flight before the first is used (one workgroup: the
+    // kernel's time is its chain of memory latencies, 12 of them with one element per thread and round)
+    constexpr uint32_t PER = 4;
+    for (uint32_t base = 0; base < n; base += 1024 * PER) {
+        float p[PER], t[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = base + k * 1024 + threadIdx.x;
+            p[k] = i < n ? pred[i] : 0.0f; t[k] = i < n ? target[i] : 0.0f;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = base + k * 1024 + threadIdx.x;
+            const float d = p[k] - t[k];
+            acc = fmaf(d, d, acc);
+            if (i < n) grad[i] = (d * gk) * s;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
