@@ -485,7 +485,9 @@ constexpr int FILL_THREADS = 256;
 constexpr int SPT = 4;                                         // consecutive samples per lane and segment
 constexpr int SEGS = 1;                                        // segments per block: a lane walks SPT * SEGS consecutive samples
 constexpr uint32_t UNIT_SAMPLES = FILL_THREADS * SPT;          // 512
-constexpr uint32_t STAGE_CAP = 4096;                           // items staged in LDS (all of a unit unless corner pairs split)
+constexpr uint32_t STAGE_CAP = 4096 + 256;                     // items staged in LDS: a fine level's unit is 1024 cells x 4 pair rows = 4096 items
+                                                               // PLUS 4 for every cell whose x-neighbour lies in the next partition (1 cell in 4096);
+                                                               // with a cap of exactly 4096, 22 % of the fine levels' units took the unstaged path
 constexpr uint32_t KEY_SINGLE = 15u;                           // key code: 0..11 -> e1 = e0 ^ ((2 << code) - 1) (e0 + 1 is such an xor too: the trailing ones of e0 and the zero above them flip)
 constexpr int ACC_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
@@ -680,7 +682,11 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 Rows r;
                 cell_rows(cpg, r);
 #pragma unroll
-                for (int yz = 0; yz < 4; yz++) { atomicAdd(&hist[r.c0[yz]], 1u); if (!r.pair[yz]) atomicAdd(&hist[r.c1[yz]], 1u); }
+                for (int yz = 0; yz < 4; yz++) atomicAdd(&hist[r.c0[yz]], 1u);
+                if (!(r.pair[0] && r.pair[1] && r.pair[2] && r.pair[3])) {
+#pragma unroll
+                    for (int yz = 0; yz < 4; yz++) if (!r.pair[yz]) atomicAdd(&hist[r.c1[yz]], 1u);
+                }
             };
 #pragma unroll
             for (int s_ = 0; s_ < SPT; s_++) {
@@ -724,8 +730,12 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 uint32_t sl0[4], sl1[4];
 #pragma unroll
                 for (int yz = 0; yz < 4; yz++) sl0[yz] = atomicAdd(&hist[r.c0[yz]], 1u);
+                // four pair rows is the common cell: one test instead of a divergent branch per row and phase
+                const bool all_pairs = r.pair[0] && r.pair[1] && r.pair[2] && r.pair[3];
+                if (!all_pairs) {
 #pragma unroll
-                for (int yz = 0; yz < 4; yz++) sl1[yz] = r.pair[yz] ? 0u : atomicAdd(&hist[r.c1[yz]], 1u);
+                    for (int yz = 0; yz < 4; yz++) sl1[yz] = r.pair[yz] ? 0u : atomicAdd(&hist[r.c1[yz]], 1u);
+                }
                 auto put = [&](uint32_t slot, uint32_t ci, uint32_t key, int c, bool pair) {
                     V val;
                     if constexpr (sizeof(T) == 2) { val.x = pack_half2(a0[c], a1[c]); val.y = pair ? pack_half2(a0[c + 1], a1[c + 1]) : 0u; }
@@ -736,10 +746,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                         qvals[dst] = val; qkeys[dst] = (uint16_t)key;
                     }
                 };
+                if (all_pairs) {
 #pragma unroll
-                for (int yz = 0; yz < 4; yz++) {
-                    put(sl0[yz], r.c0[yz], r.k0[yz], 2 * yz, r.pair[yz]);
-                    if (!r.pair[yz]) put(sl1[yz], r.c1[yz], r.k1[yz], 2 * yz + 1, false);
+                    for (int yz = 0; yz < 4; yz++) put(sl0[yz], r.c0[yz], r.k0[yz], 2 * yz, true);
+                } else {
+#pragma unroll
+                    for (int yz = 0; yz < 4; yz++) {
+                        put(sl0[yz], r.c0[yz], r.k0[yz], 2 * yz, r.pair[yz]);
+                        if (!r.pair[yz]) put(sl1[yz], r.c1[yz], r.k1[yz], 2 * yz + 1, false);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
