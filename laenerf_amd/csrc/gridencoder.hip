@@ -906,15 +906,15 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
             // i.e. |value| >= 128 or non-finite; below that the cheap conversion is exact (gradients that large are rare)
             const uint32_t carry = (((w0 & 0x7c007c00u) + 0x28002800u) | ((w1 & 0x7c007c00u) + 0x28002800u)) & 0x80008000u;
             if (carry == 0) {
+                // branch-free: a single-corner item (1 in ~4096) carries zeros in its second word, which are added to e0 again
                 long long a, b;
                 half2_to_fix24_small(w0, a, b);
                 atomicAdd(&acc64[e0], (unsigned long long)a);
                 atomicAdd(&acc64[PART + e0], (unsigned long long)b);
-                if (code != KEY_SINGLE) {
-                    half2_to_fix24_small(w1, a, b);
-                    atomicAdd(&acc64[e1], (unsigned long long)a);
-                    atomicAdd(&acc64[PART + e1], (unsigned long long)b);
-                }
+                const uint32_t e1s = code != KEY_SINGLE ? e1 : e0;
+                half2_to_fix24_small(w1, a, b);
+                atomicAdd(&acc64[e1s], (unsigned long long)a);
+                atomicAdd(&acc64[PART + e1s], (unsigned long long)b);
             } else {
                 if (half_nonfinite(w0) || half_nonfinite(w0 >> 16)) atomicOr(&poison[e0 >> 5], 1u << (e0 & 31));
                 else {
