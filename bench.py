@@ -614,8 +614,12 @@ def main():
                 return n_graph_samples[b]
             for p_ in range(P):
                 ev_main[p_].record(main)
-            first = ((n_warm + G - 1) // G) * G - 2 * G      # whole groups, ending right before the first timed step
-            n_warm = first + 2 * G
+            # whole groups, ending right before the first timed step.  Six groups of replays (48 steps, ~20 ms): on a fresh
+            # box the first ~10 ms of back-to-back replays run slower than the rest (first window 0.420 ms against 0.408 for
+            # the next four, profiles/r2c_bench_line.json), and K = 20 timed steps are only 8 ms
+            WARM_GROUPS = 6
+            first = ((n_warm + G - 1) // G) * G - 2 * G
+            n_warm = first + WARM_GROUPS * G
             for i in range(first, n_warm):
                 step(i)
             torch.cuda.synchronize()
