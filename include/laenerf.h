@@ -294,7 +294,9 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
  * forward pass) and hand the result to the second half, which needs the gradients.  plan:
  * lae_grid_backward_plan_bytes(B, L) bytes of device memory owned by the caller, read-only for `_planned` except for its
  * work-queue words, which every execution resets itself (a plan serves any number of executions, one at a time).
- * grad is level-major [L, B, 2] (the layout of lae_grid_encode_backward). */
+ * grad is level-major [L, B, 2] (the layout of lae_grid_encode_backward).  B <= 2^24 samples and L <= 32 (LAE_EINVAL beyond:
+ * the kernels address the batch with 32-bit byte offsets); lae_grid_encode_backward itself takes any B and falls back to its
+ * global-atomic kernel above that size. */
 LAE_API uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L);
 LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                   float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,

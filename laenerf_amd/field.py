@@ -89,6 +89,8 @@ def field_backward_plan(x, enc, bound=1):
     """counting half of the hash-grid backward for the samples x [M,3] (fp16 table path): depends on the positions
     only, so it can be launched right after the march, on another stream, beside the forward pass"""
     x = x.float().contiguous()
+    if x.shape[0] > (1 << 24):          # beyond the binned pipeline's batch limit (include/laenerf.h): no plan, the backward
+        return None                     # then runs whole on the generic path
     in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
     return _grid.grid_backward_plan(x, enc.offsets, x.shape[0], 3, 2, enc.num_levels, np.log2(enc.per_level_scale), enc.base_resolution,
                                     enc.gridtype_id, enc.align_corners, enc.interp_id, True, in_map)
