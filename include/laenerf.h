@@ -286,7 +286,12 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                const int32_t* offsets_host, void* stream);
+                                const int32_t* offsets_host, int32_t* nonfinite_flag, void* stream);
+/* nonfinite_flag (may be NULL): device word that is OR-ed with 1 when this call STORES a non-finite value into
+ * grad_embeddings (an overflowed sum, a non-finite contribution, or a non-finite value already there that it adds to).  A
+ * caller whose gradient buffer is written by these calls only can hand the optimizer's found_inf word (state word 2 of
+ * lae_adam_*) and leave the table out of lae_adam_check.  Needs the binned pipeline on every level: D = 3, C = 2,
+ * offsets_host given, every level <= 2^21 entries, B <= 2^24 (LAE_EINVAL otherwise). */
 
 /* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- the bookkeeping of a counting
  * sort: items per (level, 1024 samples, table partition), their scans -- depends on the sample positions only,
@@ -304,7 +309,7 @@ LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* of
 LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                     const int32_t* offsets_host, const void* plan, void* stream);
+                                     const int32_t* offsets_host, const void* plan, int32_t* nonfinite_flag, void* stream);
 
 /* Bytes of LIBRARY workspace the binned backward (D = 3, C = 2) takes for B samples and L levels when it runs both halves
  * itself: the plan + the item queue, sized for the worst case of 8 items per (sample, level) at 10 bytes each for fp16

@@ -45,11 +45,11 @@ SIGNATURES = {
     "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
     "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
     "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp],
+    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp, vp],
     "lae_grid_backward_workspace_bytes": [u32, u32, i32],
     "lae_grid_backward_plan_bytes": [u32, u32],
     "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp],
+    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grid_set_forward_mode": [i32],
     "lae_grid_forward_schedule": [vp, u32, f32, u32, u32, vp, vp],

@@ -876,7 +876,7 @@ template <typename T>
 __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
     bool align_corners, BwdPlan plan, const typename BVal<T>::type* __restrict__ qvals, const uint16_t* __restrict__ qkeys,
-    unsigned long long* __restrict__ partials) {
+    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag) {
     using V = typename BVal<T>::type;
     constexpr bool HALF = sizeof(T) == 2;
     constexpr uint32_t ACCW = HALF ? 2 * PART : PART;
@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         }
         if constexpr (HALF) {
             uint32_t* d2 = reinterpret_cast<uint32_t*>(dst);
+            bool wrote_nonfinite = false;
             // the old values of the lane's entries first, all in flight together (a load per touched entry inside the loop
             // below made every round wait for its own memory latency)
 #pragma unroll
@@ -1110,7 +1111,11 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                     r1 = half_nonfinite(o >> 16) ? (o >> 16) : fix24_to_half(i1 + half_to_fix24(o >> 16));
                 }
                 d2[e] = r0 | (r1 << 16);
+                wrote_nonfinite |= half_nonfinite(r0) || half_nonfinite(r1);
             }
+            // every non-finite value in the table gradient was stored by a flush like this one: the caller's flag (the
+            // optimizer's found_inf word) makes a scan of the 12 M-entry gradient for non-finite values unnecessary
+            if (nf_flag && wrote_nonfinite) atomicOr(nf_flag, 1);
         } else {
             const float* af = reinterpret_cast<const float*>(acc64);
             float2* d2 = reinterpret_cast<float2*>(dst);
@@ -1118,6 +1123,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 const float v0 = af[e], v1 = af[PART + e];
                 if (v0 == 0.0f && v1 == 0.0f) continue;
                 float2 o = d2[e]; o.x += v0; o.y += v1; d2[e] = o;
+                if (nf_flag && !(isfinite(o.x) && isfinite(o.y))) atomicOr(nf_flag, 1);
             }
         }
         __syncthreads();
@@ -1359,6 +1365,7 @@ struct BwdArgs {
     const void* grad; const float* inputs; const int32_t* offsets; void* gemb; uint32_t B, L; LevelScales sc;
     uint32_t gridtype; bool align; uint32_t interp; uint64_t gs_b, gs_l; hipStream_t stream;
     const int32_t* offsets_host = nullptr;
+    int32_t* nf_flag = nullptr;                                 // set to 1 when a non-finite table gradient is stored (binned path)
 };
 template <typename T, int D, int C>
 static void launch_bwd(const BwdArgs& a) {
@@ -1524,7 +1531,7 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
         k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
     else
         k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
-    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials);
+    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
     // (its blocks return at once for the levels the binned path has handled).
@@ -1549,14 +1556,22 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                          const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
                          int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f,
-                         const int32_t* offsets_host = nullptr, const void* plan = nullptr) {
+                         const int32_t* offsets_host = nullptr, const void* plan = nullptr, int32_t* nf_flag = nullptr) {
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
     if (plan && !(D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
+    if (nf_flag) {
+        // only the binned pipeline knows what it stores (the generic kernel's float atomics do not): every level must go
+        // through it, which the host copy of the level sizes proves
+        if (!(D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !g_force_atomic_bwd) || !offsets_host) return LAE_EINVAL;
+        for (uint32_t l = 0; l < L; l++)
+            if (!level_is_binned((uint32_t)(offsets_host[l + 1] - offsets_host[l]))) return LAE_EINVAL;
+    }
     BwdArgs a;
     a.offsets_host = offsets_host;
+    a.nf_flag = nf_flag;
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1659,9 +1674,10 @@ int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                const int32_t* offsets_host, void* stream) {
+                                const int32_t* offsets_host, int32_t* nonfinite_flag, void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
-                         gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale, offsets_host);
+                         gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale, offsets_host, nullptr,
+                         nonfinite_flag);
 }
 
 uint64_t lae_grid_backward_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
@@ -1692,10 +1708,10 @@ int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, u
 int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                      uint32_t interp, int dtype, float in_shift, float in_scale, const int32_t* offsets_host,
-                                     const void* plan, void* stream) {
+                                     const void* plan, int32_t* nonfinite_flag, void* stream) {
     if (!plan) return LAE_ENULL;
     return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
-                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan);
+                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan, nonfinite_flag);
 }
 
 int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks, uint32_t* nseg_out,

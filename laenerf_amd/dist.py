@@ -166,6 +166,8 @@ def allreduce_gradients(optimizer, world_size=None, group=None):
         if shadow is not None:
             if p.grad is not None:                           # folded into the accumulator, like FusedAdam._grad does
                 shadow.grad_half.add_(p.grad.to(torch.half)); p.grad = None
+            if hasattr(shadow, "unreported"):
+                shadow.unreported = True                     # the reduced sum may overflow: the optimizer scans the table again
             grads.append(shadow.grad_half)
         elif p.grad is not None:
             grads.append(p.grad)

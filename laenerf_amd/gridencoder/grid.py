@@ -61,9 +61,12 @@ class _grid_encode(Function):
         # optimizer after it has consumed it) and autograd sees no gradient for `embeddings`
         grad_embeddings = ctx.shadow.grad_half if ctx.shadow is not None else torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
+        flag = ctx.shadow.flag_for_backward(B) if ctx.shadow is not None and D == 3 and C == 2 else None
+        if ctx.shadow is not None and flag is None:
+            ctx.shadow.unreported = True
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
                                       grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True, in_map=ctx.in_map,
-                                      offsets_host=ctx.offsets_host)
+                                      offsets_host=ctx.offsets_host, nonfinite_flag=flag)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
             if ctx.in_map[1] != 1.0:
@@ -80,6 +83,19 @@ class TableShadow:
         self.half = embeddings.detach().to(torch.half).contiguous()
         self.grad_half = torch.zeros_like(self.half)
         self.version = embeddings._version
+        # FusedAdam's found_inf word (device address) once the optimizer has adopted the table and every level goes through
+        # the binned backward: that backward then reports the non-finite values it stores itself, and the optimizer leaves
+        # the table out of its scan (optim.FusedAdam.step).  `unreported` = grad_half was written by something that does
+        # not report (a folded .grad, a gradient all-reduce): the next step scans it again.
+        self.nonfinite_flag = None
+        self.unreported = False
+
+    def flag_for_backward(self, n_samples=0):
+        """address to hand to grid_encode_backward(nonfinite_flag=...), or None (then the write counts as unreported)"""
+        if self.nonfinite_flag is None or n_samples > (1 << 24):     # beyond the binned pipeline's batch limit
+            self.unreported = True
+            return None
+        return self.nonfinite_flag
 
     def table_half(self, embeddings):
         if embeddings._version != self.version:        # someone else wrote the fp32 table (load_state_dict, init, ...)

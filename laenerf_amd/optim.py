@@ -57,6 +57,15 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: no parameter to optimise")
         # device state block (include/laenerf.h): scale | tracker | found_inf | skip | step | 1/bc1 | sqrt(bc2) | 1/scale | skipped
         self.dev_state = torch.zeros(16, dtype=torch.int32, device=dev)
+        # hash-grid tables whose every level goes through the binned backward: that backward ORs found_inf (state word 2)
+        # itself whenever it stores a non-finite gradient, so step() leaves them out of its scan (24.5 MB per step for the
+        # 12 M-entry table) unless something else wrote their accumulator since (TableShadow.unreported)
+        if self.use_scaler:
+            for p, _, _, shadow, _ in self.items:
+                owner = tables.get(id(p))
+                if shadow is not None and isinstance(owner, GridEncoder) and owner.input_dim == 3 and owner.level_dim == 2 \
+                        and owner.num_levels <= 32 and int((owner.offsets_host[1:] - owner.offsets_host[:-1]).max()) <= (1 << 21):
+                    shadow.nonfinite_flag = self.dev_state.data_ptr() + 8
         self._scale_view = self.dev_state.view(torch.float32)
         self._scale_view[0] = init_scale if self.use_scaler else 1.0
         self._lr_host = [float(g["lr"]) for g in self.param_groups]
@@ -134,6 +143,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # module forward with autograd): fold that gradient into the accumulator
                 shadow.grad_half.add_(p.grad.to(torch.half))
                 p.grad = None
+                if hasattr(shadow, "unreported"):
+                    shadow.unreported = True             # this sum may overflow and nobody reports it: scan the table this step
             return shadow.grad_half, 1
         if p.grad is None:
             p.grad = torch.zeros_like(p)
@@ -167,12 +178,32 @@ class FusedAdam(torch.optim.Optimizer):
         lib, st, s = _lib.load(), self.dev_state.data_ptr(), _lib.stream()
         a = self._tables()
         if self.use_scaler:
-            _lib.check(lib.lae_adam_check_multi(a["n"], a["grads"], a["is_half"], a["sizes"], st, s), "adam_check")
+            c = self._check_tables(a)
+            if c["n"]:
+                _lib.check(lib.lae_adam_check_multi(c["n"], c["grads"], c["is_half"], c["sizes"], st, s), "adam_check")
         _lib.check(lib.lae_adam_begin(st, self.betas[0], self.betas[1], self.growth_interval, self.growth_factor,
                                       self.backoff_factor, int(self.use_scaler), s), "adam_begin")
         _lib.check(lib.lae_adam_apply_multi(a["n"], a["params"], a["m"], a["v"], a["grads"], a["is_half"], a["shadows"],
                                             a["sizes"], a["lrs"], st, self.betas[0], self.betas[1], self.eps,
                                             self.weight_decay, s), "adam_apply")
+        for *_, shadow, _ in self.items:                     # the accumulators are zero again
+            if shadow is not None and hasattr(shadow, "unreported"):
+                shadow.unreported = False
+
+    def _check_tables(self, a):
+        """the gradients step() scans for non-finite values: all of them, minus the tables whose backward reports into
+        found_inf itself (see __init__)"""
+        keep = tuple(not (sh is not None and getattr(sh, "nonfinite_flag", None) is not None and not sh.unreported)
+                     for _, _, _, sh, _ in self.items)
+        cached = a.get("check")
+        if cached is None or cached["keep"] != keep:
+            idx = [i for i, k in enumerate(keep) if k]
+            n = len(idx)
+            arr = (ctypes.c_void_p * max(n, 1))
+            cached = a["check"] = {"keep": keep, "n": n, "grads": arr(*[a["grads"][i] for i in idx]),
+                                   "is_half": (ctypes.c_int * max(n, 1))(*[a["is_half"][i] for i in idx]),
+                                   "sizes": (ctypes.c_uint64 * max(n, 1))(*[a["sizes"][i] for i in idx])}
+        return cached
 
     # ---- torch.optim.Adam-compatible checkpoints
     def state_dict(self):

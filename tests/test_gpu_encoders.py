@@ -188,6 +188,45 @@ def test_grid_backward_fp16_bit_exact_on_lattice_points(O, B):
     assert (np.abs(want.astype(np.float64)) >= 128).any() and (np.abs(fix) < 1024).any()    # both conversion paths and subnormals were in play
 
 
+def test_grid_backward_reports_stored_nonfinite_values(O):
+    """nonfinite_flag of the backward (include/laenerf.h): set when a non-finite gradient is STORED -- an inf contribution, a
+    sum that overflows fp16, a non-finite value already in the buffer that the call adds to -- and left alone otherwise;
+    refused (LAE_EINVAL) when a level is too large for the binned pipeline, which is the only one that can tell"""
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, pls, table, x = grid_case(O, B=20000)
+    B, L, C = 20000, 16, 2
+    oh = np.ascontiguousarray(offsets.astype(np.int32))
+    g = (np.random.default_rng(2).standard_normal((L, B, C)) * 1e-1).astype(np.float16)
+
+    def run(grad, ge=None, **kw):
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ge = torch.zeros(table.shape, device=DEV, dtype=torch.half) if ge is None else ge
+        G.grid_encode_backward(T(grad), T(x), T(table).half(), T(offsets), ge, B, 3, C, L, np.log2(pls), 16, None, None, 0, False, 0,
+                               offsets_host=oh, nonfinite_flag=flag.data_ptr(), **kw)
+        return int(flag.item()), ge
+
+    f, ge = run(g)
+    assert f == 0 and torch.isfinite(ge.float()).all()
+    bad = g.copy(); bad[11, 777, 1] = np.inf
+    f, ge = run(bad)
+    assert f == 1 and not torch.isfinite(ge.float()).all()
+    big = g.copy(); big[0] = 60000.0                                   # level 0: dozens of samples per entry -> the sum overflows
+    f, ge = run(big)
+    assert f == 1 and torch.isinf(ge.float()).any()
+    f, _ = run(g, ge=ge)                                               # adds on top of the overflowed buffer: still there -> reported
+    assert f == 1
+    plan = G.grid_backward_plan(T(x), T(offsets), B, 3, C, L, np.log2(pls), 16, 0, False, 0, True)
+    f, _ = run(bad, plan=plan)
+    assert f == 1
+    # a level with more than 2^21 entries goes through the generic atomic kernel: the flag cannot be promised
+    offsets2, pls2, table2, x2 = grid_case(O, L=4, T_log2=22, desired=4096, B=6000)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        G.grid_encode_backward(T(np.zeros((4, 6000, 2), np.float16)), T(x2), T(table2).half(), T(offsets2),
+                               torch.zeros(table2.shape, device=DEV, dtype=torch.half), 6000, 3, 2, 4, np.log2(pls2), 16, None, None, 0,
+                               False, 0, offsets_host=np.ascontiguousarray(offsets2.astype(np.int32)), nonfinite_flag=flag.data_ptr())
+
+
 def test_grid_backward_fp16(O):
     from laenerf_amd.backend import gridencoder_backend as G
     offsets, pls, table, x = grid_case(O, B=4000, L=8, T_log2=14, desired=512)

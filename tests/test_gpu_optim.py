@@ -40,6 +40,8 @@ def test_fused_adam_matches_torch_adam_and_gradscaler():
                 gh.view(-1)[17] = float("inf")
             if it % 2 == 0 or x is a.encoder.embeddings:
                 owner.shadow.grad_half.copy_(gh.view_as(owner.shadow.grad_half))
+                owner.shadow.unreported = True       # written behind the operators' back: nobody reported a non-finite value,
+                                                     # so the optimizer has to scan this accumulator (TableShadow contract)
             else:
                 x.grad = gh.float()                                              # gradient that arrived through plain autograd
             y.grad = gh.float()
@@ -89,6 +91,52 @@ def test_shadow_follows_external_writes_and_lr_schedule():
     fa.step()
     assert torch.equal(before, net.encoder.embeddings.detach()) and fa.steps_taken == 1       # lr 0: state moves, weights do not
     assert float(fa.items[0][1].abs().sum()) > 0
+
+
+def test_table_gradient_reports_nonfinite_values_itself():
+    """the hash-grid backward ORs the optimizer's found_inf word when it stores a non-finite table gradient, so step() scans
+    only the MLP gradients (no 24 MB read per step) -- and still skips the step, backs the scale off and zeroes everything
+    exactly like GradScaler when a gradient overflows; a gradient folded in from plain autograd puts the table back into the scan"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    bits = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(DEV)
+    o, d = S.lego_like_rays(512, seed=3)
+    o, d = torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV)
+    gt = torch.rand(512, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    net = small_net(2)
+    r = NeRFRenderer(net, bound=1).to(DEV)
+    r.density_bitfield = bits
+    net.train()
+    opt = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, init_scale=1024.0)
+    sh = net.encoder.shadow
+    assert sh.nonfinite_flag == opt.dev_state.data_ptr() + 8
+    before = None
+    for it in range(4):
+        with torch.autocast("cuda", dtype=torch.float16):
+            res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
+            loss = torch.nn.functional.mse_loss(res["image"], gt)
+        if it == 2:
+            loss = loss * float("inf")                     # every gradient of this step is inf / nan
+            before = [p.detach().clone() for p in net.parameters()]
+        opt.scale(loss).backward()
+        assert not sh.unreported                           # only the reporting backward wrote the accumulator
+        scanned = opt._check_tables(opt._tables())
+        assert scanned["n"] == len(opt.items) - 1          # the table is not scanned
+        if it == 2:
+            assert int(opt.dev_state[2].item()) == 1       # ... because its backward has reported already
+            assert not torch.isfinite(sh.grad_half.float()).all()
+        opt.step()
+        assert float(sh.grad_half.abs().sum()) == 0
+        if it == 2:
+            assert all(torch.equal(a_, b_.detach()) for a_, b_ in zip(before, net.parameters()))     # skipped: nothing moved
+    assert opt.steps_taken == 3 and opt.steps_skipped == 1 and opt.get_scale() == 512.0
+    # a gradient that reaches the table through plain autograd is folded in by the optimizer: scanned again, inf still caught
+    net.encoder.embeddings.grad = torch.zeros_like(net.encoder.embeddings)
+    net.encoder.embeddings.grad.view(-1)[5] = float("inf")
+    assert opt._check_tables(opt._tables())["n"] == len(opt.items) and sh.unreported
+    opt.step()
+    assert opt.steps_skipped == 2 and not sh.unreported
 
 
 def test_training_with_fused_adam_tracks_torch_path():
