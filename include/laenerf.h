@@ -397,11 +397,13 @@ LAE_API int lae_nerf_density_forward(const void* enc, const void* sigma_weights,
  * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).
  * grad_h is an [M,16] fp16 scratch (receives dL/dh).  Sigmoid and trunc_exp (activation.py:14-17) backward are fused.
  * accumulate_weight_grads != 0: grad_*_weights += dW (the fused optimizer's persistent buffers) instead of = dW.
- * enc_level_major != 0: enc AND grad_enc are [16, M, 2] (what lae_grid_encode_backward consumes directly). */
+ * enc_level_major != 0: enc AND grad_enc are [16, M, 2] (what lae_grid_encode_backward consumes directly).  nonfinite_flag (may be NULL): device word OR-ed with 1 when a non-finite WEIGHT gradient is stored (see
+ * lae_grid_encode_backward_ex). */
 LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream);
+                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major,
+                           int32_t* nonfinite_flag, void* stream);
 
 /* ---- freqencoder (freqencoder/src/freqencoder.h:6-10; bindings.cpp:5-8) ----
  * outputs [B, C], C = D + 2*D*deg: the input, then per frequency f < deg the D sines and D cosines of x * 2^f.

@@ -446,7 +446,8 @@ class _FFMLP:
 
     @staticmethod
     def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,
-                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights, accumulate=False, level_major=False):
+                           grad_h, grad_enc, grad_sigma_weights, grad_color_weights, accumulate=False, level_major=False,
+                           nonfinite_flag=None):
         ts = (grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, grad_h, grad_enc,
               grad_sigma_weights, grad_color_weights)
         need_cuda(*ts); need_contig(*ts)
@@ -455,7 +456,7 @@ class _FFMLP:
                                                  ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
                                                  ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
                                                  ptr(grad_color_weights), int(bool(accumulate)), int(bool(level_major)),
-                                                 stream()), "nerf_head_backward")
+                                                 nonfinite_flag, stream()), "nerf_head_backward")
 
     @staticmethod
     def ffmlp_set_mode(mode):

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MLP_BLOCK) void k_mlp_dw(
 // accumulate != 0: gw += sum (the optimizer's persistent gradient buffer) instead of gw = sum.
 constexpr int DWR_GROUPS = 16;
 __device__ __forceinline__ void dw_reduce_body(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW, half_t* __restrict__ gw,
-                                               int accumulate, uint32_t block) {
+                                               int accumulate, uint32_t block, int32_t* __restrict__ nf_flag = nullptr) {
     __shared__ float part[DWR_GROUPS][64];
     const uint32_t e = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const uint32_t i = block * 64 + e;
@@ -377,7 +377,10 @@ __device__ __forceinline__ void dw_reduce_body(const float* __restrict__ slabs, 
         for (int w = DWR_GROUPS / 2; w > 0; w >>= 1)
 #pragma unroll
             for (int u = 0; u < w; u++) t[u] = t[u] + t[u + w];
-        gw[i] = accumulate ? (half_t)((float)gw[i] + t[0]) : (half_t)t[0];
+        const half_t r = accumulate ? (half_t)((float)gw[i] + t[0]) : (half_t)t[0];
+        gw[i] = r;
+        // the caller's flag (the optimizer's found_inf word): a non-finite weight gradient is reported where it is stored
+        if (nf_flag && (__builtin_bit_cast(uint16_t, r) & 0x7c00u) == 0x7c00u) atomicOr(nf_flag, 1);
     }
 }
 __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
@@ -388,9 +391,9 @@ __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __re
 __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce2(const float* __restrict__ slabs_a, uint32_t n_a, uint32_t nW_a,
                                                                 half_t* __restrict__ gw_a, const float* __restrict__ slabs_b,
                                                                 uint32_t n_b, uint32_t nW_b, half_t* __restrict__ gw_b,
-                                                                uint32_t nb_a, int accumulate) {
-    if (blockIdx.x < nb_a) dw_reduce_body(slabs_a, n_a, nW_a, gw_a, accumulate, blockIdx.x);
-    else dw_reduce_body(slabs_b, n_b, nW_b, gw_b, accumulate, blockIdx.x - nb_a);
+                                                                uint32_t nb_a, int accumulate, int32_t* __restrict__ nf_flag) {
+    if (blockIdx.x < nb_a) dw_reduce_body(slabs_a, n_a, nW_a, gw_a, accumulate, blockIdx.x, nf_flag);
+    else dw_reduce_body(slabs_b, n_b, nW_b, gw_b, accumulate, blockIdx.x - nb_a, nf_flag);
 }
 
 // ---------------------------------------------------------------- fused NeRF head (network_ff.py:51-81 in one kernel)
@@ -1375,7 +1378,8 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
 int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
-                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, void* stream) {
+                           void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, int32_t* nonfinite_flag,
+                           void* stream) {
     if (!grad_sigma_weights || !grad_color_weights) return LAE_ENULL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {                                        // no samples: zero weight gradients (like the reference's GEMMs on empty batches)
@@ -1404,7 +1408,7 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
     if (rc != LAE_OK) return rc;
     const uint32_t nb_c = lae::cdiv(nW_c, 64u), nb_s = lae::cdiv(nW_s, 64u);
     k_dw_reduce2<<<nb_c + nb_s, 64 * DWR_GROUPS, 0, s>>>(ws, n_c, nW_c, (half_t*)grad_color_weights, ws_s, n_s, nW_s,
-                                                        (half_t*)grad_sigma_weights, nb_c, accumulate_weight_grads);
+                                                        (half_t*)grad_sigma_weights, nb_c, accumulate_weight_grads, nonfinite_flag);
     return lae::check_launch("nerf_head_backward");
 }
 

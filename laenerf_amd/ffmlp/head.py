@@ -55,8 +55,13 @@ class _nerf_head(Function):
         grad_h = torch.empty_like(h)
         grad_enc = torch.empty_like(enc) if ctx.need_enc_grad else None
         if ctx.shadows is not None:
+            a, b = ctx.shadows[0].flag_for_backward(), ctx.shadows[1].flag_for_backward()    # the optimizer's found_inf word
+            flag = a if a is not None and a == b else None
+            if flag is None:
+                ctx.shadows[0].unreported = ctx.shadows[1].unreported = True
             _backend.nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h,
-                                        grad_enc, ctx.shadows[0].grad_half, ctx.shadows[1].grad_half, accumulate=True)
+                                        grad_enc, ctx.shadows[0].grad_half, ctx.shadows[1].grad_half, accumulate=True,
+                                        nonfinite_flag=flag)
             return grad_enc, None, None, None, None, None, None
         gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
         _backend.nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h,

@@ -55,12 +55,14 @@ class _nerf_field(Function):
         grad_rgbs = grad_rgbs.float().contiguous()
         grad_h = torch.empty_like(h)
         grad_feats = torch.empty_like(feats)                                              # level-major, like feats
+        wflag = None
         if ctx.shadows is not None:
             gws, gwc = ctx.shadows[0].grad_half, ctx.shadows[1].grad_half
+            wflag = _weights_flag(ctx.shadows)
         else:
             gws, gwc = torch.empty_like(ws), torch.empty_like(wc)
         _mlp.nerf_head_backward(grad_sigmas, grad_rgbs, feats, dirs, h, rgbs, ws, wc, M, ctx.density_scale, grad_h, grad_feats,
-                                gws, gwc, accumulate=ctx.shadows is not None, level_major=True)
+                                gws, gwc, accumulate=ctx.shadows is not None, level_major=True, nonfinite_flag=wflag)
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         flag = enc.shadow.flag_for_backward(M) if enc.shadow is not None else None    # the optimizer's found_inf word, or None
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
@@ -69,6 +71,16 @@ class _nerf_field(Function):
         return (None, None, None if enc.shadow is not None else grad_table,
                 None if ctx.shadows is not None else gws.to(ctx.wdtypes[0]),
                 None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None, None)
+
+
+def _weights_flag(shadows):
+    """one flag for the two weight accumulators the head backward writes: the optimizer's found_inf word if both shadows
+    carry the same one, else None (and both writes count as unreported)"""
+    a, b = shadows[0].flag_for_backward(), shadows[1].flag_for_backward()
+    if a is not None and a == b:
+        return a
+    shadows[0].unreported = shadows[1].unreported = True
+    return None
 
 
 def field_supported(enc, sigma_net, color_net):

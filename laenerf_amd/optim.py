@@ -66,6 +66,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if shadow is not None and isinstance(owner, GridEncoder) and owner.input_dim == 3 and owner.level_dim == 2 \
                         and owner.num_levels <= 32 and int((owner.offsets_host[1:] - owner.offsets_host[:-1]).max()) <= (1 << 21):
                     shadow.nonfinite_flag = self.dev_state.data_ptr() + 8
+                elif shadow is not None and isinstance(owner, FFMLP):
+                    shadow.nonfinite_flag = self.dev_state.data_ptr() + 8    # the fused head backward reports its weight gradients
         self._scale_view = self.dev_state.view(torch.float32)
         self._scale_view[0] = init_scale if self.use_scaler else 1.0
         self._lr_host = [float(g["lr"]) for g in self.param_groups]
