@@ -616,7 +616,7 @@ def main():
                 ev_main[p_].record(main)
             # whole groups, ending right before the first timed step.  Six groups of replays (48 steps, ~20 ms): on a fresh
             # box the first ~10 ms of back-to-back replays run slower than the rest (first window 0.420 ms against 0.408 for
-            # the next four, profiles/r2c_bench_line.json), and K = 20 timed steps are only 8 ms
+            # the next four with two groups), and K = 20 timed steps are only 8 ms
             WARM_GROUPS = 6
             first = ((n_warm + G - 1) // G) * G - 2 * G
             n_warm = first + WARM_GROUPS * G
