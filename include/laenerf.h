@@ -151,6 +151,18 @@ LAE_API int lae_composite_rays_train_forward_blend(const float* sigmas, const fl
                                            uint32_t M, uint32_t N, float T_thresh, const float* nears, const float* fars,
                                            const float* bg_rays, float bg_r, float bg_g, float bg_b, float* weights_sum,
                                            float* depth, float* image, float* depth_out, float* image_out, void* stream);
+/* MI355X-native: lae_composite_rays_train_forward_blend + lae_mse_loss_forward (target [N,3], scale as there) +
+ * lae_composite_rays_train_backward_blend (grad_weights_sum = NULL, upstream gradient 1) as ONE launch -- d loss / d pixel of a
+ * ray needs that ray's pixel only -- plus a one-block launch that adds the workgroups' squared-error sums in a fixed order into
+ * loss_out[0] = MSE * scale, loss_out[1] = MSE.  Same arithmetic as the three calls.  grad_image [N,3], grad_sigmas [M],
+ * grad_rgbs [M,3] are outputs (every row written); partials: cdiv(N, 4) floats of scratch. */
+LAE_API int lae_composite_rays_train_step(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
+                                  uint32_t N, float T_thresh, const float* nears, const float* fars, const float* bg_rays, float bg_r,
+                                  float bg_g, float bg_b, const uint32_t* rows_end, const float* target, const float* scale,
+                                  float* weights_sum, float* depth, float* image, float* depth_out, float* image_out,
+                                  float* grad_image, float* grad_sigmas, float* grad_rgbs, float* loss_out, float* partials,
+                                  void* stream);
+
 /* Backward of the above w.r.t. (weights_sum, image_out): grad_ws_eff = grad_ws - sum_c grad_image_c * bg_c.  Writes EVERY
  * row of grad_sigmas / grad_rgbs in [0, M) (zeros after the early stop and in [rows_end, M)), so they need no
  * pre-zeroing; requires the contiguous ray-id-order sample layout of lae_march_rays_train. */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "lae_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, vp],
     "lae_composite_rays_train_forward_blend": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays_train_step": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_composite_rays_train_backward_blend": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, f32, f32, f32, vp, vp, vp, vp],
     "lae_composite_rays_train_backward_blend_ex": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, f32, f32, f32, vp, vp, vp, vp, vp],
     "lae_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -168,6 +168,23 @@ class _RayMarching:
             "composite_rays_train_forward_blend")
 
     @staticmethod
+    def composite_rays_train_step(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears, fars, bg_rays, bg, rows_end, target, scale,
+                                  weights_sum, depth, image, depth_out, image_out, grad_image, grad_sigmas, grad_rgbs, loss_out,
+                                  partials):
+        """MI355X extension: compositing forward (+ blend) + MSE criterion + compositing backward in one launch"""
+        ts = (sigmas, rgbs, deltas, rays, nears, fars, bg_rays, rows_end, target, scale, weights_sum, depth, image, depth_out,
+              image_out, grad_image, grad_sigmas, grad_rgbs, loss_out, partials)
+        need_cuda(*ts); need_contig(*ts)
+        _need_f32(sigmas, rgbs, deltas, nears, fars, bg_rays, target, scale, weights_sum, depth, image, depth_out, image_out,
+                  grad_image, grad_sigmas, grad_rgbs, loss_out, partials)
+        if partials.numel() < (N + 3) // 4:
+            raise RuntimeError("composite_rays_train_step: partials needs cdiv(N, 4) floats")
+        check(_lib.load().lae_composite_rays_train_step(
+            ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh, ptr(nears), ptr(fars), ptr(bg_rays), bg[0], bg[1], bg[2],
+            ptr(rows_end), ptr(target), ptr(scale), ptr(weights_sum), ptr(depth), ptr(image), ptr(depth_out), ptr(image_out),
+            ptr(grad_image), ptr(grad_sigmas), ptr(grad_rgbs), ptr(loss_out), ptr(partials), stream()), "composite_rays_train_step")
+
+    @staticmethod
     def composite_rays_train_backward_blend(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M,
                                             N, T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs, grad_scale=None):
         """grad_scale (MI355X extension): device scalar multiplied into the incoming gradients; grad_weights_sum may be None"""

@@ -645,6 +645,156 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
     }
 }
 
+// ---------------------------------------------------------------- K7 + criterion + K8 in one launch (training step)
+// composite_rays_train forward with the BLEND epilogue, the trainer's MSE criterion (d loss / d pixel needs this ray's
+// pixel only) and composite_rays_train backward (DENSE), one wavefront per ray: the three launches of the step's middle
+// (11.8 + 5.6 + 11 us and two kernel boundaries) become one.  Arithmetic is that of k_composite_train_fwd<true>,
+// k_mse_fwd and k_composite_train_bwd<true> (grad_scale = 1), statement for statement.  The loss VALUE needs all rays:
+// every workgroup leaves the sum of its rays' squared errors in partials[blockIdx.x], k_loss_finish adds them in a fixed
+// order (deterministic).
+struct StepLoss { const float* target; const float* scale; float* grad_image; float* partials; };
+
+__global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+    const int32_t* __restrict__ rays, uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum,
+    float* __restrict__ depth, float* __restrict__ image, Blend bl, StepLoss sl, const uint32_t* __restrict__ rows_end_p,
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    __shared__ float s_sq[COMP_WAVES];
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = blockIdx.x * COMP_WAVES + wv;                      // one ray per wave: scalar
+    const int lane = threadIdx.x & 63;
+    float sq = 0.0f;
+    if (n < N) {
+        const uint32_t rows_end = rows_end_p[0];
+        zero_tail_rows(rows_end, M, n, N, lane, grad_sigmas, 1);
+        zero_tail_rows(rows_end, M, n, N, lane, grad_rgbs, 3);
+        const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1];
+        const uint32_t num_steps = (uint32_t)rays[3 * (size_t)n + 2];
+        const bool has = !(num_steps == 0 || offset + num_steps > M);
+        // ---- forward (k_composite_train_fwd<true>)
+        float r = 0, g = 0, b = 0, ws = 0, d = 0;
+        if (has) {
+            float T = 1.0f, t = 0.0f;
+            for (uint32_t base = 0; base < num_steps; base += 64) {
+                const uint32_t k = base + lane;
+                bool valid = k < num_steps;
+                float alpha = 0.f, d1 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                if (valid) {
+                    const size_t i = (size_t)offset + k;
+                    alpha = 1.0f - __expf(-sigmas[i] * deltas[2 * i]);
+                    d1 = deltas[2 * i + 1];
+                    c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+                }
+                const float incl = wave_scan_mul(1.0f - alpha, lane);
+                float excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float T_post = T * incl;
+                const unsigned long long stop = __ballot(valid && T_post < T_thresh);
+                bool done = false;
+                if (stop) { const int last = __builtin_ctzll(stop); valid = valid && lane <= last; done = true; }
+                const float w = valid ? alpha * (T * excl) : 0.0f;
+                const float tk = t + wave_scan_add(d1, lane);
+                r += wave_sum(w * c0); g += wave_sum(w * c1); b += wave_sum(w * c2);
+                d += wave_sum(w * tk); ws += wave_sum(w);
+                if (done) break;
+                T *= __shfl(incl, 63, 64);
+                t = __shfl(tk, 63, 64);
+            }
+        }
+        const float* bg = bl.bg_rays ? bl.bg_rays + 3 * (size_t)index : bl.bg;
+        const float rest = 1.0f - ws;
+        const float o0 = r + rest * bg[0], o1 = g + rest * bg[1], o2 = b + rest * bg[2];
+        // ---- criterion (k_mse_fwd): grad = ((pred - target) * 2 / n_elements) * scale
+        const float s = sl.scale ? sl.scale[0] : 1.0f;
+        const float gk = 2.0f / (float)(3u * N);
+        const float e0 = o0 - sl.target[3 * (size_t)index], e1 = o1 - sl.target[3 * (size_t)index + 1],
+                    e2 = o2 - sl.target[3 * (size_t)index + 2];
+        sq = fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+        float g0 = (e0 * gk) * s, g1 = (e1 * gk) * s, g2 = (e2 * gk) * s;
+        if (lane == 0) {
+            weights_sum[index] = ws; depth[index] = d;
+            image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+            bl.image_out[3 * (size_t)index] = o0; bl.image_out[3 * (size_t)index + 1] = o1; bl.image_out[3 * (size_t)index + 2] = o2;
+            const float nr = bl.nears[index];
+            bl.depth_out[index] = fmaxf(d - nr, 0.0f) / (bl.fars[index] - nr);
+            sl.grad_image[3 * (size_t)index] = g0; sl.grad_image[3 * (size_t)index + 1] = g1; sl.grad_image[3 * (size_t)index + 2] = g2;
+        }
+        // ---- backward (k_composite_train_bwd<true>, grad_weights_sum = 0, grad_scale = 1)
+        if (has) {
+            const float gws = 0.0f - ((g0 * bg[0] + g1 * bg[1]) + g2 * bg[2]);
+            const float rf = r, gf = g, bf = b;
+            const float tail = gws * (1 - ws);
+            float T = 1.0f, rr = 0, gg = 0, bb = 0;
+            bool stopped = false;
+            for (uint32_t base = 0; base < num_steps; base += 64) {
+                const uint32_t k = base + lane;
+                bool valid = k < num_steps;
+                const size_t i = (size_t)offset + k;
+                if (stopped) {                                                      // samples after the early stop: zero gradient
+                    if (valid) { grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f; }
+                    continue;
+                }
+                const bool in_ray = valid;
+                float alpha = 0.f, d0 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                if (valid) {
+                    d0 = deltas[2 * i];
+                    alpha = 1.0f - __expf(-sigmas[i] * d0);
+                    c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+                }
+                const float incl = wave_scan_mul(1.0f - alpha, lane);
+                float excl = __shfl_up(incl, 1, 64);
+                if (lane == 0) excl = 1.0f;
+                const float T_post = T * incl;
+                const unsigned long long stop = __ballot(valid && T_post < T_thresh);
+                bool done = false;
+                if (stop) { const int last = __builtin_ctzll(stop); valid = valid && lane <= last; done = true; }
+                const float w = valid ? alpha * (T * excl) : 0.0f;
+                const float rk = rr + wave_scan_add(w * c0, lane);
+                const float gkk = gg + wave_scan_add(w * c1, lane);
+                const float bk = bb + wave_scan_add(w * c2, lane);
+                if (valid) {
+                    grad_rgbs[3 * i] = g0 * w; grad_rgbs[3 * i + 1] = g1 * w; grad_rgbs[3 * i + 2] = g2 * w;
+                    grad_sigmas[i] = d0 * (g0 * (T_post * c0 - (rf - rk)) + g1 * (T_post * c1 - (gf - gkk)) +
+                                           g2 * (T_post * c2 - (bf - bk)) + tail);
+                } else if (in_ray) {
+                    grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f;
+                }
+                if (done) { stopped = true; continue; }
+                T *= __shfl(incl, 63, 64);
+                rr = __shfl(rk, 63, 64); gg = __shfl(gkk, 63, 64); bb = __shfl(bk, 63, 64);
+            }
+        }
+    }
+    if (lane == 0) s_sq[wv] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < COMP_WAVES; w++) t += s_sq[w];
+        sl.partials[blockIdx.x] = t;
+    }
+}
+
+// sum of the workgroups' squared-error sums in a fixed order -> loss_out[0] = mean * scale, loss_out[1] = mean
+__global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ partials, uint32_t n_part, uint32_t n_elem,
+                                                       const float* __restrict__ scale, float* __restrict__ loss_out) {
+    __shared__ float part[16];
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n_part; i += 1024) acc += partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += part[w];
+        const float loss = t / (float)n_elem;
+        loss_out[0] = loss * (scale ? scale[0] : 1.0f);
+        loss_out[1] = loss;
+    }
+}
+
 // ---------------------------------------------------------------- K9 / K10 (inference march)
 // raymarching.cu:700-805 and :811-926 (EDIT = distill variant)
 template <bool EDIT>
@@ -1240,6 +1390,26 @@ int lae_composite_rays_train_forward_blend(const float* sigmas, const float* rgb
     k_composite_train_fwd<true><<<lae::cdiv(N, COMP_WAVES), COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N,
                                                                                               T_thresh, weights_sum, depth, image, bl);
     return lae::check_launch("composite_rays_train_forward_blend");
+}
+
+int lae_composite_rays_train_step(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
+                                  uint32_t N, float T_thresh, const float* nears, const float* fars, const float* bg_rays, float bg_r,
+                                  float bg_g, float bg_b, const uint32_t* rows_end, const float* target, const float* scale,
+                                  float* weights_sum, float* depth, float* image, float* depth_out, float* image_out,
+                                  float* grad_image, float* grad_sigmas, float* grad_rgbs, float* loss_out, float* partials,
+                                  void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays || !weights_sum || !depth || !image || !nears || !fars || !depth_out || !image_out || !rows_end || !target || !grad_image ||
+        !loss_out || !partials)
+        return LAE_ENULL;
+    if (M > 0 && (!sigmas || !rgbs || !deltas || !grad_sigmas || !grad_rgbs)) return LAE_ENULL;
+    const Blend bl{nears, fars, bg_rays, {bg_r, bg_g, bg_b}, image_out, depth_out};
+    const StepLoss sl{target, scale, grad_image, partials};
+    const uint32_t nb = lae::cdiv(N, COMP_WAVES);
+    k_composite_train_step<<<nb, COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, bl,
+                                                                 sl, rows_end, grad_sigmas, grad_rgbs);
+    k_loss_finish<<<1, 1024, 0, STREAM(stream)>>>(partials, nb, 3u * N, scale, loss_out);
+    return lae::check_launch("composite_rays_train_step");
 }
 
 int lae_composite_rays_train_backward_blend_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,

@@ -89,6 +89,8 @@ class FusedAdam(torch.optim.Optimizer):
         one = cache.get(key)
         if one is None:
             one = cache[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+            from .raymarching.raymarching import register_unit_root_grad
+            register_unit_root_grad(one)                   # the fused criterion node skips the multiplication by it
         loss.backward(gradient=one)
 
     def get_scale(self):

@@ -242,34 +242,50 @@ def composite_rays_train_blend(sigmas, rgbs, deltas, rays, nears, fars, bg_color
     return _composite_rays_train_blend.apply(sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh)
 
 
+# root gradients known to be all ones (laenerf_amd.optim.FusedAdam.backward registers the tensor it passes to
+# loss.backward): for them the fused node below hands its stored sample gradients on unchanged.  address -> weak reference:
+# an address whose tensor has died may belong to anything by now
+_unit_root_grads = {}
+
+
+def register_unit_root_grad(t):
+    import weakref
+    _unit_root_grads[t.data_ptr()] = weakref.ref(t)
+
+
+def _is_unit_root_grad(t):
+    r = _unit_root_grads.get(t.data_ptr())
+    return r is not None and r() is not None and r().shape == t.shape
+
+
 class _composite_rays_train_blend_mse(Function):
     """composite_rays_train_blend + the trainer's criterion and loss scaling (`MSELoss(pred_rgb, gt).mean()` then
-    `scaler.scale(loss)`, nerf/utils.py train_step) as ONE autograd node: forward = compositing kernel + the fused MSE
-    kernel (loss, scaled loss, d(scaled loss)/d(pred)); backward = the compositing backward kernel alone, which takes the
-    upstream gradient as a device scalar.  Between the loss and the sample gradients torch otherwise runs a ones-fill, an
-    elementwise multiplication, a zero-fill for the unused weights_sum gradient and two copies (~25 us per step)."""
+    `scaler.scale(loss)`, nerf/utils.py train_step) as ONE autograd node and ONE kernel: d loss / d pixel of a ray depends on
+    that ray's pixel only, so the compositing forward, the criterion and the compositing backward of a ray run back to back
+    in the wavefront that owns it (`lae_composite_rays_train_step`; three launches and two kernel boundaries in the middle of
+    the step before).  The sample gradients are therefore computed in forward() for an upstream gradient of 1 and stored;
+    backward() returns them -- multiplied by the upstream gradient unless that is known to be ones."""
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh, target, scale):
-        from .. import _lib
         sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
         M, N = sigmas.shape[0], rays.shape[0]
         dev, dt = sigmas.device, sigmas.dtype
         weights_sum, depth, image = (torch.empty(N, dtype=dt, device=dev), torch.empty(N, dtype=dt, device=dev),
                                      torch.empty(N, 3, dtype=dt, device=dev))
         depth_out, image_out = torch.empty(N, dtype=dt, device=dev), torch.empty(N, 3, dtype=dt, device=dev)
-        _backend.composite_rays_train_forward_blend(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears.contiguous(),
-                                                    fars.contiguous(), bg_rays, bg, weights_sum, depth, image, depth_out, image_out)
         target = target.float().contiguous()
         if target.shape != image_out.shape:
             raise RuntimeError("composite_rays_train_blend_mse: target must be [N,3]")
         out = torch.empty(2, dtype=torch.float32, device=dev)
         grad_image = torch.empty_like(image_out)
-        _lib.check(_lib.load().lae_mse_loss_forward(image_out.data_ptr(), target.data_ptr(), image_out.numel(), _lib.ptr(scale),
-                                                    out.data_ptr(), grad_image.data_ptr(), _lib.stream()), "mse_loss_forward")
-        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image)
-        ctx.dims = [M, N, T_thresh, bg]
+        grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
+        partials = torch.empty((N + 3) // 4, dtype=torch.float32, device=dev)
+        _backend.composite_rays_train_step(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears.contiguous(), fars.contiguous(), bg_rays,
+                                           bg, rows_end, target, scale, weights_sum, depth, image, depth_out, image_out, grad_image,
+                                           grad_sigmas, grad_rgbs, out, partials)
+        ctx.save_for_backward(grad_sigmas, grad_rgbs)
         ctx.mark_non_differentiable(weights_sum, depth_out, image_out, out)
         ctx.set_materialize_grads(False)                 # no zero-filled gradients for the four auxiliary outputs (4 fill launches)
         return out[0], weights_sum, depth_out, image_out, out
@@ -279,12 +295,10 @@ class _composite_rays_train_blend_mse(Function):
     def backward(ctx, grad_loss, *_):
         if grad_loss is None:
             return (None,) * 12
-        sigmas, rgbs, deltas, rays, weights_sum, image, bg_rays, rows_end, grad_image = ctx.saved_tensors
-        M, N, T_thresh, bg = ctx.dims
-        grad_sigmas, grad_rgbs = torch.empty_like(sigmas), torch.empty_like(rgbs)
-        _backend.composite_rays_train_backward_blend(None, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
-                                                     T_thresh, bg_rays, bg, rows_end, grad_sigmas, grad_rgbs,
-                                                     grad_scale=grad_loss.float().reshape(1).contiguous())
+        grad_sigmas, grad_rgbs = ctx.saved_tensors
+        if not _is_unit_root_grad(grad_loss):              # a general upstream gradient: d(loss) scales every sample gradient
+            gl = grad_loss.float()
+            grad_sigmas, grad_rgbs = grad_sigmas * gl, grad_rgbs * gl
         return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None
 
 
