@@ -491,21 +491,35 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict
 // depth sums are additive scans, the early stop `T < T_thresh` is a ballot + ctz.  Sample reads and gradient
 // writes are lane-consecutive (coalesced); the reference's one-thread-per-ray loop strides by ray.
 // Scan association differs from the serial loop -> results agree to fp32 rounding (tests: 2e-6).
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+// Wave-level scans on the DPP data path (row shifts 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / :31 across
+// them -- GFX9 controls, present on gfx950): six dependent VALU operations per scan.  Written with __shfl_up the compiler
+// emits ds_bpermute_b32, an LDS round trip per step: 74 of them in the training compositing kernel, whose duration is the
+// dependent chain of its longest rays (several passes of 64 samples, forward and backward).  Lanes that a shift leaves
+// without a source take the operation's identity (`old` operand), so no per-step select is needed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_add(float v, int) {
+    v += dpp_f<0x111, 0xf>(0.0f, v); v += dpp_f<0x112, 0xf>(0.0f, v); v += dpp_f<0x114, 0xf>(0.0f, v); v += dpp_f<0x118, 0xf>(0.0f, v);
+    v += dpp_f<0x142, 0xa>(0.0f, v);        // row_bcast:15 -> rows 1 and 3
+    v += dpp_f<0x143, 0xc>(0.0f, v);        // row_bcast:31 -> rows 2 and 3
     return v;
 }
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= d) v *= o; }
+__device__ __forceinline__ float wave_scan_mul(float v, int) {
+    v *= dpp_f<0x111, 0xf>(1.0f, v); v *= dpp_f<0x112, 0xf>(1.0f, v); v *= dpp_f<0x114, 0xf>(1.0f, v); v *= dpp_f<0x118, 0xf>(1.0f, v);
+    v *= dpp_f<0x142, 0xa>(1.0f, v);
+    v *= dpp_f<0x143, 0xc>(1.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+__device__ __forceinline__ float wave_last(float v) {        // value of lane 63 in every lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+__device__ __forceinline__ float wave_prev(float v, float first) {   // value of the lane below; `first` in lane 0 (wave_shr:1)
+    return dpp_f<0x138, 0xf>(first, v);
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_last(wave_scan_add(v, 0)); }
 
 constexpr int COMP_WAVES = 4;
 constexpr int COMP_BLOCK = 64 * COMP_WAVES;
@@ -539,8 +553,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
                 c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
             }
             const float incl = wave_scan_mul(1.0f - alpha, lane);           // prod_{j<=k} within the pass
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
+            const float excl = wave_prev(incl, 1.0f);
             const float T_post = T * incl;
             const unsigned long long stop = __ballot(valid && T_post < T_thresh);   // :557 (sample included)
             bool done = false;
@@ -550,8 +563,8 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_fwd(
             r += wave_sum(w * c0); g += wave_sum(w * c1); b += wave_sum(w * c2);
             d += wave_sum(w * tk); ws += wave_sum(w);
             if (done) break;
-            T *= __shfl(incl, 63, 64);
-            t = __shfl(tk, 63, 64);
+            T *= wave_last(incl);
+            t = wave_last(tk);
         }
     }
     if (lane == 0) {
@@ -622,8 +635,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
             c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
         }
         const float incl = wave_scan_mul(1.0f - alpha, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_prev(incl, 1.0f);
         const float T_post = T * incl;
         const unsigned long long stop = __ballot(valid && T_post < T_thresh);
         bool done = false;
@@ -640,8 +652,8 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
             grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f;
         }
         if (done) { if (DENSE) { stopped = true; continue; } break; }
-        T *= __shfl(incl, 63, 64);
-        r = __shfl(rk, 63, 64); g = __shfl(gk, 63, 64); b = __shfl(bk, 63, 64);
+        T *= wave_last(incl);
+        r = wave_last(rk); g = wave_last(gk); b = wave_last(bk);
     }
 }
 
@@ -673,21 +685,35 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
         const bool has = !(num_steps == 0 || offset + num_steps > M);
         // ---- forward (k_composite_train_fwd<true>)
         float r = 0, g = 0, b = 0, ws = 0, d = 0;
+        // operands of one pass of 64 samples; the next pass is requested before the current one is scanned: the kernel's
+        // time is that of its longest rays (several passes, forward and backward), one memory latency per pass otherwise
+        struct Pass { float sg, d0, d1, c0, c1, c2; };
+        auto fetch = [&](uint32_t base) {
+            Pass p{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const uint32_t k = base + lane;
+            if (k < num_steps) {
+                const size_t i = (size_t)offset + k;
+                p.sg = sigmas[i]; p.d0 = deltas[2 * i]; p.d1 = deltas[2 * i + 1];
+                p.c0 = rgbs[3 * i]; p.c1 = rgbs[3 * i + 1]; p.c2 = rgbs[3 * i + 2];
+            }
+            return p;
+        };
         if (has) {
             float T = 1.0f, t = 0.0f;
+            Pass nxt = fetch(0);
             for (uint32_t base = 0; base < num_steps; base += 64) {
                 const uint32_t k = base + lane;
                 bool valid = k < num_steps;
+                const Pass cur = nxt;
+                if (base + 64 < num_steps) nxt = fetch(base + 64);
                 float alpha = 0.f, d1 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
                 if (valid) {
-                    const size_t i = (size_t)offset + k;
-                    alpha = 1.0f - __expf(-sigmas[i] * deltas[2 * i]);
-                    d1 = deltas[2 * i + 1];
-                    c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+                    alpha = 1.0f - __expf(-cur.sg * cur.d0);
+                    d1 = cur.d1;
+                    c0 = cur.c0; c1 = cur.c1; c2 = cur.c2;
                 }
                 const float incl = wave_scan_mul(1.0f - alpha, lane);
-                float excl = __shfl_up(incl, 1, 64);
-                if (lane == 0) excl = 1.0f;
+                const float excl = wave_prev(incl, 1.0f);
                 const float T_post = T * incl;
                 const unsigned long long stop = __ballot(valid && T_post < T_thresh);
                 bool done = false;
@@ -697,8 +723,8 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
                 r += wave_sum(w * c0); g += wave_sum(w * c1); b += wave_sum(w * c2);
                 d += wave_sum(w * tk); ws += wave_sum(w);
                 if (done) break;
-                T *= __shfl(incl, 63, 64);
-                t = __shfl(tk, 63, 64);
+                T *= wave_last(incl);
+                t = wave_last(tk);
             }
         }
         const float* bg = bl.bg_rays ? bl.bg_rays + 3 * (size_t)index : bl.bg;
@@ -726,10 +752,13 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
             const float tail = gws * (1 - ws);
             float T = 1.0f, rr = 0, gg = 0, bb = 0;
             bool stopped = false;
+            Pass nxt = fetch(0);
             for (uint32_t base = 0; base < num_steps; base += 64) {
                 const uint32_t k = base + lane;
                 bool valid = k < num_steps;
                 const size_t i = (size_t)offset + k;
+                const Pass cur = nxt;
+                if (!stopped && base + 64 < num_steps) nxt = fetch(base + 64);
                 if (stopped) {                                                      // samples after the early stop: zero gradient
                     if (valid) { grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f; }
                     continue;
@@ -737,13 +766,12 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
                 const bool in_ray = valid;
                 float alpha = 0.f, d0 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
                 if (valid) {
-                    d0 = deltas[2 * i];
-                    alpha = 1.0f - __expf(-sigmas[i] * d0);
-                    c0 = rgbs[3 * i]; c1 = rgbs[3 * i + 1]; c2 = rgbs[3 * i + 2];
+                    d0 = cur.d0;
+                    alpha = 1.0f - __expf(-cur.sg * d0);
+                    c0 = cur.c0; c1 = cur.c1; c2 = cur.c2;
                 }
                 const float incl = wave_scan_mul(1.0f - alpha, lane);
-                float excl = __shfl_up(incl, 1, 64);
-                if (lane == 0) excl = 1.0f;
+                const float excl = wave_prev(incl, 1.0f);
                 const float T_post = T * incl;
                 const unsigned long long stop = __ballot(valid && T_post < T_thresh);
                 bool done = false;
@@ -760,8 +788,8 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
                     grad_rgbs[3 * i] = 0.f; grad_rgbs[3 * i + 1] = 0.f; grad_rgbs[3 * i + 2] = 0.f; grad_sigmas[i] = 0.f;
                 }
                 if (done) { stopped = true; continue; }
-                T *= __shfl(incl, 63, 64);
-                rr = __shfl(rk, 63, 64); gg = __shfl(gkk, 63, 64); bb = __shfl(bk, 63, 64);
+                T *= wave_last(incl);
+                rr = wave_last(rk); gg = wave_last(gkk); bb = wave_last(bk);
             }
         }
     }
