@@ -44,14 +44,17 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 
-// wave64 inclusive scan (Hillis-Steele over __shfl_up); returns inclusive sum
+// wave64 inclusive scan on the DPP data path: row shifts 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / :31
+// across them (GFX9 controls); lanes a shift leaves without a source add 0.  (__shfl_up compiles to ds_bpermute_b32, an
+// LDS round trip per step.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += dpp_u32<0x111, 0xf>(v); v += dpp_u32<0x112, 0xf>(v); v += dpp_u32<0x114, 0xf>(v); v += dpp_u32<0x118, 0xf>(v);
+    v += dpp_u32<0x142, 0xa>(v);
+    v += dpp_u32<0x143, 0xc>(v);
     return v;
 }
 
