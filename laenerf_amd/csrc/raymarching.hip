@@ -809,8 +809,7 @@ __global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ 
     __shared__ float part[16];
     float acc = 0.0f;
     for (uint32_t i = threadIdx.x; i < n_part; i += 1024) acc += partials[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
