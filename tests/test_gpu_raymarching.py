@@ -254,3 +254,50 @@ def test_composite_blend_equals_separate_ops(rm, bg_mode):
                                               1e-4, bgr, bgc, rays.rows_end, gs, gc)
         assert torch.isfinite(gs).all() and torch.isfinite(gc).all()
         assert torch.allclose(gs, g1s, rtol=1e-5, atol=1e-6) and torch.equal(gc, g1c)
+
+
+@pytest.mark.parametrize("bg_mode", ["const", "per_ray"])
+def test_composite_train_step_equals_the_three_kernels(rm, bg_mode):
+    """lae_composite_rays_train_step (compositing forward + blend, MSE criterion, compositing backward in one launch) against
+    lae_composite_rays_train_forward_blend + lae_mse_loss_forward + lae_composite_rays_train_backward_blend on the same
+    buffers: rays of several 64-sample passes, early stops (dense sigmas), rays without samples, a trimmed and a fixed-size
+    sample buffer that drops overflowing rays, poisoned gradient buffers (every row must be written).  Pixels and
+    gradients: the same bits; the loss: the same sum in another order."""
+    from laenerf_amd import _lib
+    from laenerf_amd.backend import raymarching_backend as B
+    N_ = 700
+    sc = scene(1, 1.0, n_rays=N_, seed=9)
+    o, d, bits, n, f = T(sc["o"]), T(sc["d"]), T(sc["bits"]), T(sc["nears"]), T(sc["fars"])
+    counter = torch.zeros(2, dtype=torch.int32, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    scale = torch.tensor([1024.0], device=DEV)
+    for mean_count, dens in ((-1, 60.0), (-1, 0.5), (30000, 5.0)):
+        counter.zero_()
+        xyzs, dirs, deltas, rays = rm.march_rays_train(o, d, 1.0, bits, 1, 128, n, f, counter, mean_count, False, 128, False, 0, 1024)
+        M = xyzs.shape[0]
+        assert int(N(rays)[:, 2].max()) > 128 and int((N(rays)[:, 2] == 0).sum()) > 0       # multi-pass rays and empty rays
+        sig = torch.rand(M, device=DEV, generator=gen) * dens
+        rgb = torch.rand(M, 3, device=DEV, generator=gen)
+        target = torch.rand(N_, 3, device=DEV, generator=gen)
+        bgr = torch.rand(N_, 3, device=DEV, generator=gen) if bg_mode == "per_ray" else None
+        bgc = (1.0, 1.0, 1.0)
+        new = lambda *shape: torch.full(shape, float("nan"), device=DEV)
+        # the three kernels
+        ws0, dp0, im0, do0, io0 = new(N_), new(N_), new(N_, 3), new(N_), new(N_, 3)
+        B.composite_rays_train_forward_blend(sig, rgb, deltas, rays, M, N_, 1e-4, n, f, bgr, bgc, ws0, dp0, im0, do0, io0)
+        loss0, gi0 = new(2), new(N_, 3)
+        _lib.check(_lib.load().lae_mse_loss_forward(io0.data_ptr(), target.data_ptr(), io0.numel(), scale.data_ptr(), loss0.data_ptr(),
+                                                    gi0.data_ptr(), _lib.stream()), "mse")
+        gs0, gc0 = new(M), new(M, 3)
+        B.composite_rays_train_backward_blend(None, gi0, sig, rgb, deltas, rays, ws0, im0, M, N_, 1e-4, bgr, bgc, rays.rows_end, gs0, gc0)
+        # the one kernel
+        ws1, dp1, im1, do1, io1, gi1, gs1, gc1, loss1 = new(N_), new(N_), new(N_, 3), new(N_), new(N_, 3), new(N_, 3), new(M), new(M, 3), new(2)
+        part = new((N_ + 3) // 4)
+        B.composite_rays_train_step(sig, rgb, deltas, rays, M, N_, 1e-4, n, f, bgr, bgc, rays.rows_end, target, scale, ws1, dp1, im1, do1,
+                                    io1, gi1, gs1, gc1, loss1, part)
+        for a_, b_ in ((ws0, ws1), (dp0, dp1), (im0, im1), (io0, io1), (gi0, gi1), (gs0, gs1), (gc0, gc1)):
+            assert torch.isfinite(b_).all() and torch.equal(a_, b_)
+        assert torch.equal(torch.nan_to_num(do0, nan=-1.0), torch.nan_to_num(do1, nan=-1.0))
+        assert loss1[1].item() == pytest.approx(loss0[1].item(), rel=2e-6) and loss1[0].item() == pytest.approx(1024.0 * loss1[1].item(), rel=1e-6)
+        ref = torch.nn.functional.mse_loss(io1, target).item()
+        assert loss1[1].item() == pytest.approx(ref, rel=1e-5)
