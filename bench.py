@@ -48,9 +48,10 @@ def parse():
                    help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
                         "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured HIP graph")
-    p.add_argument("--steps-per-graph", type=int, default=8,
-                   help="pipelined mode: consecutive train steps captured into one graph replay (1, 2, 4, 8 or 16; reduced to a "
-                        "divisor of --steps).  A graph boundary costs 15-18 us of device time on this stack")
+    p.add_argument("--steps-per-graph", type=int, default=0,
+                   help="pipelined mode: consecutive train steps captured into one graph replay (at most 16; reduced to a divisor "
+                        "of --steps; 0 = the largest divisor of --steps that is <= 16).  A graph boundary costs 15-18 us of device "
+                        "time on this stack")
     p.add_argument("--march-beside", choices=["forward", "backward"], default="backward",
                    help="pipelined mode: which half of step k the march of step k+1 runs beside")
     p.add_argument("--no-pipeline", action="store_true",
@@ -447,7 +448,13 @@ def main():
         from laenerf_amd.optim import FusedAdam
         opt = scaler = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     fused_loss = not args.torch_loss and not args.torch_optimizer
-    n_batches = max(16, 4 * min(int(args.steps_per_graph), 16))   # resident ray batches: >= 4 groups of --steps-per-graph steps
+    spg = int(args.steps_per_graph)
+    if spg <= 0:                                                   # largest divisor of --steps that is <= 16
+        spg = max(dv for dv in range(1, 17) if args.steps % dv == 0)
+    spg = max(1, min(spg, 16))
+    while spg > 1 and args.steps % spg:
+        spg -= 1
+    n_batches = spg * max(4, -(-16 // spg))                        # resident ray batches: >= 4 groups of spg steps, >= 16 batches
     batches = []
     for b in range(n_batches):
         # one training view per step, random pixels of it: what the reference's loader does (DataLoader batch_size = 1,
@@ -546,9 +553,7 @@ def main():
         # they run concurrently, and every march graph keeps its own output buffers (read by its shading graph).
         main = torch.cuda.current_stream()
         marched, n_graph_samples = [], []
-        G = max(1, min(int(args.steps_per_graph), 16))
-        while G > 1 and (args.steps % G or n_batches % G):
-            G //= 2
+        G = spg                                             # divides --steps and n_batches by construction
         if G > 1:
             # G consecutive steps per replay: {march(b) ... march(b+G-1)} on the side stream, one group ahead of
             # {shade, backward, Adam of b; ... of b+G-1} on the main stream.  Every step does exactly the kernels of the
