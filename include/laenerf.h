@@ -298,12 +298,15 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                const int32_t* offsets_host, int32_t* nonfinite_flag, void* stream);
+                                const int32_t* offsets_host, int32_t* nonfinite_flag, uint32_t* touched_lines, void* stream);
 /* nonfinite_flag (may be NULL): device word that is OR-ed with 1 when this call STORES a non-finite value into
  * grad_embeddings (an overflowed sum, a non-finite contribution, or a non-finite value already there that it adds to).  A
  * caller whose gradient buffer is written by these calls only can hand the optimizer's found_inf word (state word 2 of
  * lae_adam_*) and leave the table out of lae_adam_check.  Needs the binned pipeline on every level: D = 3, C = 2,
- * offsets_host given, every level <= 2^21 entries, B <= 2^24 (LAE_EINVAL otherwise). */
+ * offsets_host given, every level <= 2^21 entries, B <= 2^24 (LAE_EINVAL otherwise).
+ * touched_lines (may be NULL; fp16 only, same conditions): bitmap with one bit per 8 table entries (bit k of word w = entries
+ * 8 * (32 w + k) ... + 7, i.e. one 64-byte line of the fp32 table); the call sets the bits of the lines it stores a gradient in.
+ * lae_adam_apply_multi skips lines whose bit was never set (their gradient and both Adam moments are exactly zero). */
 
 /* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- the bookkeeping of a counting
  * sort: items per (level, 1024 samples, table partition), their scans -- depends on the sample positions only,
@@ -321,7 +324,8 @@ LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* of
 LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                     const int32_t* offsets_host, const void* plan, int32_t* nonfinite_flag, void* stream);
+                                     const int32_t* offsets_host, const void* plan, int32_t* nonfinite_flag, uint32_t* touched_lines,
+                                     void* stream);
 
 /* Bytes of LIBRARY workspace the binned backward (D = 3, C = 2) takes for B samples and L levels when it runs both halves
  * itself: the plan + the item queue, sized for the worst case of 8 items per (sample, level) at 10 bytes each for fp16
@@ -506,11 +510,14 @@ LAE_API int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void
 LAE_API int lae_mse_loss_forward(const float* pred, const float* target, uint32_t n, const float* scale, float* loss_out, float* grad,
                          void* stream);
 
-/* multi-tensor forms of check / apply: host arrays of n_tensors (<= 8) device pointers / sizes; one launch each */
+/* multi-tensor forms of check / apply: host arrays of n_tensors (<= 8) device pointers / sizes; one launch each.
+ * touched_lines (may be NULL, entries may be NULL): per tensor the bitmap lae_grid_encode_backward_ex maintains (one bit per 16
+ * parameters); with weight_decay == 0 a line whose bit is clear is neither read nor written -- Adam's update of parameters whose
+ * gradient, exp_avg and exp_avg_sq are all zero is exactly zero. */
 LAE_API int lae_adam_check_multi(uint32_t n_tensors, const void* const* grads, const int* grad_is_half, const uint64_t* sizes, void* state,
                          void* stream);
 LAE_API int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, void* const* grads,
-                         const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs,
+                         const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs, const void* const* touched_lines,
                          const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* torch_ema.ExponentialMovingAverage.update() of the reference's trainer (nerf/utils.py:407-408 construct, :1502-1503 update once per

@@ -46,11 +46,11 @@ SIGNATURES = {
     "lae_grid_encode_forward": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, vp],
     "lae_grid_encode_backward": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, vp],
     "lae_grid_encode_forward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp, vp],
+    "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp, vp, vp],
     "lae_grid_backward_workspace_bytes": [u32, u32, i32],
     "lae_grid_backward_plan_bytes": [u32, u32],
     "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp],
+    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grid_set_forward_mode": [i32],
     "lae_grid_forward_schedule": [vp, u32, f32, u32, u32, vp, vp],
@@ -78,7 +78,7 @@ SIGNATURES = {
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],
-    "lae_adam_apply_multi": [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp],
+    "lae_adam_apply_multi": [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp],
     "lae_adam_begin": [vp, f32, f32, i32, f32, f32, i32, vp],
     "lae_ema_update_multi": [u32, vp, vp, vp, f32, vp],
     "lae_adam_apply": [vp, vp, vp, vp, i32, vp, u64, vp, vp, f32, f32, f32, f32, vp],

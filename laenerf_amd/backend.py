@@ -334,10 +334,11 @@ class _GridEncoder:
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                              gridtype, align_corners, interp, blc=False, in_map=(0.0, 1.0), offsets_host=None, plan=None,
-                             nonfinite_flag=None):
+                             nonfinite_flag=None, touched_lines=None):
         """plan (MI355X extension): result of grid_backward_plan for the same inputs -- skips the count pass and scans.
-        nonfinite_flag: address (int) of a device int32 that is OR-ed with 1 when the call stores a non-finite table gradient
-        (include/laenerf.h: binned pipeline only)"""
+        nonfinite_flag: address (int) of a device int32 that is OR-ed with 1 when the call stores a non-finite table gradient;
+        touched_lines: address (int) of the "ever touched" bitmap, one bit per 8 table entries (include/laenerf.h: binned
+        pipeline only)"""
         ts = (grad, inputs, embeddings, offsets, grad_embeddings, dy_dx, grad_inputs, plan)
         need_cuda(*ts); need_contig(*ts)
         if grad.dtype != grad_embeddings.dtype:
@@ -348,14 +349,15 @@ class _GridEncoder:
                 raise RuntimeError("grid_encode_backward: a plan needs level-major gradients and no input gradient")
             check(lib.lae_grid_encode_backward_planned(ptr(grad), ptr(inputs), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                                                        gridtype, int(bool(align_corners)), interp, _dtype_code(grad), float(in_map[0]),
-                                                       float(in_map[1]), _host_i32(offsets_host, L + 1), ptr(plan), nonfinite_flag, stream()),
+                                                       float(in_map[1]), _host_i32(offsets_host, L + 1), ptr(plan), nonfinite_flag, touched_lines,
+                                                       stream()),
                   "grid_encode_backward")
             return
         args = (ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                 ptr(dy_dx), ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, _dtype_code(grad))
-        if blc or tuple(in_map) != (0.0, 1.0) or offsets_host is not None or nonfinite_flag is not None:
+        if blc or tuple(in_map) != (0.0, 1.0) or offsets_host is not None or nonfinite_flag is not None or touched_lines is not None:
             check(lib.lae_grid_encode_backward_ex(*args, int(bool(blc)), float(in_map[0]), float(in_map[1]), _host_i32(offsets_host, L + 1),
-                                                  nonfinite_flag, stream()), "grid_encode_backward")
+                                                  nonfinite_flag, touched_lines, stream()), "grid_encode_backward")
         else:
             check(lib.lae_grid_encode_backward(*args, stream()), "grid_encode_backward")
 

@@ -876,7 +876,7 @@ template <typename T>
 __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
     bool align_corners, BwdPlan plan, const typename BVal<T>::type* __restrict__ qvals, const uint16_t* __restrict__ qkeys,
-    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag) {
+    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag, uint32_t* __restrict__ touched) {
     using V = typename BVal<T>::type;
     constexpr bool HALF = sizeof(T) == 2;
     constexpr uint32_t ACCW = HALF ? 2 * PART : PART;
@@ -1102,7 +1102,19 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 if (e >= n_ent) break;
                 const long long i0 = (long long)acc64[e], i1 = (long long)acc64[PART + e];
                 const bool bad = (poison[e >> 5] >> (e & 31)) & 1u;
-                if (i0 == 0 && i1 == 0 && !bad) continue;
+                const bool writes = !(i0 == 0 && i1 == 0 && !bad);
+                if (touched) {
+                    // the caller's "ever touched" bitmap, one bit per 8 entries (a 64-byte line of the fp32 table): the wave's
+                    // 64 entries are 8 lines, lane j < 8 reports line j (a plain read first: set bits cost no atomic)
+                    const unsigned long long wm = __ballot(writes);
+                    const uint32_t lane_ = tid & 63u;
+                    if (lane_ < 8u && ((wm >> (8u * lane_)) & 0xffull)) {
+                        const uint32_t lg = ((table_off + part_lo + (e - lane_)) >> 3) + lane_;
+                        const uint32_t bit = 1u << (lg & 31u);
+                        if (!(touched[lg >> 5] & bit)) atomicOr(&touched[lg >> 5], bit);
+                    }
+                }
+                if (!writes) continue;
                 const uint32_t o = oldv[it];               // only writer of this table slice: old + exact sum, rounded ONCE
                 uint32_t r0, r1;
                 if (bad) { r0 = 0x7e00u; r1 = 0x7e00u; }
@@ -1366,6 +1378,7 @@ struct BwdArgs {
     uint32_t gridtype; bool align; uint32_t interp; uint64_t gs_b, gs_l; hipStream_t stream;
     const int32_t* offsets_host = nullptr;
     int32_t* nf_flag = nullptr;                                 // set to 1 when a non-finite table gradient is stored (binned path)
+    uint32_t* touched = nullptr;                                // bit per 8 table entries (one 64-byte line of fp32 pairs): set when a gradient is stored there
 };
 template <typename T, int D, int C>
 static void launch_bwd(const BwdArgs& a) {
@@ -1531,7 +1544,7 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
         k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
     else
         k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
-    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag);
+    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag, a.touched);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
     // (its blocks return at once for the levels the binned path has handled).
@@ -1556,13 +1569,15 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
                          void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                          const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
                          int dtype, bool blc, void* stream, float in_shift = 0.0f, float in_scale = 1.0f,
-                         const int32_t* offsets_host = nullptr, const void* plan = nullptr, int32_t* nf_flag = nullptr) {
+                         const int32_t* offsets_host = nullptr, const void* plan = nullptr, int32_t* nf_flag = nullptr,
+                         uint32_t* touched = nullptr) {
     (void)embeddings;
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !offsets || !grad_embeddings) return LAE_ENULL;
     if (plan && !(D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !blc && !g_force_atomic_bwd)) return LAE_EINVAL;
     if (gridtype > 1 || interp > 1) return LAE_EINVAL;
-    if (nf_flag) {
+    if (touched && dtype != LAE_F16) return LAE_EINVAL;
+    if (nf_flag || touched) {
         // only the binned pipeline knows what it stores (the generic kernel's float atomics do not): every level must go
         // through it, which the host copy of the level sizes proves
         if (!(D == 3 && C == 2 && L <= 32 && B <= BWD_MAX_SAMPLES && !g_force_atomic_bwd) || !offsets_host) return LAE_EINVAL;
@@ -1572,6 +1587,7 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     BwdArgs a;
     a.offsets_host = offsets_host;
     a.nf_flag = nf_flag;
+    a.touched = touched;
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1674,10 +1690,10 @@ int lae_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                                 int align_corners, uint32_t interp, int dtype, int blc, float in_shift, float in_scale,
-                                const int32_t* offsets_host, int32_t* nonfinite_flag, void* stream) {
+                                const int32_t* offsets_host, int32_t* nonfinite_flag, uint32_t* touched_lines, void* stream) {
     return grid_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs,
                          gridtype, align_corners, interp, dtype, blc != 0, stream, in_shift, in_scale, offsets_host, nullptr,
-                         nonfinite_flag);
+                         nonfinite_flag, touched_lines);
 }
 
 uint64_t lae_grid_backward_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
@@ -1708,10 +1724,10 @@ int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, u
 int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                      uint32_t interp, int dtype, float in_shift, float in_scale, const int32_t* offsets_host,
-                                     const void* plan, int32_t* nonfinite_flag, void* stream) {
+                                     const void* plan, int32_t* nonfinite_flag, uint32_t* touched_lines, void* stream) {
     if (!plan) return LAE_ENULL;
     return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
-                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan, nonfinite_flag);
+                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan, nonfinite_flag, touched_lines);
 }
 
 int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks, uint32_t* nseg_out,

@@ -147,6 +147,7 @@ struct CheckSegs { const void* grad[MAX_SEGS]; size_t n[MAX_SEGS]; int is_half[M
 struct ApplySegs {
     float* p[MAX_SEGS]; float* m[MAX_SEGS]; float* v[MAX_SEGS]; void* grad[MAX_SEGS]; half_t* shadow[MAX_SEGS];
     const float* lr[MAX_SEGS]; size_t n[MAX_SEGS]; int is_half[MAX_SEGS]; int count;
+    const uint32_t* touched[MAX_SEGS];       // bit per 16 parameters (8 table entries x 2): 0 = gradient and both moments are zero
 };
 
 template <typename G>
@@ -182,9 +183,15 @@ __global__ __launch_bounds__(256) void k_check_multi(CheckSegs sg, OptState* __r
 template <typename G>
 __device__ __forceinline__ void seg_apply(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, G* __restrict__ grad,
                                           half_t* __restrict__ shadow, size_t n, bool skip, float inv_scale, float bc2_sqrt,
-                                          float lr_over_bc1, const AdamHyper& h) {
+                                          float lr_over_bc1, const AdamHyper& h, const uint32_t* __restrict__ touched = nullptr) {
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (touched) {
+            // a 64-byte line of parameters that never received a gradient has g = exp_avg = exp_avg_sq = 0: Adam's update of it is
+            // exactly zero (weight_decay = 0), so nothing of it is read or written (torch.optim.Adam would rewrite the same values)
+            const size_t line = i >> 4;
+            if (!((touched[line >> 5] >> (line & 31)) & 1u)) continue;
+        }
         if (i + 4 <= n) {
             float g[4];
             if constexpr (sizeof(G) == 2) {
@@ -231,8 +238,8 @@ __global__ __launch_bounds__(256) void k_apply_multi(ApplySegs sg, const OptStat
     const float inv_scale = st->inv_scale, bc2_sqrt = st->bc2_sqrt;
     for (int s = 0; s < sg.count; s++) {
         const float lr_over_bc1 = (float)((double)sg.lr[s][0] * (double)st->inv_bc1);
-        if (sg.is_half[s]) seg_apply(sg.p[s], sg.m[s], sg.v[s], (half_t*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h);
-        else seg_apply(sg.p[s], sg.m[s], sg.v[s], (float*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h);
+        if (sg.is_half[s]) seg_apply(sg.p[s], sg.m[s], sg.v[s], (half_t*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h, sg.touched[s]);
+        else seg_apply(sg.p[s], sg.m[s], sg.v[s], (float*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h, sg.touched[s]);
     }
 }
 
@@ -313,7 +320,8 @@ int lae_ema_update_multi(uint32_t n_tensors, float* const* shadows, const float*
 
 int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const* exp_avgs, float* const* exp_avg_sqs, void* const* grads,
                          const int* grad_is_half, void* const* shadows_half, const uint64_t* sizes, const float* const* lrs,
-                         const void* state, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+                         const void* const* touched_lines, const void* state, float beta1, float beta2, float eps, float weight_decay,
+                         void* stream) {
     if (n_tensors == 0) return LAE_OK;
     if (!params || !exp_avgs || !exp_avg_sqs || !grads || !grad_is_half || !shadows_half || !sizes || !lrs || !state) return LAE_ENULL;
     if (n_tensors > (uint32_t)MAX_SEGS) return LAE_EINVAL;
@@ -327,6 +335,7 @@ int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const*
         if (al & 15) return LAE_EINVAL;
         sg.p[i] = params[i]; sg.m[i] = exp_avgs[i]; sg.v[i] = exp_avg_sqs[i]; sg.grad[i] = grads[i];
         sg.shadow[i] = (half_t*)shadows_half[i]; sg.lr[i] = lrs[i]; sg.n[i] = sizes[i]; sg.is_half[i] = grad_is_half[i];
+        sg.touched[i] = (touched_lines && weight_decay == 0.0f) ? (const uint32_t*)touched_lines[i] : nullptr;
         biggest = std::max(biggest, (size_t)sizes[i]);
     }
     sg.count = (int)n_tensors;

@@ -168,6 +168,7 @@ def allreduce_gradients(optimizer, world_size=None, group=None):
                 shadow.grad_half.add_(p.grad.to(torch.half)); p.grad = None
             if hasattr(shadow, "unreported"):
                 shadow.unreported = True                     # the reduced sum may overflow: the optimizer scans the table again
+                shadow.mark_all_touched()                    # entries other ranks touched arrive through the reduction
             grads.append(shadow.grad_half)
         elif p.grad is not None:
             grads.append(p.grad)

@@ -65,9 +65,12 @@ class _nerf_field(Function):
                                 gws, gwc, accumulate=ctx.shadows is not None, level_major=True, nonfinite_flag=wflag)
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         flag = enc.shadow.flag_for_backward(M) if enc.shadow is not None else None    # the optimizer's found_inf word, or None
+        touched = enc.shadow.touched_for_backward(M) if flag is not None else None     # its "ever touched" bitmap, or None
+        if enc.shadow is not None and touched is None:
+            enc.shadow.mark_all_touched()
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
                                    enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, offsets_host=enc.offsets_host, plan=ctx.plan,
-                                   nonfinite_flag=flag)
+                                   nonfinite_flag=flag, touched_lines=touched)
         return (None, None, None if enc.shadow is not None else grad_table,
                 None if ctx.shadows is not None else gws.to(ctx.wdtypes[0]),
                 None if ctx.shadows is not None else gwc.to(ctx.wdtypes[1]), None, None, None, None, None, None)

@@ -62,11 +62,13 @@ class _grid_encode(Function):
         grad_embeddings = ctx.shadow.grad_half if ctx.shadow is not None else torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         flag = ctx.shadow.flag_for_backward(B) if ctx.shadow is not None and D == 3 and C == 2 else None
-        if ctx.shadow is not None and flag is None:
-            ctx.shadow.unreported = True
+        touched = ctx.shadow.touched_for_backward(B) if flag is not None and grad.dtype == torch.half else None
+        if ctx.shadow is not None and (flag is None or touched is None):
+            ctx.shadow.unreported = ctx.shadow.unreported or flag is None
+            ctx.shadow.mark_all_touched()
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
                                       grad_inputs, gridtype, ctx.align_corners, interpolation, blc=True, in_map=ctx.in_map,
-                                      offsets_host=ctx.offsets_host, nonfinite_flag=flag)
+                                      offsets_host=ctx.offsets_host, nonfinite_flag=flag, touched_lines=touched)
         if dy_dx is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
             if ctx.in_map[1] != 1.0:
@@ -89,13 +91,28 @@ class TableShadow:
         # not report (a folded .grad, a gradient all-reduce): the next step scans it again.
         self.nonfinite_flag = None
         self.unreported = False
+        # "ever touched" bitmap (one bit per 8 entries = one 64-byte line of the fp32 table), set by the binned backward where it
+        # stores a gradient; the optimizer skips lines whose bit is clear (gradient and both Adam moments exactly zero).  A
+        # writer that does not report turns every bit on (mark_all_touched): from then on nothing is skipped.
+        self.touched_lines = None
+
+    def mark_all_touched(self):
+        if self.touched_lines is not None:
+            self.touched_lines.fill_(-1)
 
     def flag_for_backward(self, n_samples=0):
         """address to hand to grid_encode_backward(nonfinite_flag=...), or None (then the write counts as unreported)"""
         if self.nonfinite_flag is None or n_samples > (1 << 24):     # beyond the binned pipeline's batch limit
             self.unreported = True
+            self.mark_all_touched()
             return None
         return self.nonfinite_flag
+
+    def touched_for_backward(self, n_samples=0):
+        """address of the bitmap for grid_encode_backward(touched_lines=...), or None"""
+        if self.touched_lines is None or self.nonfinite_flag is None or n_samples > (1 << 24):
+            return None
+        return self.touched_lines.data_ptr()
 
     def table_half(self, embeddings):
         if embeddings._version != self.version:        # someone else wrote the fp32 table (load_state_dict, init, ...)

@@ -66,6 +66,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if shadow is not None and isinstance(owner, GridEncoder) and owner.input_dim == 3 and owner.level_dim == 2 \
                         and owner.num_levels <= 32 and int((owner.offsets_host[1:] - owner.offsets_host[:-1]).max()) <= (1 << 21):
                     shadow.nonfinite_flag = self.dev_state.data_ptr() + 8
+                    if weight_decay == 0:             # touched-lines-only update (exact only without weight decay)
+                        shadow.touched_lines = torch.zeros(p.numel() // 16 // 32 + 2, dtype=torch.int32, device=p.device)
                 elif shadow is not None and isinstance(owner, FFMLP):
                     shadow.nonfinite_flag = self.dev_state.data_ptr() + 8    # the fused head backward reports its weight gradients
         self._scale_view = self.dev_state.view(torch.float32)
@@ -149,6 +151,7 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = None
                 if hasattr(shadow, "unreported"):
                     shadow.unreported = True             # this sum may overflow and nobody reports it: scan the table this step
+                    shadow.mark_all_touched()
             return shadow.grad_half, 1
         if p.grad is None:
             p.grad = torch.zeros_like(p)
@@ -170,6 +173,8 @@ class FusedAdam(torch.optim.Optimizer):
                 "m": arr([m.data_ptr() for _, m, *_ in self.items]), "v": arr([v.data_ptr() for _, _, v, *_ in self.items]),
                 "shadows": arr([None if sh is None else sh.half.data_ptr() for _, _, _, sh, _ in self.items]),
                 "lrs": arr([self.lrs.data_ptr() + 4 * gi for *_, gi in self.items]),
+                "touched": arr([None if sh is None or getattr(sh, "touched_lines", None) is None else sh.touched_lines.data_ptr()
+                                for _, _, _, sh, _ in self.items]),
             }
         return self._args
 
@@ -181,6 +186,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.sync_lr()
         lib, st, s = _lib.load(), self.dev_state.data_ptr(), _lib.stream()
         a = self._tables()
+        for *_, shadow, _ in self.items:                     # an accumulator written by something that does not report where:
+            if shadow is not None and getattr(shadow, "unreported", False) and hasattr(shadow, "mark_all_touched"):
+                shadow.mark_all_touched()                    # every line counts as touched from now on
         if self.use_scaler:
             c = self._check_tables(a)
             if c["n"]:
@@ -188,7 +196,7 @@ class FusedAdam(torch.optim.Optimizer):
         _lib.check(lib.lae_adam_begin(st, self.betas[0], self.betas[1], self.growth_interval, self.growth_factor,
                                       self.backoff_factor, int(self.use_scaler), s), "adam_begin")
         _lib.check(lib.lae_adam_apply_multi(a["n"], a["params"], a["m"], a["v"], a["grads"], a["is_half"], a["shadows"],
-                                            a["sizes"], a["lrs"], st, self.betas[0], self.betas[1], self.eps,
+                                            a["sizes"], a["lrs"], a["touched"], st, self.betas[0], self.betas[1], self.eps,
                                             self.weight_decay, s), "adam_apply")
         for *_, shadow, _ in self.items:                     # the accumulators are zero again
             if shadow is not None and hasattr(shadow, "unreported"):
@@ -232,6 +240,9 @@ class FusedAdam(torch.optim.Optimizer):
             m.copy_(e["exp_avg"].to(m.device)); v.copy_(e["exp_avg_sq"].to(v.device))
             e["exp_avg"], e["exp_avg_sq"] = keep[id(p)]
         self.dev_state[4] = step
+        for *_, shadow, _ in self.items:                      # loaded moments may be non-zero anywhere: nothing is skippable
+            if shadow is not None and hasattr(shadow, "mark_all_touched"):
+                shadow.mark_all_touched()
         self._lr_host = None                                  # group learning rates came with the checkpoint
         self.sync_lr()
         if scaler is not None:

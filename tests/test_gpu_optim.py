@@ -275,3 +275,49 @@ def test_ema_matches_torch_ema_semantics():
     sd = ema.state_dict()
     e2 = EMA(net.parameters(), decay=0.5); e2.load_state_dict(sd)
     assert e2.num_updates == 5 and all(torch.equal(a_, b_) for a_, b_ in zip(e2.shadow_params, ema.shadow_params))
+
+
+def test_touched_lines_only_update_is_exact():
+    """the binned grid backward keeps a bitmap of the 64-byte table lines it ever stored a gradient in; FusedAdam (weight_decay 0)
+    neither reads nor writes the other lines -- their gradient and both Adam moments are zero, so torch.optim.Adam would rewrite
+    the same values.  Same model, rays and targets with and without the bitmap: identical parameters, moments and shadow after
+    several steps; untouched lines exist (the test would be vacuous otherwise) and a checkpoint load turns every bit on"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    bits = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(DEV)
+    results = []
+    for use_bitmap in (True, False):
+        net = small_net(3)
+        r = NeRFRenderer(net, bound=1).to(DEV)
+        r.density_bitfield = bits
+        net.train()
+        opt = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, init_scale=128.0)
+        sh = net.encoder.shadow
+        assert sh.touched_lines is not None
+        if not use_bitmap:
+            sh.touched_lines = None                        # the plain update of every entry
+            opt._args = None
+        for it in range(5):
+            o, d = S.lego_like_rays(512, seed=10 + it)
+            o, d = torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV)
+            gt = torch.rand(512, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(it))
+            with torch.autocast("cuda", dtype=torch.float16):
+                res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
+                loss = torch.nn.functional.mse_loss(res["image"], gt)
+            opt.scale(loss).backward()
+            opt.step()
+        item = [x for x in opt.items if x[0] is net.encoder.embeddings][0]
+        results.append((net.encoder.embeddings.detach().clone(), item[1].clone(), item[2].clone(), sh.half.clone(), sh, opt))
+    (p1, m1, v1, h1, sh1, opt1), (p0, m0, v0, h0, _, _) = results
+    assert torch.equal(p1, p0) and torch.equal(m1, m0) and torch.equal(v1, v0) and torch.equal(h1, h0)
+    n_lines = p1.numel() // 16
+    bitsum = sum(bin(int(w) & 0xffffffff).count("1") for w in sh1.touched_lines.cpu().tolist())
+    assert 0 < bitsum < n_lines                              # some lines touched, some never
+    # every line that holds a non-zero second moment is marked
+    nz = (v1.view(-1, 16) != 0).any(dim=1).cpu().numpy()
+    words = np.array(sh1.touched_lines.cpu().tolist(), dtype=np.int64) & 0xffffffff
+    marked = ((words[np.arange(n_lines) >> 5] >> (np.arange(n_lines) & 31)) & 1).astype(bool)
+    assert not (nz & ~marked).any()
+    opt1.load_state_dict(opt1.state_dict())
+    assert int((sh1.touched_lines != -1).sum()) == 0
