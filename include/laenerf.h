@@ -305,8 +305,10 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
  * lae_adam_*) and leave the table out of lae_adam_check.  Needs the binned pipeline on every level: D = 3, C = 2,
  * offsets_host given, every level <= 2^21 entries, B <= 2^24 (LAE_EINVAL otherwise).
  * touched_lines (may be NULL; fp16 only, same conditions): bitmap with one bit per 8 table entries (bit k of word w = entries
- * 8 * (32 w + k) ... + 7, i.e. one 64-byte line of the fp32 table); the call sets the bits of the lines it stores a gradient in.
- * lae_adam_apply_multi skips lines whose bit was never set (their gradient and both Adam moments are exactly zero). */
+ * 8 * (32 w + k) ... + 7, i.e. one 64-byte line of the fp32 table); the counting half of the call sets the bits of the lines
+ * that hold a corner of a cell some sample lies in (a superset of the lines that receive a non-zero gradient).
+ * lae_adam_apply_multi skips lines whose bit was never set (their gradient and both Adam moments are exactly zero).  With
+ * the two-call form the bitmap goes to lae_grid_encode_backward_plan (the counting half), not to _planned. */
 
 /* MI355X-native: the binned backward (D = 3, C = 2) in two halves.  Its first half -- the bookkeeping of a counting
  * sort: items per (level, 1024 samples, table partition), their scans -- depends on the sample positions only,
@@ -318,14 +320,18 @@ LAE_API int lae_grid_encode_backward_ex(const void* grad, const float* inputs, c
  * the kernels address the batch with 32-bit byte offsets); lae_grid_encode_backward itself takes any B and falls back to its
  * global-atomic kernel above that size. */
 LAE_API uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L);
+/* 32-bit words of a touched_lines bitmap for a table of n_entries (= offsets[L]) entries: the line bits (+ slack) followed by
+ * one "every line of level l is marked" word per level, which the counting pass sets and then stops marking that level.
+ * The caller zero-fills the buffer once; filling it with ones means "skip nothing". */
+LAE_API uint64_t lae_grid_touched_lines_words(uint64_t n_entries);
 LAE_API int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                   float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                  float in_shift, float in_scale, void* plan, void* stream);
+                                  float in_shift, float in_scale, const int32_t* offsets_host, void* plan,
+                                  uint32_t* touched_lines, void* stream);
 LAE_API int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings,
                                      uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                                      int align_corners, uint32_t interp, int dtype, float in_shift, float in_scale,
-                                     const int32_t* offsets_host, const void* plan, int32_t* nonfinite_flag, uint32_t* touched_lines,
-                                     void* stream);
+                                     const int32_t* offsets_host, const void* plan, int32_t* nonfinite_flag, void* stream);
 
 /* Bytes of LIBRARY workspace the binned backward (D = 3, C = 2) takes for B samples and L levels when it runs both halves
  * itself: the plan + the item queue, sized for the worst case of 8 items per (sample, level) at 10 bytes each for fp16

@@ -49,8 +49,9 @@ SIGNATURES = {
     "lae_grid_encode_backward_ex": [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32, i32, u32, i32, i32, f32, f32, vp, vp, vp, vp],
     "lae_grid_backward_workspace_bytes": [u32, u32, i32],
     "lae_grid_backward_plan_bytes": [u32, u32],
-    "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp],
-    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp, vp],
+    "lae_grid_touched_lines_words": [u64],
+    "lae_grid_encode_backward_plan": [vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp],
+    "lae_grid_encode_backward_planned": [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, f32, f32, vp, vp, vp, vp],
     "lae_grid_set_backward_mode": [i32],
     "lae_grid_set_forward_mode": [i32],
     "lae_grid_forward_schedule": [vp, u32, f32, u32, u32, vp, vp],
@@ -99,6 +100,7 @@ _RESTYPES = {
     "lae_workspace_bytes": u64,
     "lae_grid_backward_workspace_bytes": u64,
     "lae_grid_backward_plan_bytes": u64,
+    "lae_grid_touched_lines_words": u64,
     "lae_version": ctypes.c_char_p,
     "lae_last_error": ctypes.c_char_p,
 }

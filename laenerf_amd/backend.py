@@ -320,15 +320,19 @@ class _GridEncoder:
             check(lib.lae_grid_encode_forward(*args, stream()), "grid_encode_forward")
 
     @staticmethod
-    def grid_backward_plan(inputs, offsets, B, D, C, L, S, H, gridtype, align_corners, interp, half, in_map=(0.0, 1.0)):
+    def grid_backward_plan(inputs, offsets, B, D, C, L, S, H, gridtype, align_corners, interp, half, in_map=(0.0, 1.0),
+                           offsets_host=None, touched_lines=None):
         """first half of the binned grid backward (positions only: count pass + scans) -> plan tensor for
-        grid_encode_backward(plan=...)"""
+        grid_encode_backward(plan=...).  touched_lines: address of the "ever touched" bitmap this pass maintains (needs
+        offsets_host); the returned tensor carries `.marks_touched` accordingly"""
         need_cuda(inputs, offsets); need_contig(inputs, offsets)
         lib = _lib.load()
         plan = torch.empty(int(lib.lae_grid_backward_plan_bytes(B, L)), dtype=torch.uint8, device=inputs.device)
         check(lib.lae_grid_encode_backward_plan(ptr(inputs), ptr(offsets), B, D, C, L, float(S), H, gridtype, int(bool(align_corners)),
-                                                interp, 1 if half else 0, float(in_map[0]), float(in_map[1]), ptr(plan), stream()),
+                                                interp, 1 if half else 0, float(in_map[0]), float(in_map[1]),
+                                                _host_i32(offsets_host, L + 1), ptr(plan), touched_lines, stream()),
               "grid_backward_plan")
+        plan.marks_touched = touched_lines is not None
         return plan
 
     @staticmethod
@@ -347,10 +351,11 @@ class _GridEncoder:
         if plan is not None:
             if blc or dy_dx is not None:
                 raise RuntimeError("grid_encode_backward: a plan needs level-major gradients and no input gradient")
+            if touched_lines is not None and not getattr(plan, "marks_touched", False):
+                raise RuntimeError("grid_encode_backward: the plan was made without the touched-lines bitmap (pass it to grid_backward_plan)")
             check(lib.lae_grid_encode_backward_planned(ptr(grad), ptr(inputs), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,
                                                        gridtype, int(bool(align_corners)), interp, _dtype_code(grad), float(in_map[0]),
-                                                       float(in_map[1]), _host_i32(offsets_host, L + 1), ptr(plan), nonfinite_flag, touched_lines,
-                                                       stream()),
+                                                       float(in_map[1]), _host_i32(offsets_host, L + 1), ptr(plan), nonfinite_flag, stream()),
                   "grid_encode_backward")
             return
         args = (ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), B, D, C, L, float(S), H,

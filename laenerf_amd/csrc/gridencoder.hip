@@ -517,7 +517,8 @@ template <typename T, bool FILL, bool PLAIN>
 __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     const T* __restrict__ gradT, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
     uint32_t L, LevelScales sc, uint32_t gridtype_, bool align_corners_, uint32_t interp_, uint32_t U, BwdPlan plan,
-    typename BVal<T>::type* __restrict__ qvals, uint16_t* __restrict__ qkeys) {
+    typename BVal<T>::type* __restrict__ qvals, uint16_t* __restrict__ qkeys, uint32_t* __restrict__ touched_,
+    uint32_t* __restrict__ level_full) {
     const uint32_t gridtype = PLAIN ? 0u : gridtype_, interp = PLAIN ? 0u : interp_;
     const bool align_corners = PLAIN ? false : align_corners_;
     using V = typename BVal<T>::type;
@@ -530,7 +531,16 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     __shared__ uint32_t hist[BK_MAX], start[BK_MAX + 1], gbase[FILL ? BK_MAX : 1];
     __shared__ __attribute__((aligned(16))) V s_vals[FILL ? STAGE_CAP : 1];
     __shared__ __attribute__((aligned(16))) uint16_t s_keys[FILL ? STAGE_CAP : 8];
+    extern __shared__ uint32_t s_lines[];                  // count pass with `touched`: line bits of this level, aligned to the global words
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // bit of entry e of this level in the caller's bitmap: (table_off + e) / 8; the LDS copy starts at the bitmap word that
+    // holds the level's first line
+    const uint32_t line_shift = (li.table_off >> 3) & 31u;
+    const uint32_t line_words = (line_shift + ((li.hashmap_size + 7u) >> 3) + 31u) >> 5;
+    // a level all of whose lines are marked has nothing to add: level_full[level] (set below by a block that sees it) switches
+    // the marking of that level off for good (on the bench scene: levels 9-15 after a few steps)
+    uint32_t* __restrict__ touched = (!FILL && touched_ && !level_full[level]) ? touched_ : nullptr;
+    if (!FILL && touched) { for (uint32_t k = tid; k < line_words; k += FILL_THREADS) s_lines[k] = 0u; }
     // a lane walks SPT * SEGS consecutive samples; every segment of SPT samples per lane is a UNIT with its own counter
     // row / queue runs (the staging area holds one unit), the cell a lane is in is carried from segment to segment
     const uint32_t b0 = (chunk * FILL_THREADS + tid) * (SPT * SEGS);
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
 
     // items of the cell cp, one row of x-neighbours (y, z corner) at a time: a PAIR item {counter c0, key k0} when both
     // entries sit in one partition a low-bit xor apart, else two single items {c0, k0}, {c1, k1}
-    struct Rows { uint32_t c0[4], k0[4], c1[4], k1[4]; bool pair[4]; };
+    struct Rows { uint32_t c0[4], k0[4], c1[4], k1[4], i0[4], i1[4]; bool pair[4]; };   // i0 / i1: the two entries of the row (count pass only)
     auto cell_rows = [&](const uint32_t (&cp)[3], Rows& r) {
         const uint32_t lane_copy = lane & (NC - 1);
         if (li.use_hash && li.pow2) {
@@ -564,6 +574,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             for (int yz = 0; yz < 4; yz++) {
                 const uint32_t i0 = (cp[0] ^ ((yz & 1) ? hy1 : hy0) ^ ((yz & 2) ? hz1 : hz0)) & m, i1 = i0 ^ dx;
                 r.c0[yz] = (i0 >> PART_SHIFT) * NC + lane_copy; r.c1[yz] = (i1 >> PART_SHIFT) * NC + lane_copy;
+                r.i0[yz] = i0; r.i1[yz] = i1;
                 r.pair[yz] = pr;
                 r.k0[yz] = (i0 & (PART - 1)) | code;
                 r.k1[yz] = (i1 & (PART - 1)) | (KEY_SINGLE << 12);
@@ -590,6 +601,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             const uint32_t e0 = i0 & (PART - 1), e1 = i1 & (PART - 1), d = e0 ^ e1;
             const bool same_part = (i0 >> PART_SHIFT) == (i1 >> PART_SHIFT) && d != 0;
             r.c0[yz] = (i0 >> PART_SHIFT) * NC + lane_copy; r.c1[yz] = (i1 >> PART_SHIFT) * NC + lane_copy;
+            r.i0[yz] = i0; r.i1[yz] = i1;
             r.pair[yz] = same_part && (d & (d + 1)) == 0;
             r.k0[yz] = e0 | ((r.pair[yz] ? (uint32_t)(__builtin_popcount(d) - 1) : KEY_SINGLE) << 12);
             r.k1[yz] = e1 | (KEY_SINGLE << 12);
@@ -683,6 +695,16 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 cell_rows(cpg, r);
 #pragma unroll
                 for (int yz = 0; yz < 4; yz++) atomicAdd(&hist[r.c0[yz]], 1u);
+                if (touched) {
+                    // "ever touched" bitmap of the caller, one bit per 8 entries (a 64-byte line of the fp32 table): the block
+                    // notes the lines of its cells' corners in LDS (a superset of the lines that get a non-zero gradient is fine)
+#pragma unroll
+                    for (int yz = 0; yz < 4; yz++) {
+                        const uint32_t l0 = line_shift + (r.i0[yz] >> 3), l1 = line_shift + (r.i1[yz] >> 3);
+                        atomicOr(&s_lines[l0 >> 5], 1u << (l0 & 31u));
+                        if (l1 != l0) atomicOr(&s_lines[l1 >> 5], 1u << (l1 & 31u));
+                    }
+                }
                 if (!(r.pair[0] && r.pair[1] && r.pair[2] && r.pair[3])) {
 #pragma unroll
                     for (int yz = 0; yz < 4; yz++) if (!r.pair[yz]) atomicAdd(&hist[r.c1[yz]], 1u);
@@ -704,6 +726,22 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 uint32_t n = 0;
                 for (uint32_t c = 0; c < NC; c++) n += hist[k * NC + c];
                 plan.part_cnt[((size_t)level * BK_MAX + k) * U + u] = n;
+            }
+            if (touched) {                                     // new line bits of this block -> the caller's bitmap (a plain read first)
+                uint32_t* gw = touched + ((li.table_off >> 3) >> 5);
+                const uint32_t n_lines = (li.hashmap_size + 7u) >> 3;
+                bool full = true;
+                for (uint32_t k = tid; k < line_words; k += FILL_THREADS) {
+                    const uint32_t w = s_lines[k], cur = gw[k];
+                    if (w && (cur & w) != w) atomicOr(&gw[k], w);
+                    // bits of word k that belong to this level: [line_shift, line_shift + n_lines) in the level's bit space
+                    const uint32_t lo_bit = k == 0 ? line_shift : 0u;
+                    const uint32_t end = line_shift + n_lines - 32u * k;          // bits of this word below `end` are the level's
+                    uint32_t mask = end >= 32u ? 0xffffffffu : ((1u << end) - 1u);
+                    mask &= ~((1u << lo_bit) - 1u);
+                    full = full && (((cur | w) & mask) == mask);
+                }
+                if (__syncthreads_and(full ? 1 : 0) && tid == 0) level_full[level] = 1u;
             }
             __syncthreads();                                   // hist is zeroed again by the next segment
         } else {
@@ -876,7 +914,7 @@ template <typename T>
 __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
     bool align_corners, BwdPlan plan, const typename BVal<T>::type* __restrict__ qvals, const uint16_t* __restrict__ qkeys,
-    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag, uint32_t* __restrict__ touched) {
+    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag) {
     using V = typename BVal<T>::type;
     constexpr bool HALF = sizeof(T) == 2;
     constexpr uint32_t ACCW = HALF ? 2 * PART : PART;
@@ -1102,19 +1140,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 if (e >= n_ent) break;
                 const long long i0 = (long long)acc64[e], i1 = (long long)acc64[PART + e];
                 const bool bad = (poison[e >> 5] >> (e & 31)) & 1u;
-                const bool writes = !(i0 == 0 && i1 == 0 && !bad);
-                if (touched) {
-                    // the caller's "ever touched" bitmap, one bit per 8 entries (a 64-byte line of the fp32 table): the wave's
-                    // 64 entries are 8 lines, lane j < 8 reports line j (a plain read first: set bits cost no atomic)
-                    const unsigned long long wm = __ballot(writes);
-                    const uint32_t lane_ = tid & 63u;
-                    if (lane_ < 8u && ((wm >> (8u * lane_)) & 0xffull)) {
-                        const uint32_t lg = ((table_off + part_lo + (e - lane_)) >> 3) + lane_;
-                        const uint32_t bit = 1u << (lg & 31u);
-                        if (!(touched[lg >> 5] & bit)) atomicOr(&touched[lg >> 5], bit);
-                    }
-                }
-                if (!writes) continue;
+                if (i0 == 0 && i1 == 0 && !bad) continue;
                 const uint32_t o = oldv[it];               // only writer of this table slice: old + exact sum, rounded ONCE
                 uint32_t r0, r1;
                 if (bad) { r0 = 0x7e00u; r1 = 0x7e00u; }
@@ -1378,7 +1404,8 @@ struct BwdArgs {
     uint32_t gridtype; bool align; uint32_t interp; uint64_t gs_b, gs_l; hipStream_t stream;
     const int32_t* offsets_host = nullptr;
     int32_t* nf_flag = nullptr;                                 // set to 1 when a non-finite table gradient is stored (binned path)
-    uint32_t* touched = nullptr;                                // bit per 8 table entries (one 64-byte line of fp32 pairs): set when a gradient is stored there
+    uint32_t* touched = nullptr;                                // bit per 8 table entries (one 64-byte line of fp32 pairs): set by the count pass
+    uint32_t* touched_full = nullptr;                           // MAX_LEVELS words behind the bitmap: level l is fully marked
 };
 template <typename T, int D, int C>
 static void launch_bwd(const BwdArgs& a) {
@@ -1498,10 +1525,24 @@ static inline size_t bwd_exec_ws_bytes(uint32_t B, uint32_t L) {
 template <typename T>
 static void bwd_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t L, const BwdArgs& a, const BwdPlan& plan) {
     const uint32_t U = bwd_units(B);
+    // the count pass keeps the line bits of its level in LDS when the caller wants its "ever touched" bitmap maintained:
+    // room for the largest level (a.touched implies a.offsets_host and every level <= 2^21 entries, checked by the callers)
+    size_t line_lds = 0;
+    if (a.touched) {
+        uint32_t words = ((1u << 21) >> 3 >> 5) + 2;
+        if (a.offsets_host) {
+            words = 1;
+            for (uint32_t l = 0; l < L; l++) {
+                const uint32_t off = (uint32_t)a.offsets_host[l], size = (uint32_t)(a.offsets_host[l + 1] - a.offsets_host[l]);
+                words = std::max(words, ((((off >> 3) & 31u) + ((size + 7u) >> 3) + 31u) >> 5));
+            }
+        }
+        line_lds = (size_t)words * 4;
+    }
     if (a.gridtype == 0 && !a.align && a.interp == 0)
-        k_bwd_walk<T, false, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
+        k_bwd_walk<T, false, true><<<U / SEGS * L, FILL_THREADS, line_lds, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr, a.touched, a.touched_full);
     else
-        k_bwd_walk<T, false, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr);
+        k_bwd_walk<T, false, false><<<U / SEGS * L, FILL_THREADS, line_lds, a.stream>>>(nullptr, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, nullptr, nullptr, a.touched, a.touched_full);
     k_bwd_scan_units<<<lae::cdiv((size_t)L * BK_MAX, 4), 256, 0, a.stream>>>(offsets, L, U, plan);
     k_bwd_scan_parts<<<1, 1024, 0, a.stream>>>(L * BK_MAX, plan);
 }
@@ -1541,10 +1582,10 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     T* ge = (T*)gemb;
     if (!caller_plan) bwd_plan<T>(inputs, offsets, B, L, a, plan);
     if (a.gridtype == 0 && !a.align && a.interp == 0)
-        k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
+        k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
     else
-        k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys);
-    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag, a.touched);
+        k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
+    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
     // (its blocks return at once for the levels the binned path has handled).
@@ -1561,6 +1602,10 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     }
     return LAE_OK;
 }
+
+// words of the "ever touched" bitmap proper (one bit per 8 entries, + 2 words of slack); MAX_LEVELS words of per-level
+// "fully marked" flags follow it (include/laenerf.h)
+static inline size_t touched_words(const int32_t* offsets_host, uint32_t L) { return ((size_t)offsets_host[L] >> 3 >> 5) + 2; }
 
 // 0 = binned LDS pipeline where available (default), 1 = always the generic global-atomic kernel
 static int g_force_atomic_bwd = 0;
@@ -1588,6 +1633,7 @@ static int grid_backward(const void* grad, const float* inputs, const void* embe
     a.offsets_host = offsets_host;
     a.nf_flag = nf_flag;
     a.touched = touched;
+    if (touched) a.touched_full = touched + touched_words(offsets_host, L);
     a.grad = grad; a.inputs = inputs; a.offsets = offsets; a.gemb = grad_embeddings; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1702,13 +1748,23 @@ uint64_t lae_grid_backward_workspace_bytes(uint32_t B, uint32_t L, int dtype) {
 
 uint64_t lae_grid_backward_plan_bytes(uint32_t B, uint32_t L) { return plan_layout(B, L).bytes; }
 
+uint64_t lae_grid_touched_lines_words(uint64_t n_entries) { return (n_entries >> 3 >> 5) + 2 + MAX_LEVELS; }
+
 int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                   uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float in_shift,
-                                  float in_scale, void* plan, void* stream) {
+                                  float in_scale, const int32_t* offsets_host, void* plan, uint32_t* touched_lines, void* stream) {
     if (B == 0) return LAE_OK;
     if (!inputs || !offsets || !plan) return LAE_ENULL;
     if (D != 3 || C != 2 || L > 32 || B > BWD_MAX_SAMPLES || gridtype > 1 || interp > 1 || (dtype != LAE_F32 && dtype != LAE_F16)) return LAE_EINVAL;
+    if (touched_lines) {                                   // every level must go through this pass (see lae_grid_encode_backward_ex)
+        if (!offsets_host || dtype != LAE_F16 || g_force_atomic_bwd) return LAE_EINVAL;
+        for (uint32_t l = 0; l < L; l++)
+            if (!level_is_binned((uint32_t)(offsets_host[l + 1] - offsets_host[l]))) return LAE_EINVAL;
+    }
     BwdArgs a;
+    a.offsets_host = offsets_host;
+    a.touched = touched_lines;
+    if (touched_lines) a.touched_full = touched_lines + touched_words(offsets_host, L);
     a.grad = nullptr; a.inputs = inputs; a.offsets = offsets; a.gemb = nullptr; a.B = B; a.L = L;
     int rc = fill_scales(a.sc, L, S, H);
     if (rc) return rc;
@@ -1724,10 +1780,10 @@ int lae_grid_encode_backward_plan(const float* inputs, const int32_t* offsets, u
 int lae_grid_encode_backward_planned(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
                                      uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                      uint32_t interp, int dtype, float in_shift, float in_scale, const int32_t* offsets_host,
-                                     const void* plan, int32_t* nonfinite_flag, uint32_t* touched_lines, void* stream) {
+                                     const void* plan, int32_t* nonfinite_flag, void* stream) {
     if (!plan) return LAE_ENULL;
     return grid_backward(grad, inputs, nullptr, offsets, grad_embeddings, B, D, C, L, S, H, nullptr, nullptr, gridtype, align_corners,
-                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan, nonfinite_flag, touched_lines);
+                         interp, dtype, false, stream, in_shift, in_scale, offsets_host, plan, nonfinite_flag, nullptr);
 }
 
 int lae_grid_forward_schedule(const int32_t* offsets_host, uint32_t L, float S, uint32_t H, uint32_t n_chunks, uint32_t* nseg_out,

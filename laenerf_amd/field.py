@@ -66,6 +66,8 @@ class _nerf_field(Function):
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         flag = enc.shadow.flag_for_backward(M) if enc.shadow is not None else None    # the optimizer's found_inf word, or None
         touched = enc.shadow.touched_for_backward(M) if flag is not None else None     # its "ever touched" bitmap, or None
+        if ctx.plan is not None and touched is not None and not getattr(ctx.plan, "marks_touched", False):
+            touched = None                                 # a plan made without the bitmap: nothing was marked
         if enc.shadow is not None and touched is None:
             enc.shadow.mark_all_touched()
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
@@ -109,5 +111,7 @@ def field_backward_plan(x, enc, bound=1):
     if x.shape[0] > (1 << 24):          # beyond the binned pipeline's batch limit (include/laenerf.h): no plan, the backward
         return None                     # then runs whole on the generic path
     in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+    touched = enc.shadow.touched_for_backward(x.shape[0]) if enc.shadow is not None else None     # the optimizer's bitmap, or None
     return _grid.grid_backward_plan(x, enc.offsets, x.shape[0], 3, 2, enc.num_levels, np.log2(enc.per_level_scale), enc.base_resolution,
-                                    enc.gridtype_id, enc.align_corners, enc.interp_id, True, in_map)
+                                    enc.gridtype_id, enc.align_corners, enc.interp_id, True, in_map, offsets_host=enc.offsets_host,
+                                    touched_lines=touched)

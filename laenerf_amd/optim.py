@@ -16,6 +16,7 @@ device; `state_dict()` / `load_state_dict()` are torch.optim.Adam's (`state[i] =
 `param_groups[i]["params"]`), so a checkpoint of the reference's optimizer loads (plus a `scaler` entry).
 """
 import ctypes
+import os
 
 import torch
 
@@ -66,8 +67,9 @@ class FusedAdam(torch.optim.Optimizer):
                 if shadow is not None and isinstance(owner, GridEncoder) and owner.input_dim == 3 and owner.level_dim == 2 \
                         and owner.num_levels <= 32 and int((owner.offsets_host[1:] - owner.offsets_host[:-1]).max()) <= (1 << 21):
                     shadow.nonfinite_flag = self.dev_state.data_ptr() + 8
-                    if weight_decay == 0:             # touched-lines-only update (exact only without weight decay)
-                        shadow.touched_lines = torch.zeros(p.numel() // 16 // 32 + 2, dtype=torch.int32, device=p.device)
+                    if weight_decay == 0 and not os.environ.get("LAE_ADAM_NO_TOUCHED_LINES"):   # touched-lines-only update (exact only without weight decay; the variable is an A/B switch)
+                        n_words = int(_lib.load().lae_grid_touched_lines_words(p.shape[0]))
+                        shadow.touched_lines = torch.zeros(n_words, dtype=torch.int32, device=p.device)
                 elif shadow is not None and isinstance(owner, FFMLP):
                     shadow.nonfinite_flag = self.dev_state.data_ptr() + 8    # the fused head backward reports its weight gradients
         self._scale_view = self.dev_state.view(torch.float32)

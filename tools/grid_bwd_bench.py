@@ -17,8 +17,15 @@ M = xyzs.shape[0]
 grad = (torch.randn(16, M, 2, device=dev) * 1e-2).half()
 ge = torch.zeros(enc.embeddings.shape, dtype=torch.half, device=dev)
 S_ = np.log2(enc.per_level_scale)
+# LAE_BWD_BENCH_TOUCHED=1: with the optimizer's flag word and "ever touched" bitmap, as the training step calls it
+extra = {}
+if os.environ.get("LAE_BWD_BENCH_TOUCHED"):
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    from laenerf_amd import _lib
+    touched = torch.zeros(int(_lib.load().lae_grid_touched_lines_words(enc.embeddings.shape[0])), dtype=torch.int32, device=dev)
+    extra = dict(nonfinite_flag=flag.data_ptr(), touched_lines=touched.data_ptr())
 def run():
-    G.grid_encode_backward(grad, xyzs, None, enc.offsets, ge, M, 3, 2, 16, S_, 16, None, None, 0, False, 0, blc=False, in_map=(1.0, 0.5), offsets_host=enc.offsets_host)
+    G.grid_encode_backward(grad, xyzs, None, enc.offsets, ge, M, 3, 2, 16, S_, 16, None, None, 0, False, 0, blc=False, in_map=(1.0, 0.5), offsets_host=enc.offsets_host, **extra)
 for rep in range(2):
     for _ in range(5): run()
     torch.cuda.synchronize()
