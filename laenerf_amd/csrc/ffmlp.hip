@@ -457,10 +457,16 @@ __device__ __forceinline__ void color_inputs(const float* __restrict__ dirs, siz
 __device__ __forceinline__ void color_inputs(float dx, float dy, float dz, const h4& hq, int g, h4 (&cin)[2]) {
     float o[16], gx[1], gy[1], gz[1];
     sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
+    // the lane keeps components 4g .. 4g + 3.  Every lane evaluates all 16 (~40 instructions) and picks with bit masks:
+    // written as `g == 0 ? o[j] : g == 1 ? ...` the compiler sinks the polynomials into four divergent branches, which a
+    // wave (all four g groups) then runs one after the other -- ~190 of the ~600 instructions per 16-row tile
+    const uint32_t m0 = g == 0 ? 0xffffffffu : 0u, m1 = g == 1 ? 0xffffffffu : 0u, m2 = g == 2 ? 0xffffffffu : 0u,
+                   m3 = g == 3 ? 0xffffffffu : 0u;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const float v = g == 0 ? o[j] : g == 1 ? o[4 + j] : g == 2 ? o[8 + j] : o[12 + j];
-        cin[0][j] = (half_t)v;
+        const uint32_t bits = (__builtin_bit_cast(uint32_t, o[j]) & m0) | (__builtin_bit_cast(uint32_t, o[4 + j]) & m1) |
+                              (__builtin_bit_cast(uint32_t, o[8 + j]) & m2) | (__builtin_bit_cast(uint32_t, o[12 + j]) & m3);
+        cin[0][j] = (half_t)__builtin_bit_cast(float, bits);
     }
     const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[0]), 16, 64));
     cin[1][0] = hq[1]; cin[1][1] = hq[2]; cin[1][2] = hq[3];
