@@ -426,10 +426,22 @@ __device__ __forceinline__ void stage_rows(half_t* dst, int ld, const half_t* __
 // one 64-wide layer on a 16-row tile: acc[mt] = sum_kt W[mt*16+c][kt*16+4g..] * in[kt]
 template <int KT>
 __device__ __forceinline__ void layer64(const half_t* Wl, int ld, const h4 (&in)[KT], int c, int g, f4 (&acc)[4]) {
+    // k-steps outside, the four output tiles inside: four independent accumulators in flight, so consecutive MFMAs never
+    // wait for one another's result (tile by tile the compiler reused one accumulator and padded with s_nop)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-        acc[mt] = mfma_ksteps<KT>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g); },
-                                  in, f4{0, 0, 0, 0});
+    for (int mt = 0; mt < 4; mt++) acc[mt] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int kt = 0; kt + 1 < KT; kt += 2)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const half_t* wr = Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g;
+            acc[mt] = mfma32(*reinterpret_cast<const h4*>(wr), *reinterpret_cast<const h4*>(wr + 16), in[kt], in[kt + 1], acc[mt]);
+        }
+    if constexpr (KT & 1) {                                  // odd tail: one K = 16 step
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+            acc[mt] = mfma16(*reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + (KT - 1) * 16 + 4 * g), in[KT - 1], acc[mt]);
+    }
 }
 // ReLU + fp16 rounding of a 64-wide layer.  round(max(x, 0)) == max(round(x), 0), so the maximum is taken on the packed
 // halves (v_cvt_pk_f16_f32 + v_pk_max_f16: 2 values per instruction; fmaxf on the floats costs a canonicalising
