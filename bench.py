@@ -211,13 +211,20 @@ def frame_workload(args, world, rank, dev, backend_name):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    import hashlib
+    frame_hash = hashlib.sha256(res["image"].cpu().numpy().tobytes()).hexdigest()[:16]
+    hashes = [frame_hash]
     if world > 1:
         tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        hashes = [None] * world
+        dist.all_gather_object(hashes, frame_hash)               # every rank holds the whole frame after the all-gather
     if rank == 0:
         ms = dt / args.steps * 1e3
         print(json.dumps({
+            "frame_sha256_per_rank": hashes, "ranks_hold_the_same_frame": len(set(hashes)) == 1,
+            "gather_bytes_per_rank": int(-(-(-(-H * W // 128)) // world) * 128 * 5 * 4),
             "metric": "Mrays/s, 1920x1080 whole-frame inference render", "value": round(H * W * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
@@ -229,6 +236,47 @@ def frame_workload(args, world, rank, dev, backend_name):
               flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def frame1080(dev, frames=5):
+    """configs[3] on ONE GPU, inside the default line so that the driver times it: the 1920x1080 bonsai-shaped frame of
+    `--workload frame1080` (bound 2, 2 cascades, 6 328 848-entry table, camera inside the box) through
+    dist.render_frame_sharded at W = 1, median of `frames` frames after two warm-ups; plus ONE rank's share of an 8-way split
+    (tiles 0, 8, 16, ...: what each of 8 GPUs would render before the 5.18 MB all-gather) timed alone on this GPU."""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.dist import render_frame_sharded, render_shard
+    net, r = eval_model(dev, bound=2, seed=1234)
+    H, W = 1080, 1920
+    o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    stats = {}
+
+    def render(ro, rd):
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            res = r.render_eval(ro, rd, bg_color=1, max_steps=1024, want_stats=True)
+        stats.update(res["stats"])
+        return res
+
+    def timed(fn):
+        ts = []
+        for it in range(frames + 2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return sorted(ts[2:])[len(ts[2:]) // 2], out
+    t, res = timed(lambda: render_frame_sharded(render, o, d, 0, 1))
+    whole = dict(stats)
+    t8, _ = timed(lambda: render_shard(render, o, d, 0, 8))
+    return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
+            "iterations": whole["iterations"], "samples_through_network": whole["rows"],
+            "Msamples_per_s": round(whole["rows"] / t / 1e6, 1),
+            "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
+            "shard_of_8": {"ms": round(t8 * 1e3, 2), "rays": int(-(-(-(-H * W // 128)) // 8) * 128), "iterations": stats["iterations"],
+                           "note": "rank 0's tiles of an 8-way round-robin split rendered alone on this one GPU"},
+            "gather_bytes_per_rank_at_8": int(-(-(-(-H * W // 128)) // 8) * 128 * 5 * 4),
+            "note": "configs[3]-shaped (mip360/bonsai) 1080p inference frame, fixed eval model (seed 1234), device-resident loop, "
+                    "through dist.render_frame_sharded (W = 1: no exchange); tests/test_gpu_frame1080.py checks the W = 2 / 8 "
+                    "partitions against this frame"}
 
 
 def grid_update(dev):
@@ -778,6 +826,7 @@ def main():
         }
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
+            out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)
         if world == 1 and not args.no_style:
             out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
             out["grid_update"] = grid_update(dev)

@@ -106,10 +106,21 @@ _RESTYPES = {
 }
 
 _lib = None
+ABI_TAG = b"abi3"            # include/laenerf.h LAE_ABI_TAG: the prototypes in SIGNATURES are written against this tag
+
+
+def _abi_of(path):
+    lib = ctypes.CDLL(path)
+    fn = lib.lae_version
+    fn.argtypes, fn.restype = [], ctypes.c_char_p
+    return lib, fn().split()[-1]
 
 
 def load():
-    """dlopen the HIP library (after torch, so its libamdhip64 is the one already mapped)."""
+    """dlopen the HIP library (after torch, so its libamdhip64 is the one already mapped).  The library's ABI tag is compared
+    with the one these prototypes were written against before anything else is called: a stale build is rebuilt once (the
+    in-tree default only; dlopen cannot replace a mapped image, so the fresh build is loaded under a new path name) or
+    refused -- never used with misaligned arguments."""
     global _lib
     if _lib is not None:
         return _lib
@@ -117,7 +128,21 @@ def load():
         raise RuntimeError(
             f"laenerf_amd: HIP library not built ({SO_PATH}); run `python -m laenerf_amd.build` "
             "(there is no CPU fallback)")
-    lib = ctypes.CDLL(SO_PATH)
+    lib, tag = _abi_of(SO_PATH)
+    if tag != ABI_TAG:
+        if os.environ.get("LAE_HIP_LIB"):
+            raise RuntimeError(f"laenerf_amd: {SO_PATH} is ABI {tag.decode()}, this package binds {ABI_TAG.decode()}")
+        from . import build as _build
+        _build.build(force=True)
+        fresh = SO_PATH + f".{os.getpid()}.reload"
+        import shutil
+        shutil.copyfile(SO_PATH, fresh)
+        try:
+            lib, tag = _abi_of(fresh)
+        finally:
+            os.remove(fresh)
+        if tag != ABI_TAG:
+            raise RuntimeError(f"laenerf_amd: rebuilt library is ABI {tag.decode()}, this package binds {ABI_TAG.decode()}")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.argtypes = argtypes

@@ -539,7 +539,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     const uint32_t line_words = (line_shift + ((li.hashmap_size + 7u) >> 3) + 31u) >> 5;
     // a level all of whose lines are marked has nothing to add: level_full[level] (set below by a block that sees it) switches
     // the marking of that level off for good (on the bench scene: levels 9-15 after a few steps)
-    uint32_t* __restrict__ touched = (!FILL && touched_ && !level_full[level]) ? touched_ : nullptr;
+    // The decision is made ONCE per block (thread 0 reads the flag, the block agrees through LDS): blocks of this very launch
+    // set level_full[level], so a per-thread read could split a block's waves between marking and not marking -- mismatched
+    // barrier counts below and uninitialised LDS words ORed into the bitmap.
+    __shared__ uint32_t s_mark;
+    if (!FILL) {
+        if (tid == 0) s_mark = (touched_ && !level_full[level]) ? 1u : 0u;
+        __syncthreads();
+    }
+    uint32_t* __restrict__ touched = (!FILL && s_mark) ? touched_ : nullptr;
     if (!FILL && touched) { for (uint32_t k = tid; k < line_words; k += FILL_THREADS) s_lines[k] = 0u; }
     // a lane walks SPT * SEGS consecutive samples; every segment of SPT samples per lane is a UNIT with its own counter
     // row / queue runs (the staging area holds one unit), the cell a lane is in is carried from segment to segment

@@ -96,7 +96,7 @@ int num_cus() {
 }  // namespace lae
 
 extern "C" {
-const char* lae_version(void) { return "laenerf-hip gfx950 abi1"; }
+const char* lae_version(void) { return "laenerf-hip gfx950 " LAE_ABI_TAG; }
 const char* lae_last_error(void) { return lae::g_err; }
 int lae_free_workspaces(void) { lae::free_workspaces(); return LAE_OK; }
 uint64_t lae_workspace_bytes(int retired) { return (uint64_t)lae::workspace_bytes(retired != 0); }

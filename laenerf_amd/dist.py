@@ -6,11 +6,22 @@ and ONE all-gather (RCCL over xGMI; gloo in the CPU tests) of the [n_shard, 5] f
 weights_sum) rebuilds the frame on every rank -- the shape of the reference's dormant
 `dist.all_gather(preds)` (nerf/utils.py:1560-1562).  No other collective is on the data path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 TILE = 128
 RS_AG_MIN_ELEMS = 1 << 20      # gradients at least this large go out as reduce-scatter + all-gather (RCCL only)
+# World size 1 needs no exchange and every function below returns early for it -- unless this switch is on: then a
+# one-rank group still goes through EVERY collective call (all_gather_into_tensor, broadcast, reduce_scatter_tensor,
+# all_reduce).  That is how a one-GPU box executes the RCCL entry points, dtypes and stream hand-offs the 8-GPU run uses
+# (tests/test_gpu_rccl.py, tools/rccl_w1_check.py); W = 1 moves no data between devices.
+FORCE_COLLECTIVES = os.environ.get("LAE_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def _exchange(world_size):
+    return world_size > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 def shard_indices(n_rays, rank, world_size, tile=TILE):
@@ -51,7 +62,7 @@ def gather_frame(local_block, n_rays, rank, world_size, tile=TILE, group=None):
     """local_block [n_shard, K] (rows in shard_indices order) -> full [n_rays, K] on every rank: ONE all_gather_into_tensor
     (RCCL over xGMI: every rank ships its block to its 7 peers over 7 links) + the de-interleave."""
     local_block = local_block.contiguous()
-    if world_size == 1:
+    if not _exchange(world_size):
         return deinterleave(local_block.unsqueeze(0), n_rays, 1, tile)
     dev = local_block.device
     rehearsal = local_block.is_cuda and dist.get_backend(group) == "gloo"    # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
@@ -62,12 +73,26 @@ def gather_frame(local_block, n_rays, rank, world_size, tile=TILE, group=None):
     return deinterleave(out.to(dev) if rehearsal else out, n_rays, world_size, tile)
 
 
-def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None):
-    """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict"""
+def render_shard(render_fn, rays_o, rays_d, rank, world_size):
+    """rank `rank`'s part of the frame: its tiles' rays through render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n],
+    weights_sum [n]), packed as the [n_shard, 5] fp32 block (rgb, depth, weights_sum) the all-gather ships"""
     n = rays_o.shape[0]
     idx = shard_indices_device(n, rank, world_size, rays_o.device)          # cached on the device: no host work per frame
     res = render_fn(rays_o[idx], rays_d[idx])
-    block = torch.cat([res["image"].float(), res["depth"].float()[:, None], res["weights_sum"].float()[:, None]], dim=1)
+    return torch.cat([res["image"].float(), res["depth"].float()[:, None], res["weights_sum"].float()[:, None]], dim=1)
+
+
+def assemble_frame(blocks, n_rays, tile=TILE):
+    """the W ranks' blocks (rank order) -> frame dict; what gather_frame does after the all-gather, for callers that hold
+    every block already (one process rendering the W shards one after the other: tests, frames too large for one call)"""
+    full = deinterleave(torch.stack(list(blocks)), n_rays, len(blocks), tile)
+    return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
+
+
+def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None):
+    """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict"""
+    n = rays_o.shape[0]
+    block = render_shard(render_fn, rays_o, rays_d, rank, world_size)
     full = gather_frame(block, n, rank, world_size, group=group)
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
 
@@ -75,11 +100,14 @@ def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None
 @torch.no_grad()
 def broadcast_model_state(module, src=0, group=None):
     """SURVEY.md 8e "replicate model state ... by one ncclBroadcast at load": every parameter and buffer of `module`
-    (hash table, MLP weights, density grid / bitfield, aabb) goes out from rank `src` as ONE flat broadcast per dtype;
-    the fp16 shadow tables a FusedAdam keeps are refreshed lazily through the parameters' version counters."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    (hash table, MLP weights, density grid / bitfield, aabb) goes out from rank `src` as ONE flat broadcast per dtype.
+    The copies go into the parameters THEMSELVES (under no_grad), not into `.data`: `.data` is a separate tensor object with
+    its own version counter, so a write through it leaves `p._version` where it was and the fp16 shadow tables a FusedAdam
+    keeps (TableShadow.table_half compares versions) would go on serving the pre-broadcast table.  Shadows
+    found on the module tree are re-derived here as well, so the result does not hinge on the lazy check."""
+    if not dist.is_available() or not dist.is_initialized() or not _exchange(dist.get_world_size(group)):
         return module
-    tensors = [p.data for p in module.parameters()] + [b for b in module.buffers()]
+    tensors = list(module.parameters()) + [b for b in module.buffers()]
     attrs = [getattr(module, n) for n in ("density_bitfield", "density_grid") if isinstance(getattr(module, n, None), torch.Tensor)]
     seen, uniq = set(), []
     for t in tensors + attrs:
@@ -97,7 +125,13 @@ def broadcast_model_state(module, src=0, group=None):
             flat = buf.to(dev)
         off = 0
         for t in ts:
-            t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()      # copy_ bumps the version -> shadows refresh
+            t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()      # in place on the parameter: bumps its version
+    for m in module.modules():                                                   # fp16 shadows follow the new fp32 values now
+        sh = getattr(m, "shadow", None)
+        if sh is not None and hasattr(sh, "half"):
+            p = getattr(m, "embeddings", None) if hasattr(m, "embeddings") else getattr(m, "weights", None)
+            if p is not None:
+                sh.half.copy_(p.detach()); sh.version = p._version
     return module
 
 
@@ -108,14 +142,16 @@ def broadcast_model_state(module, src=0, group=None):
 # parameters = 24.5 MB in the fp16 accumulator FusedAdam owns), so it goes out as ONE flat all-reduce per dtype: on
 # 8 MI355X, RCCL runs a ring/tree over the xGMI links (7 x ~153 GB/s per GPU): 2 * 7/8 * 24.5 MB / link rate ~ 0.3 ms,
 # i.e. comparable to the 0.5 ms step itself -- which is why the default bench mode keeps independent replicas.
-# NOTE: the RCCL branches of this file have never executed (no multi-GPU node was available to any round; the CPU tests
-# rehearse the control flow over gloo, whose all-reduce stands in for reduce-scatter + all-gather).
+# RCCL status: every collective of this file has executed on RCCL with a one-rank group on the one-GPU box
+# (tests/test_gpu_rccl.py: all_gather_into_tensor, broadcast, reduce_scatter_tensor + all_gather_into_tensor on fp16,
+# all_reduce on fp32); no multi-GPU node was available to any round, the CPU tests rehearse W = 2 over gloo (whose
+# all-reduce stands in for reduce-scatter + all-gather).
 def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20):
     """in place: every tensor becomes the mean over the ranks.  Tensors are packed by dtype into flat buckets of at most
     `bucket_bytes` (one all-reduce each); fp16 payloads are reduced in fp16 (sum of W values scaled by 1/W first, so the
     reduction cannot overflow where the local gradients did not)."""
     world_size = dist.get_world_size(group) if world_size is None else world_size
-    if world_size == 1:
+    if not _exchange(world_size):
         return tensors
     by_dtype = {}
     for t in tensors:
@@ -125,6 +161,9 @@ def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20)
         buckets = []
         for t in ts:
             nbytes = t.numel() * t.element_size()
+            if t.numel() >= RS_AG_MIN_ELEMS and t.is_contiguous():
+                buckets.append([t])                            # a table gradient travels alone, in place: never concatenated
+                continue
             if bucket and size + nbytes > bucket_bytes:
                 buckets.append(bucket); bucket, size = [], 0
             bucket.append(t); size += nbytes
@@ -139,6 +178,8 @@ def allreduce_mean_(tensors, world_size=None, group=None, bucket_bytes=64 << 20)
                 # the table gradient: reduce-scatter, then all-gather -- every rank owns 1/W of the sum in
                 # between (where a sharded optimizer step would sit); each phase moves (W-1)/W of the payload over the 7
                 # xGMI links at once.  Padded to a multiple of W; smaller payloads stay one all-reduce (latency bound).
+                # (FusedAdam's accumulators are flat stores whose length divides by every W <= 8 -- allreduce_gradients hands
+                # the whole store over -- so `pad` is 0 on that path and nothing is copied)
                 pad = (-flat.numel()) % world_size
                 work = torch.cat([flat, flat.new_zeros(pad)]) if pad else flat
                 shard = torch.empty(work.numel() // world_size, dtype=work.dtype, device=work.device)
@@ -169,7 +210,9 @@ def allreduce_gradients(optimizer, world_size=None, group=None):
             if hasattr(shadow, "unreported"):
                 shadow.unreported = True                     # the reduced sum may overflow: the optimizer scans the table again
                 shadow.mark_all_touched()                    # entries other ranks touched arrive through the reduction
-            grads.append(shadow.grad_half)
+            # the accumulator's backing store, zero-padded to a multiple of 840 elements (every W <= 8 divides it): the
+            # reduce-scatter needs equal shards and must not copy 24.5 MB per step to get them
+            grads.append(getattr(shadow, "grad_store", shadow.grad_half))
         elif p.grad is not None:
             grads.append(p.grad)
     return allreduce_mean_(grads, world_size, group)

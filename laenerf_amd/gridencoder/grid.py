@@ -83,7 +83,11 @@ class TableShadow:
 
     def __init__(self, embeddings):
         self.half = embeddings.detach().to(torch.half).contiguous()
-        self.grad_half = torch.zeros_like(self.half)
+        # the accumulator is a view of a flat store padded (with zeros that stay zero) to a multiple of 840 = lcm(1..8)
+        # elements: a data-parallel reduce-scatter over any W <= 8 ranks takes the store as it is (dist.allreduce_gradients)
+        n = self.half.numel()
+        self.grad_store = torch.zeros((n + 839) // 840 * 840, dtype=torch.half, device=self.half.device)
+        self.grad_half = self.grad_store[:n].view_as(self.half)
         self.version = embeddings._version
         # FusedAdam's found_inf word (device address) once the optimizer has adopted the table and every level goes through
         # the binned backward: that backward then reports the non-finite values it stores itself, and the optimizer leaves

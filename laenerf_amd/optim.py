@@ -123,7 +123,21 @@ class FusedAdam(torch.optim.Optimizer):
         if cur != self._lr_host:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FusedAdam: a learning rate changed inside a stream capture; call sync_lr() outside the capture")
-            self.lrs.copy_(torch.tensor(cur, dtype=torch.float32))
+            # staged through pinned host memory, asynchronously on the current stream: the reference's per-iteration LambdaLR
+            # (main_nerf.py:239-245) changes the rate EVERY step, and a pageable host-to-device copy would block the host each
+            # time.  Two alternating staging buffers + an event: a buffer is rewritten only after the copy that
+            # read it has finished.
+            st = self.__dict__.setdefault("_lr_stage", {"bufs": [torch.empty(len(cur), dtype=torch.float32).pin_memory() for _ in range(2)],
+                                                        "evs": [None, None], "k": 0})
+            k = st["k"]
+            if st["evs"][k] is not None:
+                st["evs"][k].synchronize()
+            st["bufs"][k].copy_(torch.tensor(cur, dtype=torch.float32))
+            self.lrs.copy_(st["bufs"][k], non_blocking=True)
+            ev = st["evs"][k] or torch.cuda.Event()
+            ev.record()
+            st["evs"][k] = ev
+            st["k"] = 1 - k
             self._lr_host = cur
 
     def sync_shadows(self):
@@ -136,7 +150,11 @@ class FusedAdam(torch.optim.Optimizer):
                 shadow.version = p._version
 
     def zero_grad(self, set_to_none=False):
-        """gradients are zeroed by step(); provided for Trainer code that calls it anyway"""
+        """gradients are zeroed by step(); provided for Trainer code that calls it anyway.  Also clears the found_inf word:
+        the binned grid backward and the fused head backward OR it at BACKWARD time, so a backward that overflowed and was
+        then discarded (zero_grad without a step: dropped batch, accumulation restart) must not make the next, clean step
+        be skipped.  Inside a stream capture the clear becomes part of the graph."""
+        self.dev_state[2:3].zero_()
         for p, _, _, shadow, _ in self.items:
             if shadow is not None:
                 shadow.grad_half.zero_()

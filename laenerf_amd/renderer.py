@@ -277,7 +277,7 @@ class NeRFRenderer(nn.Module):
                 and torch.get_autocast_dtype("cuda") == torch.half)
 
     def _render_frame(self, rays_o, rays_d, grid, edit_bitfield, bg_color, perturb, dt_gamma, max_steps, T_thresh, scale_depth,
-                      want_stats=False, row_budget=0):
+                      want_stats=False, row_budget=0, max_n_step=8):
         m = self.model
         enc, sn, cn = m.encoder, m.sigma_net, m.color_net
         table = enc.shadow.table_half(enc.embeddings) if enc.shadow is not None else enc.embeddings.detach().to(torch.half)
@@ -288,7 +288,8 @@ class NeRFRenderer(nn.Module):
                                         self.grid_size, table, enc.offsets, enc.per_level_scale, enc.base_resolution, ws, wc,
                                         edit_bitfield=edit_bitfield, gridtype_id=enc.gridtype_id, align_corners=enc.align_corners,
                                         interp_id=enc.interp_id, density_scale=self.density_scale, dt_gamma=dt_gamma,
-                                        max_steps=max_steps, T_thresh=T_thresh, row_budget=row_budget, noises=noises,
+                                        max_steps=max_steps, T_thresh=T_thresh, max_n_step=max_n_step, row_budget=row_budget,
+                                        noises=noises,
                                         bg_color=bg_color, scale_depth=scale_depth, want_stats=want_stats,
                                         offsets_host=getattr(enc, "offsets_host", None))
 
@@ -308,7 +309,7 @@ class NeRFRenderer(nn.Module):
     @torch.no_grad()
     def render_eval(self, rays_o, rays_d, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4,
                     scale_depth=True, dens_grid=None, device_compaction=True, frame_loop=True, want_stats=False, row_budget=0,
-                    image_hw=None, tile_hw=(8, 4)):
+                    image_hw=None, tile_hw=(8, 4), max_n_step=8):
         if image_hw is not None and rays_o.numel() == 3 * image_hw[0] * image_hw[1] and image_hw[0] % tile_hw[0] == 0 and \
                 image_hw[1] % tile_hw[1] == 0 and not (torch.is_tensor(bg_color) and bg_color.numel() > 3):
             # the rays are the pixels of one H x W image in scanline order: render them tile by tile (neighbouring rays
@@ -316,19 +317,23 @@ class NeRFRenderer(nn.Module):
             # 800x800 bench frame) and hand the per-ray results back in the caller's order
             idx, inv = self._tile_perm(image_hw[0], image_hw[1], tile_hw[0], tile_hw[1], rays_o.device)
             res = self.render_eval(rays_o.reshape(-1, 3)[idx], rays_d.reshape(-1, 3)[idx], bg_color, perturb, dt_gamma, max_steps,
-                                   T_thresh, scale_depth, dens_grid, device_compaction, frame_loop, want_stats, row_budget)
+                                   T_thresh, scale_depth, dens_grid, device_compaction, frame_loop, want_stats, row_budget,
+                                   max_n_step=max_n_step)
             return {k: (v[inv] if torch.is_tensor(v) and v.shape[:1] == inv.shape else v) for k, v in res.items()}
         """frame_loop=True (default, when the model is the default architecture under fp16 autocast): the whole loop runs
         as ONE backend call with its state on the device (lae_render_frame).  frame_loop=False: the reference's loop,
         operator by operator, with one host read of n_alive per iteration.  row_budget (frame loop only): rows per
-        iteration, 0 = N as in the reference (`n_step = max(min(N // n_alive, 8), 1)`, renderer.py:363)."""
+        iteration, 0 = N as in the reference (`n_step = max(min(N // n_alive, 8), 1)`, renderer.py:363).  max_n_step: the 8 of
+        that rule; with 1 every iteration takes ONE sample per alive ray, so a ray's result no longer depends on how many
+        other rays share the call (the reference's schedule ties `rays_t` rounding to N: a sharded frame differs from the
+        whole one by <= 1e-5; with max_n_step=1 the two are the same bits, tests/test_gpu_frame1080.py)."""
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         grid = self.density_bitfield if dens_grid is None else dens_grid
         N, device = rays_o.shape[0], rays_o.device
         if frame_loop and self._frame_loop_ok(rays_o):
             return self._render_frame(rays_o, rays_d, grid, None, bg_color, perturb, dt_gamma, max_steps, T_thresh, scale_depth,
-                                      want_stats, row_budget)
+                                      want_stats, row_budget, max_n_step)
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
         weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
         depth = torch.zeros(N, dtype=torch.float32, device=device)
@@ -338,7 +343,7 @@ class NeRFRenderer(nn.Module):
         rays_t = nears.clone()
         step = 0
         while step < max_steps and n_alive > 0:
-            n_step = max(min(N // n_alive, 8), 1)                                    # renderer.py:363
+            n_step = max(min(N // n_alive, max_n_step), 1)                           # renderer.py:363 (max_n_step = 8)
             xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
                                                         grid, self.cascade, self.grid_size, nears, fars, 128,
                                                         perturb if step == 0 else False, dt_gamma, max_steps)

@@ -35,6 +35,11 @@ def test_python_binding_table_matches_header(hip_lib):
 
 def test_version_and_no_compute_needed(hip_lib):
     assert hip_lib.lae_version().startswith(b"laenerf-hip gfx950")
+    # the ABI tag: header, library and binding agree (a stale .so behind newer prototypes would misalign arguments silently;
+    # _lib.load() compares before the first call and rebuilds or raises)
+    from laenerf_amd import _lib
+    hdr = re.search(r'#define\s+LAE_ABI_TAG\s+"(\w+)"', open(os.path.join(ROOT, "include", "laenerf.h")).read()).group(1)
+    assert hip_lib.lae_version().split()[-1] == _lib.ABI_TAG == hdr.encode()
     # scratch-size helpers are pure host functions
     assert hip_lib.lae_march_rays_train_scratch_bytes(4096) >= 4 * 2 * 4096
     assert hip_lib.lae_compact_scratch_bytes(1000) >= 4000

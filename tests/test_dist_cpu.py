@@ -71,7 +71,11 @@ def _bcast_worker(rank, world, port, ret):
     m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
     m.register_buffer("bits", torch.randint(0, 255, (64,), dtype=torch.uint8))
     m.density_bitfield = torch.randint(0, 255, (32,), dtype=torch.uint8)
+    versions = [p._version for p in m.parameters()]
     broadcast_model_state(m, src=0)
+    # the copies land in the parameters themselves: their version counters move, which is what the fp16 shadow tables of a
+    # FusedAdam watch (a copy through `.data` leaves `_version` alone -- ADVICE r2)
+    assert all(p._version > v for p, v in zip(m.parameters(), versions))
     torch.manual_seed(100)
     ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
     ref_bits = torch.randint(0, 255, (64,), dtype=torch.uint8)
@@ -131,3 +135,38 @@ def test_dp_gradient_allreduce_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert ret[0] and ret[1]
+
+
+def _forced_w1_worker(port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LAE_DIST_FORCE_COLLECTIVES="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from laenerf_amd import dist as D
+    assert D.FORCE_COLLECTIVES
+    seen = []
+    for name in ("all_gather_into_tensor", "all_reduce", "broadcast"):
+        fn = getattr(dist, name)
+        setattr(dist, name, (lambda f, n: (lambda *a, **k: (seen.append(n), f(*a, **k))[1]))(fn, name))
+    n = 1000
+    idx = D.shard_indices(n, 0, 1).clamp(min=0)
+    full = D.gather_frame(torch.stack([idx.float(), idx.float() * 3], 1), n, 0, 1)
+    ok = bool(torch.equal(full[:, 0], torch.arange(n).float()) and torch.equal(full[:, 1], torch.arange(n).float() * 3))
+    ts = [torch.randn(4000).half(), torch.randn(33)]
+    ref = [t.clone() for t in ts]
+    D.allreduce_mean_(ts, 1)
+    ok &= all(torch.equal(a, b) for a, b in zip(ts, ref))            # the mean over one rank is the identity, bit for bit
+    m = torch.nn.Linear(3, 2)
+    w = m.weight.detach().clone()
+    D.broadcast_model_state(m, src=0)
+    ok &= bool(torch.equal(m.weight, w))
+    ret[0] = ok and set(seen) == {"all_gather_into_tensor", "all_reduce", "broadcast"}
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_with_one_rank():
+    """LAE_DIST_FORCE_COLLECTIVES=1: a one-rank group still goes through every collective call (how the one-GPU box executes
+    the RCCL entry points, tests/test_gpu_rccl.py); here over gloo"""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_forced_w1_worker, args=(29500 + (os.getpid() + 999) % 2000, ret))
+    p.start(); p.join(120)
+    assert p.exitcode == 0 and ret[0]

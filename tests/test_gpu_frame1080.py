@@ -1,0 +1,148 @@
+"""-m gpu: BASELINE configs[3] -- mip360/bonsai-shaped 1920x1080 frame (scripts/configs_mip360/bonsai.sh: bound 2 -> 2 cascades,
+512 KiB bitfield, 6 328 848-entry table, camera inside the box), rays sharded in 128-ray tiles (laenerf_amd/dist.py; the
+reference's dormant all_gather(preds), nerf/utils.py:1555-1570) around the inference loop of nerf/renderer.py:335-387.
+
+What can be bit-identical and what cannot: the reference's loop takes `n_step = max(min(N // n_alive, 8), 1)` samples per
+ray and iteration, N = the rays of THE CALL, and `rays_t` is re-rounded at every iteration boundary (composite_rays adds the
+deltas up again, raymarching.cu:985-1034).  A shard is a call with N / W rays, so its boundaries fall elsewhere and a ray's
+result may move by rounding -- under the reference's own loop as much as here.  With one sample per iteration (max_n_step=1)
+a ray's arithmetic does not depend on its neighbours: there the W-way partitions must reproduce the whole frame BIT FOR BIT,
+which pins the sharding machinery (tile deal, padding rows, block layout, de-interleave) exactly; on the reference schedule
+the partitions are asserted within 1e-5 (north_star: 1e-4 RGB)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from gpu_util import DEV, N, T
+
+pytestmark = pytest.mark.gpu
+
+H, W = 1080, 1920
+
+
+@pytest.fixture(scope="module")
+def bonsai():
+    import bench
+    from laenerf_amd import synthetic as S
+    net, r = bench.eval_model(torch.device(DEV), bound=2, seed=1234)
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)            # densities over orders of magnitude: rays end at different depths
+    assert r.cascade == 2 and r.density_bitfield.numel() == 2 * 128 ** 3 // 8 and net.encoder.embeddings.shape[0] == 6328848
+    o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
+    return net, r, T(o), T(d)
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+def _render(r, **kw):
+    def fn(ro, rd):
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            return r.render_eval(ro, rd, bg_color=1, max_steps=1024, **kw)
+    return fn
+
+
+def test_frame1080_partitions_reproduce_the_whole_frame_bit_for_bit(bonsai):
+    from laenerf_amd.dist import assemble_frame, render_frame_sharded, render_shard
+    net, r, o, d = bonsai
+    fn = _render(r, max_n_step=1)
+    whole = fn(o, d)
+    assert float((whole["weights_sum"] > 0).float().mean()) > 0.2
+    one = render_frame_sharded(fn, o, d, 0, 1)                 # W = 1 through the public entry point
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(_bits(one[k]), _bits(whole[k])), k
+    for world in (2, 8):
+        blocks = [render_shard(fn, o, d, rank, world) for rank in range(world)]       # the W ranks, one after the other
+        assert len({b.shape for b in blocks}) == 1 and blocks[0].shape[1] == 5        # equal shards (all-gather requirement)
+        full = assemble_frame(blocks, H * W)
+        for k in ("image", "depth", "weights_sum"):
+            assert torch.equal(_bits(full[k]), _bits(whole[k])), (world, k)
+
+
+def test_frame1080_partitions_on_the_reference_schedule(bonsai):
+    from laenerf_amd.dist import assemble_frame, render_shard
+    net, r, o, d = bonsai
+    fn = _render(r, want_stats=True)
+    whole = fn(o, d)
+    assert whole["stats"]["rows"] >= H * W and 1 <= whole["stats"]["iterations"] <= 1024
+    hit = N(whole["weights_sum"]) > 0
+    for world in (2, 8):
+        full = assemble_frame([render_shard(fn, o, d, rank, world) for rank in range(world)], H * W)
+        assert np.abs(N(full["image"]) - N(whole["image"])).max() <= 1e-5
+        assert np.abs(N(full["weights_sum"]) - N(whole["weights_sum"])).max() <= 1e-5
+        assert np.abs(N(full["depth"])[hit] - N(whole["depth"])[hit]).max() <= 1e-5
+        assert np.array_equal(np.isnan(N(full["depth"])), np.isnan(N(whole["depth"])))
+        same = (_bits(full["image"]) == _bits(whole["image"])).all(dim=1).float().mean().item()
+        assert same > 0.9                                      # the re-rounding touches few rays
+
+
+def test_frame1080_subset_against_the_oracle_loop(bonsai, O):
+    """512 pixels of the frame as their own call (the reference's loop on N = 512) against the oracle's march / encode / MLP /
+    composite driven by the same schedule: schedule and row counts exact, values within the fp16-MLP tolerance"""
+    net, r, o, d = bonsai
+    net.encoder.embeddings.data = net.encoder.embeddings.data.half().float()
+    n = 512
+    sel = torch.linspace(0, H * W - 1, n, device=DEV).long()
+    os_, ds_ = o[sel].contiguous(), d[sel].contiguous()
+    with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+        got = r.render_eval(os_, ds_, bg_color=1, max_steps=1024, T_thresh=1e-4, want_stats=True)
+    on, dn, bits = N(os_), N(ds_), N(r.density_bitfield)
+    nears, fars = O.near_far_from_aabb(on, dn, [-2, -2, -2, 2, 2, 2], 0.2)
+    th = O.to_f16_bits(N(net.encoder.embeddings))
+    ws_h, wc_h = O.to_f16_bits(N(net.sigma_net.weights)), O.to_f16_bits(N(net.color_net.weights))
+    offs = N(net.encoder.offsets)
+    wsum, depth, image = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    alive, rays_t = np.arange(n, dtype=np.int32), nears.copy()
+    step, rows, iters = 0, 0, 0
+    while step < 1024 and alive.size > 0:
+        n_alive = alive.size
+        n_step = max(min(n // n_alive, 8), 1)
+        xyzs, dirs, deltas = O.march_rays(n_alive, n_step, alive, rays_t, on, dn, 2.0, bits, 2, 128, nears, fars,
+                                          np.zeros(n_alive, np.float32))[:3]
+        m = n_alive * n_step
+        pad = (-m) % 128
+        x01 = ((xyzs[:m] + np.float32(2)) * np.float32(0.25)).astype(np.float32)
+        enc, _ = O.grid_encode_forward(x01, th, offs, net.encoder.per_level_scale, 16, f16=True, out_blc=True)
+        h, _ = O.ffmlp_forward(np.concatenate([enc, np.zeros((pad, 32), np.uint16)]), ws_h, 32, 16, 64, 2)
+        hf = O.from_f16_bits(h)[:m]
+        sigma = np.exp(hf[:, 0]).astype(np.float32)
+        sh, _ = O.sh_encode_forward(dirs[:m], 4)
+        cin = O.to_f16_bits(np.concatenate([sh, hf[:, 1:], np.zeros((m, 1), np.float32)], 1))
+        oc, _ = O.ffmlp_forward(np.concatenate([cin, np.zeros((pad, 32), np.uint16)]), wc_h, 32, 16, 64, 3)
+        rgb = (1 / (1 + np.exp(-O.from_f16_bits(oc)[:m, :3]))).astype(np.float32)
+        O.composite_rays(n_alive, n_step, alive, rays_t, sigma, rgb, deltas[:m], wsum, depth, image, 1e-4)
+        alive = alive[alive >= 0]
+        step += n_step; rows += m; iters += 1
+    image = image + (1 - wsum)[:, None]
+    assert got["stats"]["iterations"] == iters and got["stats"]["rows"] == rows
+    assert (wsum > 0).mean() > 0.2
+    assert np.abs(N(got["weights_sum"]) - wsum).max() < 3e-3
+    assert np.abs(N(got["image"]) - image).max() < 3e-3
+    hit = wsum > 0
+    dref = np.clip(depth - nears, 0, None)[hit] / (fars - nears)[hit]
+    assert np.abs(N(got["depth"])[hit] - dref).max() < 3e-3
+
+
+def test_frame1080_two_ranks_in_fresh_processes_hold_the_same_frame():
+    """`bench.py --workload frame1080` as the driver launches it for N = 2 (torch.distributed.run, one process per rank); on
+    this one-GPU box both ranks use cuda:0 and the exchange goes over gloo (LAE_BENCH_DIST_BACKEND / LAE_BENCH_SINGLE_DEVICE).
+    Fresh child processes: nothing is exec'ed from this (GPU-initialised) process."""
+    env = dict(os.environ, LAE_BENCH_DIST_BACKEND="gloo", LAE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() + 1080) % 2000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "frame1080",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["unit"] == "Mrays/s" and j["value"] > 1
+    assert len(j["frame_sha256_per_rank"]) == 2 and j["ranks_hold_the_same_frame"] is True
+    assert j["gather_bytes_per_rank"] == 8100 * 128 * 5 * 4
+    assert j["config"]["rays_per_frame"] == H * W and j["config"]["rays_hitting_geometry"] > 0.2
