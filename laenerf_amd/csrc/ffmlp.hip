@@ -1131,6 +1131,398 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
     }
 }
 
+// ---------------------------------------------------------------- fused NeRF head, round-3 form
+// Same arithmetic as k_nerf_head_fwd (results are the same bits), different schedule.  What the round-2 kernel cost
+// (rocprof 24.7 us for 258 k rows = 15 % of the MFMA rate) and what this form does about it:
+//  * prologue: the seven weight matrices were staged through LDS by loops of ONE 8-byte load per thread and iteration, each
+//    waited for before the next was issued (18 serial L2 round trips per workgroup), then read back into 144 registers.
+//    Here every wave loads its A fragments straight from global memory (L2 / L1 resident, 72 independent 8-byte loads in
+//    flight) -- no LDS image, no barrier.
+//  * one 16-row tile per wave iteration is a single dependency chain (MFMA -> cvt / relu -> MFMA ...; DESIGN 4d: the
+//    kernel waited on that chain, not on issue slots).  Here a wave owns FOUR tiles (64 rows) per iteration and every
+//    layer is issued for all four before its activations are needed: four independent chains per wave, one wave per SIMD
+//    (the 144 weight registers + 4 x 32 activation registers fit the 512-register budget of a one-wave SIMD).
+//  * per-row scalar work was replicated by the four lane groups of a 16-row tile (SH polynomials, exp, three sigmoids with
+//    an IEEE division each: ~170 of the ~300 VALU instructions per tile, three quarters of them discarded).  With 64 rows
+//    per iteration lane L does that work for row L once; the values reach / leave the MFMA fragment layout through a
+//    wave-private 3 KB LDS scratch (2 wide stores + 4 fragment reads for the SH block; one masked store per tile + one
+//    read for the density logit and the colour logits).  sigma / rgb leave as one coalesced row-per-lane store.
+struct Head4Scratch { half_t sh[64][16]; float q[64][4]; };             // per wave
+// in-kernel phase stamps for tools/ubench/mlp_probe.hip (compiled in only there): 100 MHz wall clock + shader clock
+#ifdef LAE_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[4096 * 32];
+#define MLP_STAMP(slot, i) do { if ((threadIdx.x & 63) == 0 && (i) < 16) { g_mlp_stamps[(size_t)(slot) * 32 + 2 * (i)] = wall_clock64(); \
+                                g_mlp_stamps[(size_t)(slot) * 32 + 2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define MLP_STAMP(slot, i) do { } while (0)
+#endif
+
+// 64-wide layer on NT tiles from register-resident A fragments; ReLU + fp16 rounding like relu4
+template <int KT, int NT>
+__device__ __forceinline__ void layer64x(const h4 (&w)[4][KT], const h4 (&in)[NT][KT], h4 (&out)[NT][4]) {
+    static_assert(KT % 2 == 0, "k-steps in pairs (K = 32 MFMA)");
+    f4 acc[NT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt += 2)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                acc[t][mt] = mfma32(w[mt][kt], w[mt][kt + 1], in[t][kt], in[t][kt + 1], kt == 0 ? f4{0, 0, 0, 0} : acc[t][mt]);
+#pragma unroll
+    for (int t = 0; t < NT; t++) relu4(acc[t], out[t]);
+}
+template <int NT>
+__device__ __forceinline__ void out16x(const h4 (&w)[4], const h4 (&in)[NT][4], f4 (&o)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) o[t] = mfma32(w[0], w[1], in[t][0], in[t][1], f4{0, 0, 0, 0});
+#pragma unroll
+    for (int t = 0; t < NT; t++) o[t] = mfma32(w[2], w[3], in[t][2], in[t][3], o[t]);
+}
+// A fragments of a row-major [rows, K] weight matrix: fragment (mt, kt) of lane (c, g) = W[16 mt + c][16 kt + 4 g .. + 3]
+template <int MT, int KT>
+__device__ __forceinline__ void load_a_frags(const half_t* __restrict__ W, int c, int g, h4 (&w)[MT][KT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) w[mt][kt] = *reinterpret_cast<const h4*>(W + (size_t)(mt * 16 + c) * (KT * 16) + kt * 16 + 4 * g);
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_nerf_head_fwd4(
+    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
+    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
+    int level_major, const uint32_t* __restrict__ n_rows_dev, uint32_t lm_rows) {
+    constexpr int NT = 4;
+    if (n_rows_dev) n_tiles = min(n_tiles, (*n_rows_dev + 15u) / 16u);
+    if (n_tiles == 0) return;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Head4Scratch* sc = reinterpret_cast<Head4Scratch*>(lds) + w;
+
+    // ---- weights: every wave keeps the A fragments of both nets in registers
+    h4 wS0[4][2], wS1[4][4], wSo[1][4], wC0[4][2], wC1[4][4], wC2[4][4], wCo[1][4];
+    MLP_STAMP(blockIdx.x * 4 + w, 0);
+    load_a_frags<4, 2>(Ws, c, g, wS0);
+    load_a_frags<4, 4>(Ws + 64 * 32, c, g, wS1);
+    load_a_frags<1, 4>(Ws + 64 * 32 + 4096, c, g, wSo);
+    if constexpr (COLOR) {
+        load_a_frags<4, 2>(Wc, c, g, wC0);
+        load_a_frags<4, 4>(Wc + 64 * 32, c, g, wC1);
+        load_a_frags<4, 4>(Wc + 64 * 32 + 4096, c, g, wC2);
+        load_a_frags<1, 4>(Wc + 64 * 32 + 8192, c, g, wCo);
+    }
+
+    const uint32_t n_groups = (n_tiles + NT - 1) / NT;
+    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)w, nwaves = gridDim.x * 4;
+    const uint32_t n_rows = n_tiles * 16u;
+    // software pipeline: the inputs of the wave's next group are requested before the current group's chains
+    h4 xf_n[NT][2] = {};
+    float d_n[3] = {0.f, 0.f, 0.f};
+    auto request = [&](uint32_t grp) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t tile = grp * NT + t;
+            if (tile < n_tiles) load_enc_frags(enc, (size_t)tile * 16 + c, (size_t)lm_rows, g, level_major, xf_n[t]);
+            else { xf_n[t][0] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}; xf_n[t][1] = xf_n[t][0]; }
+        }
+        if constexpr (COLOR) {
+            const uint32_t r = grp * 64u + (uint32_t)lane;
+            if (r < n_rows) { d_n[0] = dirs[3 * (size_t)r]; d_n[1] = dirs[3 * (size_t)r + 1]; d_n[2] = dirs[3 * (size_t)r + 2]; }
+            else { d_n[0] = 0.f; d_n[1] = 0.f; d_n[2] = 0.f; }
+        }
+    };
+    if (wave0 < n_groups) request(wave0);
+    [[maybe_unused]] int stamp_i = 1;
+    for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
+        MLP_STAMP(blockIdx.x * 4 + w, stamp_i); stamp_i++;
+        h4 xf[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { xf[t][0] = xf_n[t][0]; xf[t][1] = xf_n[t][1]; }
+        const float dx = d_n[0], dy = d_n[1], dz = d_n[2];
+        if (grp + nwaves < n_groups) request(grp + nwaves);
+        const uint32_t row_l = grp * 64u + (uint32_t)lane;               // the row this lane does the per-row work for
+        // ---- direction encoding of the 64 rows, one row per lane -> scratch (fragment reads below)
+        if constexpr (COLOR) {
+            float o[16], gx[1], gy[1], gz[1];
+            sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
+            h8 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { lo[j] = (half_t)o[j]; hi[j] = (half_t)o[8 + j]; }
+            *reinterpret_cast<h8*>(&sc->sh[lane][0]) = lo;
+            *reinterpret_cast<h8*>(&sc->sh[lane][8]) = hi;
+        }
+        // ---- sigma net, four tiles side by side
+        h4 a0[NT][4], a1[NT][4];
+        layer64x<2, NT>(wS0, xf, a0);
+        layer64x<4, NT>(wS1, a0, a1);
+        f4 so[NT];
+        out16x<NT>(wSo[0], a1, so);
+        h4 hq[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) hq[t][r] = (half_t)so[t][r];
+            const uint32_t tile = grp * NT + t;
+            if (h_out && tile < n_tiles) *reinterpret_cast<h4*>(h_out + ((size_t)tile * 16 + c) * 16 + 4 * g) = hq[t];
+            if (g == 0) sc->q[t * 16 + c][0] = (float)hq[t][0];         // density logit of row (t, c) -> lane 16 t + c
+        }
+        wave_lds_fence();
+        if (row_l < n_rows) sigmas[row_l] = density_scale * expf(sc->q[lane][0]);        // trunc_exp forward (activation.py:9)
+        if constexpr (!COLOR) { wave_lds_fence(); continue; }
+        // ---- colour net
+        h4 cin[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            cin[t][0] = *reinterpret_cast<const h4*>(&sc->sh[t * 16 + c][4 * g]);
+            const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[t][0]), 16, 64));
+            cin[t][1][0] = hq[t][1]; cin[t][1][1] = hq[t][2]; cin[t][1][2] = hq[t][3];
+            cin[t][1][3] = g == 3 ? (half_t)0.0f : nxt;
+        }
+        layer64x<2, NT>(wC0, cin, a0);
+        layer64x<4, NT>(wC1, a0, a1);
+        layer64x<4, NT>(wC2, a1, a0);
+        f4 co[NT];
+        out16x<NT>(wCo[0], a0, co);
+        wave_lds_fence();                                                // the logit reads above are done
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (g == 0) *reinterpret_cast<f4*>(&sc->q[t * 16 + c][0]) = co[t];
+        wave_lds_fence();
+        if (row_l < n_rows) {
+            const f4 v = *reinterpret_cast<const f4*>(&sc->q[lane][0]);
+            // sigmoid of the fp16 output, rounded to fp16 like torch.sigmoid on a half tensor (network_ff.py:79 under autocast)
+            struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+            F3 out;
+            out.x = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[0])));
+            out.y = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[1])));
+            out.z = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[2])));
+            *reinterpret_cast<F3*>(rgbs + (size_t)row_l * 3) = out;
+        }
+        wave_lds_fence();                                                // scratch is rewritten by the next group
+    }
+    MLP_STAMP(blockIdx.x * 4 + w, 15);
+}
+
+// ---- third form (the one that ships): as k_nerf_head_fwd4, but the A fragments are re-read from a pre-swizzled LDS image
+// (one conflict-free ds_read_b128 per fragment PAIR and four tiles) instead of being held in 144 registers: in-kernel stamps
+// (tools/ubench/mlp_probe.hip) showed that (i) 1024 waves each pulling 37 KB of fragments from L2 take 7.5 us before the first
+// row is touched, and (ii) one wave alone on a SIMD issues an instruction every ~5 cycles whatever it is, so the register-
+// resident form (286 VGPRs, one wave per SIMD) ran a 64-row group in 7300 cycles: the rate of this kernel is instructions
+// per row x issue interval, and the issue interval halves with a second wave on the SIMD.
+// LDS image of a [16 MT, 32 KP] weight matrix: fragment pair (mt, p) of lane l = 16 bytes at ((mt * KP + p) * 64 + l) * 16:
+// halves 0-3 = W[16 mt + c][32 p + 4 g ..], halves 4-7 = W[16 mt + c][32 p + 16 + 4 g ..] (the two operands of one K = 32 MFMA).
+template <int MT, int KP, int NTH>
+__device__ __forceinline__ void stage_swizzled_issue(const half_t* __restrict__ W, uint4 (&buf)[(MT * KP * 64 + NTH - 1) / NTH]) {
+    constexpr int CHUNKS = MT * 16 * KP * 32 / 8;                        // 16-byte chunks of the row-major matrix
+#pragma unroll
+    for (int i = 0; i < (MT * KP * 64 + NTH - 1) / NTH; i++) {
+        const int e = (int)threadIdx.x + i * NTH;
+        if (e < CHUNKS) buf[i] = *reinterpret_cast<const uint4*>(W + (size_t)e * 8);
+    }
+}
+template <int MT, int KP, int NTH>
+__device__ __forceinline__ void stage_swizzled_store(half_t* img, const uint4 (&buf)[(MT * KP * 64 + NTH - 1) / NTH]) {
+    constexpr int CHUNKS = MT * 16 * KP * 32 / 8, K = KP * 32;
+#pragma unroll
+    for (int i = 0; i < (MT * KP * 64 + NTH - 1) / NTH; i++) {
+        const int e = (int)threadIdx.x + i * NTH;
+        if (e < CHUNKS) {
+            const int row = (e * 8) / K, k = (e * 8) % K;                // halves k .. k + 7 of row `row`
+            const int mt = row >> 4, cc = row & 15;
+#pragma unroll
+            for (int piece = 0; piece < 2; piece++) {
+                const int kk = k + 4 * piece, p = kk >> 5, hh = (kk >> 4) & 1, gg = (kk >> 2) & 3;
+                const uint2 v = piece ? uint2{buf[i].z, buf[i].w} : uint2{buf[i].x, buf[i].y};
+                *reinterpret_cast<uint2*>(img + ((size_t)((mt * KP + p) * 64 + gg * 16 + cc)) * 8 + hh * 4) = v;
+            }
+        }
+    }
+}
+struct Head5Img {                                                       // halves
+    static constexpr int S0 = 0, S1 = S0 + 64 * 32, SO = S1 + 64 * 64, C0 = SO + 16 * 64, C1 = C0 + 64 * 32, C2 = C1 + 64 * 64,
+                         CO = C2 + 64 * 64, END = CO + 16 * 64;
+};
+// 64-wide layer on NT tiles, A fragment pairs from the swizzled image
+template <int KP, int NT>
+__device__ __forceinline__ void layer64s(const half_t* img, int lane, const h4 (&in)[NT][2 * KP], h4 (&out)[NT][4]) {
+    f4 acc[NT][4];
+#pragma unroll
+    for (int p = 0; p < KP; p++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const h8 a = *reinterpret_cast<const h8*>(img + ((size_t)((mt * KP + p) * 64 + lane)) * 8);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const h8 b = __builtin_shufflevector(in[t][2 * p], in[t][2 * p + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, p == 0 ? f4{0, 0, 0, 0} : acc[t][mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NT; t++) relu4(acc[t], out[t]);
+}
+template <int NT>
+__device__ __forceinline__ void out16s(const half_t* img, int lane, const h4 (&in)[NT][4], f4 (&o)[NT]) {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const h8 a = *reinterpret_cast<const h8*>(img + ((size_t)(p * 64 + lane)) * 8);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const h8 b = __builtin_shufflevector(in[t][2 * p], in[t][2 * p + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, p == 0 ? f4{0, 0, 0, 0} : o[t], 0, 0, 0);
+        }
+    }
+}
+
+template <bool COLOR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nerf_head_fwd5(
+    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
+    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
+    int level_major, const uint32_t* __restrict__ n_rows_dev, uint32_t lm_rows) {
+    constexpr int NT = 4, NTH = 64 * WAVES;
+    using I = Head5Img;
+    if (n_rows_dev) n_tiles = min(n_tiles, (*n_rows_dev + 15u) / 16u);
+    if (n_tiles == 0) return;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* img = lds;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Head4Scratch* sc = reinterpret_cast<Head4Scratch*>(lds + (COLOR ? I::END : I::C0)) + w;
+    MLP_STAMP(blockIdx.x * WAVES + w, 0);
+    // ---- weights -> swizzled LDS image: every global load of the workgroup in flight before the first LDS store
+    {
+        constexpr int N1 = (4 * 1 * 64 + NTH - 1) / NTH, N2 = (4 * 2 * 64 + NTH - 1) / NTH, NO = (1 * 2 * 64 + NTH - 1) / NTH;
+        uint4 b0[N1], b1[N2], b2[NO];
+        stage_swizzled_issue<4, 1, NTH>(Ws, b0);
+        stage_swizzled_issue<4, 2, NTH>(Ws + 64 * 32, b1);
+        stage_swizzled_issue<1, 2, NTH>(Ws + 64 * 32 + 4096, b2);
+        if constexpr (COLOR) {
+            uint4 c0[N1], c1[N2], c2[N2], c3[NO];
+            stage_swizzled_issue<4, 1, NTH>(Wc, c0);
+            stage_swizzled_issue<4, 2, NTH>(Wc + 64 * 32, c1);
+            stage_swizzled_issue<4, 2, NTH>(Wc + 64 * 32 + 4096, c2);
+            stage_swizzled_issue<1, 2, NTH>(Wc + 64 * 32 + 8192, c3);
+            stage_swizzled_store<4, 1, NTH>(img + I::C0, c0);
+            stage_swizzled_store<4, 2, NTH>(img + I::C1, c1);
+            stage_swizzled_store<4, 2, NTH>(img + I::C2, c2);
+            stage_swizzled_store<1, 2, NTH>(img + I::CO, c3);
+        }
+        stage_swizzled_store<4, 1, NTH>(img + I::S0, b0);
+        stage_swizzled_store<4, 2, NTH>(img + I::S1, b1);
+        stage_swizzled_store<1, 2, NTH>(img + I::SO, b2);
+    }
+    const uint32_t n_groups = (n_tiles + NT - 1) / NT;
+    const uint32_t wave0 = blockIdx.x * WAVES + (uint32_t)w, nwaves = gridDim.x * WAVES;
+    const uint32_t n_rows = n_tiles * 16u;
+    h4 xf_n[NT][2] = {};
+    float d_n[3] = {0.f, 0.f, 0.f};
+    // inputs through buffer descriptors: one 32-bit lane offset per group, the tile / k-step / level strides ride in the
+    // instruction's immediate and scalar offsets (the 64-bit address arithmetic of 16 + 3 plain loads was ~90 instructions
+    // per group), and the hardware range check returns zeros past the end instead of branches around the loads.  Level-major
+    // features: a row past the live rows of plane l reads plane l + 1 (memory of the same buffer; its results are never stored).
+    const __amdgpu_buffer_rsrc_t rs_enc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(enc), 0,
+                                                                            (int)((level_major ? lm_rows : n_rows) * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(COLOR ? dirs : sigmas), 0, (int)(n_rows * 12u), 0x00020000);
+    const uint32_t plane = lm_rows * 4u;                               // bytes per level plane
+    auto request = [&](uint32_t grp) {
+        const uint32_t row0 = grp * 64u;
+        if (level_major) {
+            const uint32_t vo = ((uint32_t)(2 * g) * lm_rows + row0 + (uint32_t)c) * 4u;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++) {
+                    const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(rs_enc, (int)(vo + t * 64u), (int)((8u * kt) * plane), 0);
+                    const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rs_enc, (int)(vo + t * 64u), (int)((8u * kt + 1u) * plane), 0);
+                    xf_n[t][kt] = __builtin_bit_cast(h4, uint2{lo, hi});
+                }
+        } else {
+            const uint32_t vo = (row0 + (uint32_t)c) * 64u + 8u * (uint32_t)g;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int kt = 0; kt < 2; kt++) {
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rs_enc, (int)(vo + t * 1024u + kt * 32u), 0, 0);
+                    xf_n[t][kt] = __builtin_bit_cast(h4, v);
+                }
+        }
+        if constexpr (COLOR) {
+            const uint32_t vo = (row0 + (uint32_t)lane) * 12u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) d_n[k] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_dir, (int)(vo + 4u * k), 0, 0));
+        }
+    };
+    if (wave0 < n_groups) request(wave0);
+    __syncthreads();                                                     // the image is complete
+    [[maybe_unused]] int stamp_i = 1;
+    for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
+        MLP_STAMP(blockIdx.x * WAVES + w, stamp_i); stamp_i++;
+        h4 xf[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { xf[t][0] = xf_n[t][0]; xf[t][1] = xf_n[t][1]; }
+        const float dx = d_n[0], dy = d_n[1], dz = d_n[2];
+        if (grp + nwaves < n_groups) request(grp + nwaves);
+        const uint32_t row_l = grp * 64u + (uint32_t)lane;
+        if constexpr (COLOR) {
+            float o[16], gx[1], gy[1], gz[1];
+            sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
+            h8 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { lo[j] = (half_t)o[j]; hi[j] = (half_t)o[8 + j]; }
+            *reinterpret_cast<h8*>(&sc->sh[lane][0]) = lo;
+            *reinterpret_cast<h8*>(&sc->sh[lane][8]) = hi;
+        }
+        h4 a0[NT][4], a1[NT][4];
+        layer64s<1, NT>(img + I::S0, lane, xf, a0);
+        layer64s<2, NT>(img + I::S1, lane, a0, a1);
+        f4 so[NT];
+        out16s<NT>(img + I::SO, lane, a1, so);
+        h4 hq[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) hq[t][r] = (half_t)so[t][r];
+            const uint32_t tile = grp * NT + t;
+            if (h_out && tile < n_tiles) *reinterpret_cast<h4*>(h_out + ((size_t)tile * 16 + c) * 16 + 4 * g) = hq[t];
+            if (g == 0) sc->q[t * 16 + c][0] = (float)hq[t][0];
+        }
+        wave_lds_fence();
+        if (row_l < n_rows) sigmas[row_l] = density_scale * expf(sc->q[lane][0]);        // trunc_exp forward (activation.py:9)
+        if constexpr (!COLOR) { wave_lds_fence(); continue; }
+        h4 cin[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            cin[t][0] = *reinterpret_cast<const h4*>(&sc->sh[t * 16 + c][4 * g]);
+            const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[t][0]), 16, 64));
+            cin[t][1][0] = hq[t][1]; cin[t][1][1] = hq[t][2]; cin[t][1][2] = hq[t][3];
+            cin[t][1][3] = g == 3 ? (half_t)0.0f : nxt;
+        }
+        layer64s<1, NT>(img + I::C0, lane, cin, a0);
+        layer64s<2, NT>(img + I::C1, lane, a0, a1);
+        layer64s<2, NT>(img + I::C2, lane, a1, a0);
+        f4 co[NT];
+        out16s<NT>(img + I::CO, lane, a0, co);
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (g == 0) *reinterpret_cast<f4*>(&sc->q[t * 16 + c][0]) = co[t];
+        wave_lds_fence();
+        if (row_l < n_rows) {
+            const f4 v = *reinterpret_cast<const f4*>(&sc->q[lane][0]);
+            struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+            F3 out;
+            out.x = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[0])));
+            out.y = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[1])));
+            out.z = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[2])));
+            *reinterpret_cast<F3*>(rgbs + (size_t)row_l * 3) = out;
+        }
+        wave_lds_fence();
+    }
+    MLP_STAMP(blockIdx.x * WAVES + w, 15);
+}
+
 // FFMLP forward for the common shape (64 wide, ReLU, linear output, 32 / 48 / 64 inputs, 1 or 2 hidden GEMMs) with the
 // weights staged in LDS once per workgroup, like k_nerf_head_fwd: the generic k_mlp_fwd re-reads every weight fragment
 // from global memory for every 32-row group (41 us per 100 k rows for the LAENeRF nets against ~10 us here).
@@ -1277,12 +1669,75 @@ static uint32_t head_blocks_per_cu() {
     if (v == 0) { const char* e = getenv("LAE_HEAD_BLOCKS_PER_CU"); v = e ? atoi(e) : 2; if (v < 1 || v > 8) v = 2; }
     return (uint32_t)v;
 }
+// 2 (default): k_nerf_head_fwd5 (64 rows per wave iteration, fragments from a swizzled LDS image); 1: k_nerf_head_fwd4 (the same
+// with the fragments in registers, one wave per SIMD); 0: the round-2 kernel.  A/B switch: LAE_HEAD_FWD_VARIANT or
+// lae_ffmlp_set_mode(16 + v).  The 16-byte staging loads of form 2 need 16-byte aligned weight pointers (else form 0).
+int g_head_fwd_variant = -1;
+static int head_fwd_variant() {
+    if (g_head_fwd_variant < 0) { const char* e = getenv("LAE_HEAD_FWD_VARIANT"); g_head_fwd_variant = e ? atoi(e) : 2; if (g_head_fwd_variant < 0 || g_head_fwd_variant > 2) g_head_fwd_variant = 2; }
+    return g_head_fwd_variant;
+}
+static uint32_t head4_blocks_per_cu() {
+    static int v = 0;
+    if (v == 0) { const char* e = getenv("LAE_HEAD4_BLOCKS_PER_CU"); v = e ? atoi(e) : 1; if (v < 1 || v > 4) v = 1; }
+    return (uint32_t)v;
+}
+static int head5_waves() {
+    static int v = 0;
+    if (v == 0) { const char* e = getenv("LAE_HEAD5_WAVES"); v = e ? atoi(e) : 8; if (v != 4 && v != 8 && v != 16) v = 8; }
+    return v;
+}
+template <bool COLOR, int WAVES>
+static int launch_head_fwd5_w(const half_t* enc, const float* dirs, const half_t* Ws, const half_t* Wc, uint32_t n_tiles, uint32_t launch_tiles,
+                              float density_scale, half_t* h_out, float* sigmas, float* rgbs, int level_major,
+                              const uint32_t* n_rows_dev, uint32_t lm_rows, hipStream_t s) {
+    const size_t lds_bytes = (size_t)(COLOR ? Head5Img::END : Head5Img::C0) * 2 + (size_t)WAVES * sizeof(Head4Scratch);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd5<COLOR, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+        attr_set = true;
+    }
+    const uint32_t n_groups = lae::cdiv(launch_tiles, 4);
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_groups, WAVES), (uint32_t)lae::num_cus() * head4_blocks_per_cu()));
+    k_nerf_head_fwd5<COLOR, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(enc, dirs, Ws, Wc, n_tiles, density_scale, h_out, sigmas, rgbs,
+                                                                        level_major, n_rows_dev, lm_rows);
+    return LAE_OK;
+}
+template <bool COLOR>
+static int launch_head_fwd5(const half_t* enc, const float* dirs, const half_t* Ws, const half_t* Wc, uint32_t n_tiles, uint32_t launch_tiles,
+                            float density_scale, half_t* h_out, float* sigmas, float* rgbs, int level_major,
+                            const uint32_t* n_rows_dev, uint32_t lm_rows, hipStream_t s) {
+    switch (head5_waves()) {
+        case 4: return launch_head_fwd5_w<COLOR, 4>(enc, dirs, Ws, Wc, n_tiles, launch_tiles, density_scale, h_out, sigmas, rgbs, level_major, n_rows_dev, lm_rows, s);
+        case 16: return launch_head_fwd5_w<COLOR, 16>(enc, dirs, Ws, Wc, n_tiles, launch_tiles, density_scale, h_out, sigmas, rgbs, level_major, n_rows_dev, lm_rows, s);
+        default: return launch_head_fwd5_w<COLOR, 8>(enc, dirs, Ws, Wc, n_tiles, launch_tiles, density_scale, h_out, sigmas, rgbs, level_major, n_rows_dev, lm_rows, s);
+    }
+}
+template <bool COLOR>
+static void launch_head_fwd4(const half_t* enc, const float* dirs, const half_t* Ws, const half_t* Wc, uint32_t n_tiles, uint32_t launch_tiles,
+                             float density_scale, half_t* h_out, float* sigmas, float* rgbs, int level_major,
+                             const uint32_t* n_rows_dev, uint32_t lm_rows, hipStream_t s) {
+    const uint32_t n_groups = lae::cdiv(launch_tiles, 4);
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_groups, 4), (uint32_t)lae::num_cus() * (COLOR ? head4_blocks_per_cu() : 2u)));
+    k_nerf_head_fwd4<COLOR><<<blocks, 256, 4 * sizeof(Head4Scratch), s>>>(enc, dirs, Ws, Wc, n_tiles, density_scale, h_out, sigmas, rgbs,
+                                                                         level_major, n_rows_dev, lm_rows);
+}
 
 int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
                                  uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
                                  float* rgbs, hipStream_t stream) {
     if (M_launch == 0) return LAE_OK;
     if (M_cap % 16 != 0) return LAE_EINVAL;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(sigma_weights) | reinterpret_cast<uintptr_t>(color_weights)) & 15) == 0;
+    if (head_fwd_variant() == 2 && al16)
+        return launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
+                                      lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
+    if (head_fwd_variant() == 1) {
+        launch_head_fwd4<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
+                               lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
+        return LAE_OK;
+    }
     const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1364,6 +1819,18 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
     if (M == 0) return LAE_OK;
     if (!enc || !dirs || !sigma_weights || !color_weights || !h_out || !sigmas || !rgbs) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(sigma_weights) | reinterpret_cast<uintptr_t>(color_weights)) & 15) == 0;
+    if (head_fwd_variant() == 2 && al16) {
+        const int rc = launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M / 16, M / 16,
+                                              density_scale, (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M,
+                                              reinterpret_cast<hipStream_t>(stream));
+        return rc != LAE_OK ? rc : lae::check_launch("nerf_head_forward");
+    }
+    if (head_fwd_variant() == 1) {
+        launch_head_fwd4<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M / 16, M / 16,
+                               density_scale, (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+        return lae::check_launch("nerf_head_forward");
+    }
     const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1384,6 +1851,16 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
     if (M == 0) return LAE_OK;
     if (!enc || !sigma_weights || !sigmas) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
+    if (head_fwd_variant() == 2 && (reinterpret_cast<uintptr_t>(sigma_weights) & 15) == 0) {
+        const int rc = launch_head_fwd5<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
+                                               (half_t*)h_out, sigmas, nullptr, 0, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+        return rc != LAE_OK ? rc : lae::check_launch("nerf_density_forward");
+    }
+    if (head_fwd_variant() == 1) {
+        launch_head_fwd4<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
+                                (half_t*)h_out, sigmas, nullptr, 0, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+        return lae::check_launch("nerf_density_forward");
+    }
     const size_t lds_bytes = (size_t)HeadCfg::S_END * 2;                 // sigma-net image only (< 64 KiB)
     const uint32_t n_tiles = M / 16;
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
@@ -1431,6 +1908,7 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
 }
 
 int lae_ffmlp_set_mode(int mode) {
+    if (mode >= 16 && mode <= 18) { g_head_fwd_variant = mode - 16; return LAE_OK; }      // fused head forward: round-2 kernel / round-3 forms
     if (mode < 0 || mode > 2) return LAE_EINVAL;
     g_ffmlp_mode = mode == 1 ? 1 : 0;                       // 1: buffer-faithful three-kernel backward
     g_bwd_fused_variant = mode == 2 ? 1 : 0;                // 2: fused backward with wave-private dW tiles

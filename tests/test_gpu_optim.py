@@ -137,6 +137,22 @@ def test_table_gradient_reports_nonfinite_values_itself():
     assert opt._check_tables(opt._tables())["n"] == 1 and sh.unreported
     opt.step()
     assert opt.steps_skipped == 2 and not sh.unreported
+    # an overflowed backward that is DISCARDED (zero_grad without a step) must not make the next, clean step be skipped:
+    # zero_grad clears found_inf along with the accumulators
+    with torch.autocast("cuda", dtype=torch.float16):
+        res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
+        loss = torch.nn.functional.mse_loss(res["image"], gt) * float("inf")
+    opt.scale(loss).backward()
+    assert int(opt.dev_state[2].item()) == 1
+    opt.zero_grad()
+    assert int(opt.dev_state[2].item()) == 0 and float(sh.grad_half.float().abs().nan_to_num(1.0).sum()) == 0
+    taken, skipped, scale = opt.steps_taken, opt.steps_skipped, opt.get_scale()
+    with torch.autocast("cuda", dtype=torch.float16):
+        res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
+        loss = torch.nn.functional.mse_loss(res["image"], gt)
+    opt.scale(loss).backward()
+    opt.step()
+    assert opt.steps_taken == taken + 1 and opt.steps_skipped == skipped and opt.get_scale() == scale
 
 
 def test_training_with_fused_adam_tracks_torch_path():
