@@ -538,9 +538,11 @@ LAE_API int lae_ema_update_multi(uint32_t n_tensors, float* const* shadows, cons
                          float one_minus_decay, void* stream);
 
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
- * backward_buffer untouched: both are scratch the reference's Python never reads), dW tiles divided among the waves of
- * a workgroup; 1 = always the three-kernel path that fills both buffers exactly like the reference; 2 = fused backward
- * with every wave accumulating all dW tiles over its own rows (the first fused design, kept for A/B). */
+ * backward_buffer untouched: both are scratch the reference's Python never reads), every wave accumulating all dW tiles
+ * over its own rows, operands transposed on the matrix cores (round 3); 1 = always the three-kernel path that fills both
+ * buffers exactly like the reference; 2 = the first fused design (wave-private dW, transposes through LDS); 3 = dW tiles
+ * divided among the waves of a workgroup (the round-2 default).  16 / 17 / 18 select the fused-head forward kernel
+ * (round 2 / registers / LDS image = default); all kept for A/B. */
 LAE_API int lae_ffmlp_set_mode(int mode);
 
 /* ffmlp.cu:721-740: the reference keeps process-global side streams for its

@@ -1022,8 +1022,368 @@ __global__ __launch_bounds__(64 * WAVES) void k_mlp_bwd_coop(
     if (w < 4) store_tile((size_t)64 * IN + (size_t)NH * 4096 + w * 16, 64, aO);
 }
 
+// in-kernel phase stamps for tools/ubench/mlp_probe.hip (compiled in only there): 100 MHz wall clock + shader clock
+#ifdef LAE_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[4096 * 64];
+#define MLP_STAMP(slot, i) do { if ((threadIdx.x & 63) == 0 && (i) < 32) { g_mlp_stamps[(size_t)(slot) * 64 + 2 * (i)] = wall_clock64(); \
+                                g_mlp_stamps[(size_t)(slot) * 64 + 2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
+#define MLP_PHASE(slot, i) do { if (stamp_i == 3) MLP_STAMP(slot, 16 + (i)); } while (0)
+#else
+#define MLP_STAMP(slot, i) do { } while (0)
+#define MLP_PHASE(slot, i) do { } while (0)
+#endif
+// ---------------------------------------------------------------- fused backward, round-3 form: no activation ever touches LDS
+// k_mlp_bwd_coop shares X / H / D / G tiles of 128 rows among 8 waves: 7 workgroup barriers per 128 rows and every
+// activation written row-major to LDS and read back transposed (66 % of its wave cycles parked at waitcnt / barrier, 10 % of
+// the MFMA rate).  What the weight gradient needs is the TRANSPOSE of tiles that the chain already holds in registers:
+//   chain layout (C/D of W x act^T):  lane (c, g) holds feats 4g .. 4g+3 of batch row c
+//   dW operand layout              :  lane (c, g) holds batch rows 4g .. 4g+3 of feature c     (A = D^T and B = H of dW = D^T H)
+// and a 16 x 16 transpose IS one MFMA: with the chain-layout registers as the A operand and the identity as B,
+// C[m][n] = sum_k A[m][k] I[k][n] = A[m][n] comes out in the C/D layout = lane (n = feature, rows 4g..) -- exact (products
+// with 0 / 1, fp32 accumulate, values are halves).  So a wave keeps its own two 16-row tiles in registers through recompute,
+// dL/dH chain and transposes, accumulates ALL dW tiles of the net itself with K = 32 MFMAs over the 32 rows (tile A rows in
+// the low k-slots, tile B rows in the high ones, the same permutation in both operands), and never synchronises with another
+// wave until the final fixed-order reduction of the four waves' dW through LDS.  Only the weights are read from LDS.
+// MFMAs per 16 rows (colour net): recompute 20, chain 22, transposes 27, dW 22 = 91 (coop: 66) -- the matrix pipe was never
+// the limit.
+template <int IN, int NH>
+struct WaveCfg {
+    static constexpr int KT0 = IN / 16;
+    static constexpr int LDX = IN + 8, LDH = 72;
+    static constexpr int W0_OFF = 0, WH_OFF = 64 * LDX, WO_OFF = WH_OFF + NH * 64 * LDH, W_HALVES = WO_OFF + 16 * LDH;
+    static constexpr int N_TILES = 4 * KT0 + NH * 16 + 4;                 // 16x16 dW tiles: W0 | hidden | Wout
+    static constexpr size_t LDS_BYTES = (size_t)W_HALVES * 2 + (size_t)N_TILES * 2048;      // weight image + two dW images (final reduction)
+};
+
+// 16 x 16 transpose on the matrix core: chain layout -> dW operand layout (see above)
+__device__ __forceinline__ h4 mfma_transpose(const h4& x, const h4& ident) {
+    const f4 r = mfma16(x, ident, f4{0, 0, 0, 0});
+    h4 o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (half_t)r[i];
+    return o;
+}
+// dL/dH of a ReLU layer: acc where the (post-ReLU, hence >= +0) activation is positive, else 0; packed halves.  -h as int16
+// is negative exactly when h > 0; its sign bit smeared over the half is the mask.  (Written with vector types the compiler
+// turns this back into four compares and selects per pair.)
+__device__ __forceinline__ h4 relu_bwd4(const f4& acc, const h4& h) {
+    h2 lo = {(half_t)acc[0], (half_t)acc[1]}, hi = {(half_t)acc[2], (half_t)acc[3]};
+    const uint2 hb = __builtin_bit_cast(uint2, h);
+    uint32_t d0 = __builtin_bit_cast(uint32_t, lo), d1 = __builtin_bit_cast(uint32_t, hi), m0, m1;
+    const uint32_t fifteen = 0x000f000fu;
+    asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, %2, %0" : "=&v"(m0) : "v"(hb.x), "v"(fifteen));
+    asm("v_pk_sub_i16 %0, 0, %1\n\tv_pk_ashrrev_i16 %0, %2, %0" : "=&v"(m1) : "v"(hb.y), "v"(fifteen));
+    d0 &= m0; d1 &= m1;
+    return __builtin_bit_cast(h4, uint2{d0, d1});
+}
+
+// four 16 x 16 transposes at once: the MFMAs first, the conversions after (a conversion right behind its MFMA waits for it)
+template <int N>
+__device__ __forceinline__ void mfma_transpose_n(const h4 (&x)[N], const h4& ident, h4 (&o)[N]) {
+    f4 r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = mfma16(x[i], ident, f4{0, 0, 0, 0});
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[i][j] = (half_t)r[i][j];
+}
+
+// WPE = waves per SIMD the kernel is compiled for: 1 (up to 512 registers: the colour net's 176 accumulator registers + two tiles
+// of working state) or 2 (256 registers: nets with one hidden GEMM; the inputs are then not requested ahead -- the partner wave
+// covers the latency -- which frees the registers of the second request)
+template <int IN, int NH, int MODE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mlp_bwd_wave(
+    const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
+    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW, HeadBwdArgs ha) {
+    using C = WaveCfg<IN, NH>;
+    constexpr int KT0 = C::KT0;
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* Wl = lds;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tq = (lane & 15) >> 2, tp = lane & 3;           // transposed-read lane address (ds_read_tr16_b64)
+    const h4 zero4 = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+    MLP_STAMP(blockIdx.x * 4 + w, 0);
+
+    const uint32_t n_pairs = (n_tiles + 1) / 2;
+    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)w, nwaves = gridDim.x * 4;
+    const size_t Bn = (size_t)n_tiles * 16;
+    // ---- inputs, requested one pair ahead (one wave per SIMD: nothing else hides a memory latency per pair)
+    struct Req { h4 xf[2][KT0]; h4 gf[2]; h4 hq[2]; float dir[2][3], y[2][3], gy[2][3], gs[2]; };
+    // (requests ahead only for an even number of input k-steps: with KT0 = 3 the build with the loop-carried request gave wrong
+    // first-layer operands for the second tile -- same source, correct without the carry; found by tests/test_gpu_ffmlp.py
+    // [*-48-64-*], not understood, so that shape takes the plain path)
+    constexpr bool AHEAD = WPE == 1 && (KT0 % 2 == 0);
+    Req nx = {};                                                         // (copied whole below: no member may be indeterminate)
+    auto request = [&](uint32_t pair) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t tile = min(2 * pair + t, n_tiles - 1);          // a tile past the batch re-reads the last one; its operands are zeroed below
+            const size_t row = (size_t)tile * 16 + c;
+            if constexpr (MODE == 1) {
+                nx.hq[t] = *reinterpret_cast<const h4*>(x + row * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 3; r++) nx.dir[t][r] = ha.dirs[3 * row + r];
+                if (g == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; r++) { nx.y[t][r] = ha.rgbs[row * 3 + r]; nx.gy[t][r] = ha.grad_rgbs[row * 3 + r]; }
+                    nx.gs[t] = ha.grad_sigmas[row];
+                }
+            } else {
+                if constexpr (KT0 == 2) load_enc_frags(x, row, Bn, g, ha.level_major, nx.xf[t]);
+                else {
+#pragma unroll
+                    for (int kt = 0; kt < KT0; kt++) nx.xf[t][kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
+                }
+                nx.gf[t] = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
+            }
+        }
+    };
+    if (AHEAD && wave0 < n_pairs) request(wave0);
+
+    // ---- weights -> LDS (row-major, padded): every 16-byte global load of the workgroup in flight before the first store
+    {
+        constexpr int CH0 = 64 * IN / 8, CHH = NH * 64 * 64 / 8, CHO = 16 * 64 / 8;
+        constexpr int N0 = (CH0 + 255) / 256, N1 = (CHH + 255) / 256, N2 = (CHO + 255) / 256;
+        uint4 b0[N0], b1[N1], b2[N2];
+#pragma unroll
+        for (int i = 0; i < N0; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CH0) b0[i] = *reinterpret_cast<const uint4*>(W + (size_t)e * 8); }
+#pragma unroll
+        for (int i = 0; i < N1; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CHH) b1[i] = *reinterpret_cast<const uint4*>(W + 64 * IN + (size_t)e * 8); }
+#pragma unroll
+        for (int i = 0; i < N2; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CHO) b2[i] = *reinterpret_cast<const uint4*>(W + 64 * IN + NH * 4096 + (size_t)e * 8); }
+#pragma unroll
+        for (int i = 0; i < N0; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CH0) { const int r = (e * 8) / IN, k = (e * 8) % IN; *reinterpret_cast<uint4*>(Wl + C::W0_OFF + r * C::LDX + k) = b0[i]; } }
+#pragma unroll
+        for (int i = 0; i < N1; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CHH) { const int r = (e * 8) / 64, k = (e * 8) % 64; *reinterpret_cast<uint4*>(Wl + C::WH_OFF + r * C::LDH + k) = b1[i]; } }
+#pragma unroll
+        for (int i = 0; i < N2; i++) { const int e = (int)threadIdx.x + 256 * i; if (e < CHO) { const int r = (e * 8) / 64, k = (e * 8) % 64; *reinterpret_cast<uint4*>(Wl + C::WO_OFF + r * C::LDH + k) = b2[i]; } }
+    }
+    __syncthreads();
+
+    h4 ident;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ident[j] = (4 * g + j == c) ? (half_t)1.0f : (half_t)0.0f;
+
+    f4 dW0[4][KT0], dWh[NH][4][4], dWo[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < KT0; j++) dW0[i][j] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NH; m++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) dWh[m][i][j] = f4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) dWo[j] = f4{0, 0, 0, 0};
+
+    [[maybe_unused]] int stamp_i = 1;
+    for (uint32_t pair = wave0; pair < n_pairs; pair += nwaves) {
+        MLP_STAMP(blockIdx.x * 4 + w, stamp_i); stamp_i++;
+        // ---- this pair's inputs (chain layout) from the request issued one iteration ago; then the next request
+        if (!AHEAD) request(pair);
+        const Req cur = nx;
+        if (AHEAD && pair + nwaves < n_pairs) request(pair + nwaves);
+        h4 xf[2][KT0], gf[2], hq[2];
+        bool act[2];
+        size_t row[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t tile = 2 * pair + t;
+            act[t] = tile < n_tiles;                                     // wave-uniform
+            row[t] = (size_t)(act[t] ? tile : 0) * 16 + c;
+            gf[t] = zero4; hq[t] = cur.hq[t];
+            if constexpr (MODE == 1) {
+                static_assert(MODE == 0 || KT0 == 2, "head colour net has a 32-wide input");
+                color_inputs(cur.dir[t][0], cur.dir[t][1], cur.dir[t][2], hq[t], g, xf[t]);
+                if (g == 0) {
+#pragma unroll
+                    for (int r = 0; r < 3; r++) gf[t][r] = (half_t)(cur.gy[t][r] * cur.y[t][r] * (1.0f - cur.y[t][r]));
+                }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < KT0; kt++) xf[t][kt] = cur.xf[t][kt];
+                gf[t] = cur.gf[t];
+            }
+            // a tile past the batch (odd tile count) re-reads the last tile and contributes nothing: with dL/dout = 0 every dL/dH
+            // and so every dW term of the tile is zero; its dX is not stored
+            if (!act[t]) gf[t] = zero4;
+        }
+        MLP_PHASE(blockIdx.x * 4 + w, 0);
+        // ---- recompute the hidden activations (post-ReLU) of both tiles; one fragment read serves both
+        h4 h[2][NH + 1][4];
+        {
+            f4 acc[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                h4 a[KT0];
+#pragma unroll
+                for (int kt = 0; kt < KT0; kt++) a[kt] = *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[t][mt] = mfma_ksteps<KT0>([&](int kt) { return a[kt]; }, xf[t], f4{0, 0, 0, 0});
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) relu4(acc[t], h[t][0]);
+#pragma unroll
+            for (int l = 0; l < NH; l++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) {
+                    h4 a[4];
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++) a[kt] = *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) acc[t][mt] = mfma_ksteps<4>([&](int kt) { return a[kt]; }, h[t][l], f4{0, 0, 0, 0});
+                }
+#pragma unroll
+                for (int t = 0; t < 2; t++) relu4(acc[t], h[t][l + 1]);
+            }
+        }
+        MLP_PHASE(blockIdx.x * 4 + w, 1);
+        // ---- output layer: dWout += G^T H_NH over the 32 rows ; dH_NH = (Wout^T G) * relu'
+        h4 d[2][4];
+        {
+            h4 TG[2], TH[2][4];
+            { const h4 gg[2] = {gf[0], gf[1]}; mfma_transpose_n<2>(gg, ident, TG); }
+#pragma unroll
+            for (int t = 0; t < 2; t++) mfma_transpose_n<4>(h[t][NH], ident, TH[t]);
+            f4 da[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                const h4 a = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);             // A[f][o] = Wout[o][f]
+#pragma unroll
+                for (int t = 0; t < 2; t++) da[t][mt] = mfma16(a, gf[t], f4{0, 0, 0, 0});
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) dWo[nt] = mfma32(TG[0], TG[1], TH[0][nt], TH[1][nt], dWo[nt]);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) d[t][mt] = relu_bwd4(da[t][mt], h[t][NH][mt]);
+        }
+        MLP_PHASE(blockIdx.x * 4 + w, 2);
+        // ---- hidden layers, last to first: dW_l += D_l^T H_{l-1} ; dH_{l-1} = (W_l^T dH_l) * relu'
+#pragma unroll
+        for (int l = NH; l >= 1; l--) {
+            h4 TD[2][4], TH[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; t++) { mfma_transpose_n<4>(d[t], ident, TD[t]); mfma_transpose_n<4>(h[t][l - 1], ident, TH[t]); }
+            f4 da[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                h4 a[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp);   // W_l^T
+#pragma unroll
+                for (int t = 0; t < 2; t++) da[t][mt] = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) dWh[l - 1][mt][nt] = mfma32(TD[0][mt], TD[1][mt], TH[0][nt], TH[1][nt], dWh[l - 1][mt][nt]);
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) d[t][mt] = relu_bwd4(da[t][mt], h[t][l - 1][mt]);
+        }
+        MLP_PHASE(blockIdx.x * 4 + w, 3);
+        // ---- input layer: dW0 += D_0^T X ; dX = W0^T dH_0
+        {
+            h4 TD[2][4], TX[2][KT0];
+#pragma unroll
+            for (int t = 0; t < 2; t++) { mfma_transpose_n<4>(d[t], ident, TD[t]); mfma_transpose_n<KT0>(xf[t], ident, TX[t]); }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int nt = 0; nt < KT0; nt++) dW0[mt][nt] = mfma32(TD[0][mt], TD[1][mt], TX[0][nt], TX[1][nt], dW0[mt][nt]);
+        }
+        if constexpr (MODE == 1) {
+            h4 a[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp);   // W0^T, features 16..31
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
+                const half_t v3 = (half_t)acc[3];
+                const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
+                h4 v;
+                v[0] = prev;
+                if (g == 0) v[0] = (half_t)(cur.gs[t] * ha.density_scale * expf(lae::clampf((float)hq[t][0], -15.0f, 15.0f)));
+                v[1] = (half_t)acc[0]; v[2] = (half_t)acc[1]; v[3] = (half_t)acc[2];
+                if (act[t]) *reinterpret_cast<h4*>(grad_in + row[t] * 16 + 4 * g) = v;
+            }
+        } else if (grad_in) {
+#pragma unroll
+            for (int it = 0; it < KT0; it++) {
+                h4 a[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp);   // W0^T
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const f4 acc = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
+                    h4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];
+                    if (!act[t]) continue;
+                    if (KT0 == 2 && ha.level_major) {
+                        const uint2 u = __builtin_bit_cast(uint2, v);
+                        *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g) * Bn + row[t]) * 2) = u.x;
+                        *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g + 1) * Bn + row[t]) * 2) = u.y;
+                    } else
+                        *reinterpret_cast<h4*>(grad_in + row[t] * IN + it * 16 + 4 * g) = v;
+                }
+            }
+        }
+        MLP_PHASE(blockIdx.x * 4 + w, 4);
+    }
+
+    // ---- the 4 waves' dW tiles -> one fp32 slab per workgroup, in a fixed order: (w0 + w2) + (w1 + w3).  Tiles travel in
+    // the C/D register layout (one 16-byte LDS access per tile and lane); the slab store undoes it.
+    MLP_STAMP(blockIdx.x * 4 + w, 14);
+    f4* red = reinterpret_cast<f4*>(lds + C::W_HALVES);                  // [2][N_TILES][64] f4
+    auto for_tiles = [&](auto&& fn) {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < KT0; j++) fn(t++, dW0[i][j]);
+#pragma unroll
+        for (int m = 0; m < NH; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) fn(t++, dWh[m][i][j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fn(t++, dWo[j]);
+    };
+    if (w < 2) for_tiles([&](int t, const f4& v) { red[((size_t)w * C::N_TILES + t) * 64 + lane] = v; });
+    __syncthreads();
+    if (w >= 2) for_tiles([&](int t, const f4& v) { f4& r = red[((size_t)(w - 2) * C::N_TILES + t) * 64 + lane]; r = r + v; });
+    __syncthreads();
+    float* slab = slabs + (size_t)blockIdx.x * nW;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)C::N_TILES * 64; e += 256) {
+        const uint32_t t = e >> 6, ln = e & 63, cc = ln & 15, gg = ln >> 4;
+        const f4 v = red[e] + red[(size_t)C::N_TILES * 64 + e];
+        size_t base; uint32_t ld;
+        if (t < 4u * KT0) { base = (size_t)((t / KT0) * 16) * IN + (t % KT0) * 16; ld = IN; }
+        else if (t < 4u * KT0 + NH * 16u) {
+            const uint32_t u = t - 4 * KT0, m = u / 16, i = (u % 16) / 4, j = u % 4;
+            base = (size_t)64 * IN + (size_t)m * 4096 + (size_t)(i * 16) * 64 + j * 16; ld = 64;
+        } else { base = (size_t)64 * IN + (size_t)NH * 4096 + (t - 4 * KT0 - NH * 16) * 16; ld = 64; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) slab[base + (size_t)(4 * gg + r) * ld + cc] = v[r];
+    }
+    MLP_STAMP(blockIdx.x * 4 + w, 15);
+}
+
 // 0 = workgroup-cooperative dW (default), 1 = wave-private dW (k_mlp_bwd_fused); A/B switch, see lae_ffmlp_set_mode
-int g_bwd_fused_variant = 0;
+int g_bwd_fused_variant = -1;
+static int bwd_fused_variant() {
+    if (g_bwd_fused_variant < 0) { const char* e = getenv("LAE_MLP_BWD_VARIANT"); g_bwd_fused_variant = e ? atoi(e) : 2; if (g_bwd_fused_variant < 0 || g_bwd_fused_variant > 3) g_bwd_fused_variant = 2; }
+    return g_bwd_fused_variant;
+}
 
 template <int IN, int NH, int MODE = 0>
 int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
@@ -1034,7 +1394,22 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
     const uint32_t n_tiles = B / 16;
     uint32_t blocks;
     float* ws;
-    if (g_bwd_fused_variant == 0) {
+    const int variant = bwd_fused_variant() == 3 ? (NH == 1 ? 2 : 0) : bwd_fused_variant();      // 3: wave-private for one hidden GEMM, cooperative for two
+    if (variant == 2) {
+        using C = WaveCfg<IN, NH>;
+        constexpr int WPE = 1;       // 2 waves per SIMD measured on the sigma net (26 spilled registers): 3.1 us per pair and SIMD against 2.4
+        const size_t lds_bytes = C::LDS_BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_wave<IN, NH, MODE, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+            attr_set = true;
+        }
+        blocks = std::max(1u, std::min(lae::cdiv(lae::cdiv(n_tiles, 2), 4), (uint32_t)lae::num_cus() * WPE));
+        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
+        if (!ws) return LAE_ELAUNCH;
+        k_mlp_bwd_wave<IN, NH, MODE, WPE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
+    } else if (variant == 0) {
         constexpr int WAVES = 8;
         using C = CoopCfg<IN, NH, WAVES>;
         const size_t lds_bytes = (size_t)C::LDS_HALVES * 2;
@@ -1148,14 +1523,6 @@ __global__ __launch_bounds__(256) void k_nerf_head_fwd(
 //    wave-private 3 KB LDS scratch (2 wide stores + 4 fragment reads for the SH block; one masked store per tile + one
 //    read for the density logit and the colour logits).  sigma / rgb leave as one coalesced row-per-lane store.
 struct Head4Scratch { half_t sh[64][16]; float q[64][4]; };             // per wave
-// in-kernel phase stamps for tools/ubench/mlp_probe.hip (compiled in only there): 100 MHz wall clock + shader clock
-#ifdef LAE_MLP_STAMPS
-__device__ unsigned long long g_mlp_stamps[4096 * 32];
-#define MLP_STAMP(slot, i) do { if ((threadIdx.x & 63) == 0 && (i) < 16) { g_mlp_stamps[(size_t)(slot) * 32 + 2 * (i)] = wall_clock64(); \
-                                g_mlp_stamps[(size_t)(slot) * 32 + 2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
-#else
-#define MLP_STAMP(slot, i) do { } while (0)
-#endif
 
 // 64-wide layer on NT tiles from register-resident A fragments; ReLU + fp16 rounding like relu4
 template <int KT, int NT>
@@ -1909,9 +2276,10 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
 
 int lae_ffmlp_set_mode(int mode) {
     if (mode >= 16 && mode <= 18) { g_head_fwd_variant = mode - 16; return LAE_OK; }      // fused head forward: round-2 kernel / round-3 forms
-    if (mode < 0 || mode > 2) return LAE_EINVAL;
+    if (mode >= 32 && mode <= 35) { g_bwd_fused_variant = mode - 32; return LAE_OK; }      // fused backward: 32 coop, 33 wave-private + LDS transposes, 34 wave-private + MFMA transposes
+    if (mode < 0 || mode > 3) return LAE_EINVAL;
     g_ffmlp_mode = mode == 1 ? 1 : 0;                       // 1: buffer-faithful three-kernel backward
-    g_bwd_fused_variant = mode == 2 ? 1 : 0;                // 2: fused backward with wave-private dW tiles
+    g_bwd_fused_variant = mode == 2 ? 1 : mode == 3 ? 0 : 2; // 0: wave-private dW + MFMA transposes (default); 2: wave-private dW + LDS transposes; 3: cooperative dW
     return LAE_OK;
 }
 

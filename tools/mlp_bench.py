@@ -58,7 +58,7 @@ def timed(fn, reps=30):
 
 
 fwd_modes = [int(x) for x in os.environ.get("MLP_BENCH_FWD", "16,17,18").split(",") if x]
-bwd_modes = [int(x) for x in os.environ.get("MLP_BENCH_BWD", "0,2").split(",") if x]
+bwd_modes = [int(x) for x in os.environ.get("MLP_BENCH_BWD", "3,0").split(",") if x]
 ref = None
 for mode in fwd_modes:
     F.ffmlp_set_mode(mode)

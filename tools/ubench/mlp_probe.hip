@@ -44,18 +44,65 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("variant %d: %u blocks x %u waves, %.2f us per launch (10 back to back)\n", variant, blocks, WV, ms * 100.0f);
     }
-    std::vector<unsigned long long> st((size_t)4096 * 32);
+    if (variant >= 100) {
+        // backward probe: k_mlp_bwd_wave<32, 2, 1, 1> (colour net of the fused head; 101) or <32, 1, 0> (sigma net; 100)
+        float *gs, *gr; half_t *gh, *genc; float* slabs;
+        hipMalloc(&gs, (size_t)M * 4); hipMalloc(&gr, (size_t)M * 12); hipMalloc(&gh, (size_t)M * 32); hipMalloc(&genc, (size_t)M * 64);
+        hipMemset(gs, 0, (size_t)M * 4); hipMemset(gr, 0, (size_t)M * 12); hipMemset(gh, 0, (size_t)M * 32);
+        k_nerf_head_fwd5<true, 8><<<256, 512, lds5>>>(enc, dirs, ws, wc, n_tiles, 1.0f, hout, sig, rgb, 1, nullptr, M);
+        const uint32_t nb = std::min(((n_tiles + 1) / 2 + 3) / 4, (uint32_t)p.multiProcessorCount * (variant == 100 ? 2 : 1));
+        const uint32_t nWc = 64 * (32 + 128 + 16), nWs = 64 * (32 + 64 + 16);
+        hipMalloc(&slabs, (size_t)nb * nWc * 4);
+        HeadBwdArgs ha{dirs, rgb, gr, gs, 1.0f, 0}, hs{}; hs.level_major = 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_wave<32, 2, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WaveCfg<32, 2>::LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_wave<32, 1, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WaveCfg<32, 1>::LDS_BYTES);
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            for (int k = 0; k < 10; k++) {
+                if (variant == 101) k_mlp_bwd_wave<32, 2, 1, 1><<<nb, 256, WaveCfg<32, 2>::LDS_BYTES>>>(nullptr, hout, wc, n_tiles, gh, slabs, nWc, ha);
+                else k_mlp_bwd_wave<32, 1, 0, 2><<<nb, 256, WaveCfg<32, 1>::LDS_BYTES>>>(gh, enc, ws, n_tiles, genc, slabs, nWs, hs);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("bwd variant %d: %u blocks, %.2f us per launch\n", variant, nb, ms * 100.0f);
+        }
+        std::vector<unsigned long long> st((size_t)4096 * 64);
+        hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_mlp_stamps), st.size() * 8);
+        const uint32_t nw = nb * 4, n_pairs = (n_tiles + 1) / 2;
+        auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+        std::vector<double> pro, epi, tot; std::vector<std::vector<double>> pr(12), prc(12);
+        for (uint32_t w = 0; w < nw; w++) {
+            const unsigned long long* s = &st[(size_t)w * 64];
+            const uint32_t mine = (n_pairs - w + nw - 1) / nw;
+            pro.push_back((double)(s[2] - s[0]) * 0.01); epi.push_back((double)(s[30] - s[28]) * 0.01); tot.push_back((double)(s[30] - s[0]) * 0.01);
+            for (uint32_t k = 0; k < mine && k < 12; k++) {
+                const unsigned long long b = (k + 1 < mine) ? s[2 * (k + 2)] : s[28], bc = (k + 1 < mine) ? s[2 * (k + 2) + 1] : s[29];
+                pr[k].push_back((double)(b - s[2 * (k + 1)]) * 0.01); prc[k].push_back((double)(bc - s[2 * (k + 1) + 1]));
+            }
+        }
+        printf("prologue (weights -> LDS): median %.2f us; epilogue (dW reduction + slab): median %.2f us; wave total median %.2f max %.2f us\n",
+               med(pro), med(epi), med(tot), *std::max_element(tot.begin(), tot.end()));
+        for (int k = 0; k < 12; k++) if (!pr[k].empty()) printf("pair %d: %zu waves, median %.2f us = %.0f clocks\n", k, pr[k].size(), med(pr[k]), med(prc[k]));
+        const char* ph[4] = {"recompute", "output layer (transposes, dWout, dH)", "hidden layers", "input layer + dX"};
+        for (int k = 0; k < 4; k++) {
+            std::vector<double> v;
+            for (uint32_t w = 0; w < nw; w++) { const unsigned long long* s = &st[(size_t)w * 64]; v.push_back((double)(s[2 * (17 + k) + 1] - s[2 * (16 + k) + 1])); }
+            printf("  third pair, %s: median %.0f clocks\n", ph[k], med(v));
+        }
+        return 0;
+    }
+    std::vector<unsigned long long> st((size_t)4096 * 64);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_mlp_stamps), st.size() * 8);
     const uint32_t nw = blocks * WV;
     unsigned long long t_min = ~0ull, t_max = 0;
-    for (uint32_t w = 0; w < nw; w++) { t_min = std::min(t_min, st[(size_t)w * 32]); t_max = std::max(t_max, st[(size_t)w * 32 + 30]); }
+    for (uint32_t w = 0; w < nw; w++) { t_min = std::min(t_min, st[(size_t)w * 64]); t_max = std::max(t_max, st[(size_t)w * 64 + 30]); }
     printf("first wave start -> last wave end: %.2f us (wall clock 100 MHz)\n", (double)(t_max - t_min) * 0.01);
     // per-phase medians over waves
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
     std::vector<double> start, wl, tot, cyc_tot;
     std::vector<std::vector<double>> grp(8), grpc(8);
     for (uint32_t w = 0; w < nw; w++) {
-        const unsigned long long* s = &st[(size_t)w * 32];
+        const unsigned long long* s = &st[(size_t)w * 64];
         start.push_back((double)(s[0] - t_min) * 0.01);
         wl.push_back((double)(s[2] - s[0]) * 0.01);
         tot.push_back((double)(s[30] - s[0]) * 0.01);
