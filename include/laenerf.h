@@ -166,7 +166,11 @@ LAE_API int lae_composite_rays_train_step(const float* sigmas, const float* rgbs
                                   float bg_g, float bg_b, const uint32_t* rows_end, const float* target, const float* scale,
                                   float* weights_sum, float* depth, float* image, float* depth_out, float* image_out,
                                   float* grad_image, float* grad_sigmas, float* grad_rgbs, float* loss_out, float* partials,
-                                  void* stream);
+                                  int defer_loss, void* stream);
+/* defer_loss != 0 (round 3): the one-block launch is left out and loss_out[0..1] is set to NaN; the sum is done later by
+ * lae_loss_finish(partials, cdiv(N, 4), 3 * N, scale, loss_out) or taken along by lae_nerf_head_backward (its loss_*
+ * arguments) -- the value feeds nothing on the device, so it need not sit on the step's critical path. */
+LAE_API int lae_loss_finish(const float* partials, uint32_t n_part, uint32_t n_elem, const float* scale, float* loss_out, void* stream);
 
 /* Backward of the above w.r.t. (weights_sum, image_out): grad_ws_eff = grad_ws - sum_c grad_image_c * bg_c.  Writes EVERY
  * row of grad_sigmas / grad_rgbs in [0, M) (zeros after the early stop and in [rows_end, M)), so they need no
@@ -430,7 +434,11 @@ LAE_API int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_r
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
                            void* grad_color_weights, int accumulate_weight_grads, int enc_level_major,
-                           int32_t* nonfinite_flag, void* stream);
+                           int32_t* nonfinite_flag, const float* loss_partials, uint32_t loss_n_part, uint32_t loss_n_elem,
+                           const float* loss_scale, float* loss_out, void* stream);
+/* loss_out != NULL (round 3): the launch that reduces the weight-gradient slabs carries one workgroup more, which finishes a
+ * loss value deferred by lae_composite_rays_train_step(defer_loss): loss_out[0] = sum(loss_partials[0 .. loss_n_part)) /
+ * loss_n_elem * (*loss_scale, or 1 when NULL), loss_out[1] = the same unscaled -- the bits lae_loss_finish would write. */
 
 /* ---- freqencoder (freqencoder/src/freqencoder.h:6-10; bindings.cpp:5-8) ----
  * outputs [B, C], C = D + 2*D*deg: the input, then per frequency f < deg the D sines and D cosines of x * 2^f.
@@ -501,7 +509,11 @@ LAE_API int lae_mark_untrained_grid(const float* poses, uint32_t B, float fx, fl
 /* ---- fused Adam + GradScaler (torch.optim.Adam / torch.cuda.amp.GradScaler in the reference: main_nerf.py:223,
  * nerf/utils.py:1474-1482).  `state` is a 64-byte device block:
  *   [0] f32 scale  [1] i32 growth_tracker  [2] i32 found_inf  [3] i32 skip  [4] i32 step  [5] f32 1/(1-beta1^step)
- *   [6] f32 sqrt(1-beta2^step)  [7] f32 1/scale of this step  [8] i32 skipped steps  [9..15] reserved.
+ *   [6] f32 sqrt(1-beta2^step)  [7] f32 1/scale of this step  [8] i32 skipped steps
+ *   [9] [10] f32 the bias corrections of step [11] (i32; 0 = none) computed with the betas [12] [13] -- left by the apply launch
+ *   so that the one-thread begin launch on the step's critical path does no double-precision pow (round 3; begin computes
+ *   them itself when [11] is not the step it is about to take)  [14..15] reserved.  The apply entry points therefore WRITE
+ *   words 9-13 of `state` although they take it as const.
  * Per step: lae_adam_check on every gradient, ONE lae_adam_begin, lae_adam_apply on every parameter.
  * check: found_inf |= any non-finite element (grad fp16 or fp32, 16-byte aligned). */
 LAE_API int lae_adam_check(const void* grad, int grad_is_half, uint64_t n, void* state, void* stream);

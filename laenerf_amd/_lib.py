@@ -30,7 +30,8 @@ SIGNATURES = {
     "lae_composite_rays_train_forward": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_composite_rays_train_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, vp, vp],
     "lae_composite_rays_train_forward_blend": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp],
-    "lae_composite_rays_train_step": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lae_composite_rays_train_step": [vp, vp, vp, vp, u32, u32, f32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "lae_loss_finish": [vp, u32, u32, vp, vp, vp],
     "lae_composite_rays_train_backward_blend": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, f32, f32, f32, vp, vp, vp, vp],
     "lae_composite_rays_train_backward_blend_ex": [vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, vp, f32, f32, f32, vp, vp, vp, vp, vp],
     "lae_march_rays": [u32, u32, vp, vp, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -68,7 +69,7 @@ SIGNATURES = {
     "lae_density_grid_positions": [vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_density_grid_update": [vp, vp, u32, f32, f32, u32, vp, vp, vp],
     "lae_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, f32, i32, vp, vp],
-    "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, i32, vp, vp],
+    "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, i32, vp, vp, u32, u32, vp, vp, vp],
     "lae_palette_forward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp],
     "lae_palette_backward_scratch_bytes": [u32],
     "lae_palette_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -76,6 +76,18 @@ def free_workspaces():
 
 
 # --------------------------------------------------------------------------- _raymarching
+# a loss value whose final sum was deferred (composite_rays_train_step(defer_loss=True)): (partials, n_part, n_elem, scale,
+# loss_out).  The fused head's backward takes it along; flush_pending_loss() finishes it with a launch of its own.
+_pending_loss = []
+
+
+def flush_pending_loss():
+    while _pending_loss:
+        partials, n_part, n_elem, scale, loss_out = _pending_loss.pop()
+        with torch.cuda.device(loss_out.device):
+            check(_lib.load().lae_loss_finish(ptr(partials), n_part, n_elem, ptr(scale), ptr(loss_out), stream()), "loss_finish")
+
+
 class _RayMarching:
     @staticmethod
     def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
@@ -170,8 +182,10 @@ class _RayMarching:
     @staticmethod
     def composite_rays_train_step(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears, fars, bg_rays, bg, rows_end, target, scale,
                                   weights_sum, depth, image, depth_out, image_out, grad_image, grad_sigmas, grad_rgbs, loss_out,
-                                  partials):
-        """MI355X extension: compositing forward (+ blend) + MSE criterion + compositing backward in one launch"""
+                                  partials, defer_loss=False):
+        """MI355X extension: compositing forward (+ blend) + MSE criterion + compositing backward in one launch.
+        defer_loss: the loss VALUE (loss_out, NaN until then) is summed later -- by the fused head's backward, which takes it
+        along in its reduction launch, or by flush_pending_loss() (laenerf_amd.optim.FusedAdam.backward / step call it)."""
         ts = (sigmas, rgbs, deltas, rays, nears, fars, bg_rays, rows_end, target, scale, weights_sum, depth, image, depth_out,
               image_out, grad_image, grad_sigmas, grad_rgbs, loss_out, partials)
         need_cuda(*ts); need_contig(*ts)
@@ -182,7 +196,11 @@ class _RayMarching:
         check(_lib.load().lae_composite_rays_train_step(
             ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, T_thresh, ptr(nears), ptr(fars), ptr(bg_rays), bg[0], bg[1], bg[2],
             ptr(rows_end), ptr(target), ptr(scale), ptr(weights_sum), ptr(depth), ptr(image), ptr(depth_out), ptr(image_out),
-            ptr(grad_image), ptr(grad_sigmas), ptr(grad_rgbs), ptr(loss_out), ptr(partials), stream()), "composite_rays_train_step")
+            ptr(grad_image), ptr(grad_sigmas), ptr(grad_rgbs), ptr(loss_out), ptr(partials), int(bool(defer_loss)), stream()),
+            "composite_rays_train_step")
+        if defer_loss:
+            flush_pending_loss()                      # an older value nobody finished (no backward ran): finish it now
+            _pending_loss[:] = [(partials, (N + 3) // 4, 3 * N, scale, loss_out)]
 
     @staticmethod
     def composite_rays_train_backward_blend(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M,
@@ -476,11 +494,15 @@ class _FFMLP:
               grad_sigma_weights, grad_color_weights)
         need_cuda(*ts); need_contig(*ts)
         _FFMLP._half(enc, h, sigma_weights, color_weights, grad_h, grad_enc, grad_sigma_weights, grad_color_weights)
+        pend = _pending_loss.pop() if _pending_loss else None          # a deferred loss value rides in the reduction launch
+        if pend is not None and pend[0].device != grad_h.device:
+            _pending_loss.append(pend); pend = None
+        lp, ln, le, lsc, lo = pend if pend is not None else (None, 0, 0, None, None)
         check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
                                                  ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
                                                  ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
                                                  ptr(grad_color_weights), int(bool(accumulate)), int(bool(level_major)),
-                                                 nonfinite_flag, stream()), "nerf_head_backward")
+                                                 nonfinite_flag, ptr(lp), ln, le, ptr(lsc), ptr(lo), stream()), "nerf_head_backward")
 
     @staticmethod
     def ffmlp_set_mode(mode):

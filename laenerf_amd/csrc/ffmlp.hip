@@ -15,6 +15,7 @@
 // chain through all layers in registers: no LDS, no shuffles.  Accumulation is
 // fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 #include "lae_common.h"
 
@@ -388,12 +389,47 @@ __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __re
     dw_reduce_body(slabs, n_slices, nW, gw, accumulate, blockIdx.x);
 }
 // the same reduction for two networks in one launch (blocks [0, nb_a) reduce A, the rest B): one graph node less per step
+// One block more than the reduction needs takes the deferred loss value along (lae_composite_rays_train_step with
+// defer_loss): the fixed-order sum of the criterion's per-workgroup partials -> loss_out[0] = mean * scale, [1] = mean,
+// the arithmetic of k_loss_finish (raymarching.hip), without a launch of its own on the step's critical path.
+struct LossFinish { const float* partials; uint32_t n_part, n_elem; const float* scale; float* out; };
 __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce2(const float* __restrict__ slabs_a, uint32_t n_a, uint32_t nW_a,
                                                                 half_t* __restrict__ gw_a, const float* __restrict__ slabs_b,
                                                                 uint32_t n_b, uint32_t nW_b, half_t* __restrict__ gw_b,
-                                                                uint32_t nb_a, int accumulate, int32_t* __restrict__ nf_flag) {
+                                                                uint32_t nb_a, uint32_t nb_b, int accumulate, int32_t* __restrict__ nf_flag,
+                                                                LossFinish lf) {
     if (blockIdx.x < nb_a) dw_reduce_body(slabs_a, n_a, nW_a, gw_a, accumulate, blockIdx.x, nf_flag);
-    else dw_reduce_body(slabs_b, n_b, nW_b, gw_b, accumulate, blockIdx.x - nb_a, nf_flag);
+    else if (blockIdx.x < nb_a + nb_b) dw_reduce_body(slabs_b, n_b, nW_b, gw_b, accumulate, blockIdx.x - nb_a, nf_flag);
+    else {
+        static_assert(64 * DWR_GROUPS == 1024, "the loss sum is written for 16 waves, like k_loss_finish");
+        __shared__ float part[16];
+        float acc = 0.0f;
+        for (uint32_t i = threadIdx.x; i < lf.n_part; i += 1024) acc += lf.partials[i];
+        {   // the wave sum of raymarching.hip (wave_sum = last lane of the DPP inclusive scan), statement for statement: the
+            // deferred value has the same bits as the one k_loss_finish writes
+            auto dpp = [](float v, auto ctrl, auto mask) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, decltype(mask)::value, 0xf, false));
+            };
+            using std::integral_constant;
+            acc += dpp(acc, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+            acc += dpp(acc, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+            acc += dpp(acc, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+            acc += dpp(acc, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+            acc += dpp(acc, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+            acc += dpp(acc, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+            acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+        }
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 16; w++) t += part[w];
+            const float loss = t / (float)lf.n_elem;
+            lf.out[0] = loss * (lf.scale ? lf.scale[0] : 1.0f);
+            lf.out[1] = loss;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- fused NeRF head (network_ff.py:51-81 in one kernel)
@@ -2241,10 +2277,16 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
                            const float* rgbs, const void* sigma_weights, const void* color_weights, uint32_t M,
                            float density_scale, void* grad_h, void* grad_enc, void* grad_sigma_weights,
                            void* grad_color_weights, int accumulate_weight_grads, int enc_level_major, int32_t* nonfinite_flag,
-                           void* stream) {
+                           const float* loss_partials, uint32_t loss_n_part, uint32_t loss_n_elem, const float* loss_scale,
+                           float* loss_out, void* stream) {
     if (!grad_sigma_weights || !grad_color_weights) return LAE_ENULL;
+    if (loss_out && (!loss_partials || loss_n_elem == 0)) return LAE_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M == 0) {                                        // no samples: zero weight gradients (like the reference's GEMMs on empty batches)
+        if (loss_out) {
+            const int rc = lae_loss_finish(loss_partials, loss_n_part, loss_n_elem, loss_scale, loss_out, stream);
+            if (rc != LAE_OK) return rc;
+        }
         if (accumulate_weight_grads) return LAE_OK;
         if (hipMemsetAsync(grad_sigma_weights, 0, 64 * (32 + 64 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
         if (hipMemsetAsync(grad_color_weights, 0, 64 * (32 + 128 + 16) * 2, s) != hipSuccess) return LAE_ELAUNCH;
@@ -2269,8 +2311,10 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
                                     (half_t*)grad_sigma_weights, s, hs, accumulate_weight_grads, ws_s, &n_s);
     if (rc != LAE_OK) return rc;
     const uint32_t nb_c = lae::cdiv(nW_c, 64u), nb_s = lae::cdiv(nW_s, 64u);
-    k_dw_reduce2<<<nb_c + nb_s, 64 * DWR_GROUPS, 0, s>>>(ws, n_c, nW_c, (half_t*)grad_color_weights, ws_s, n_s, nW_s,
-                                                        (half_t*)grad_sigma_weights, nb_c, accumulate_weight_grads, nonfinite_flag);
+    const LossFinish lf{loss_partials, loss_n_part, loss_n_elem, loss_scale, loss_out};
+    k_dw_reduce2<<<nb_c + nb_s + (loss_out ? 1u : 0u), 64 * DWR_GROUPS, 0, s>>>(ws, n_c, nW_c, (half_t*)grad_color_weights, ws_s, n_s, nW_s,
+                                                                               (half_t*)grad_sigma_weights, nb_c, nb_s,
+                                                                               accumulate_weight_grads, nonfinite_flag, lf);
     return lae::check_launch("nerf_head_backward");
 }
 

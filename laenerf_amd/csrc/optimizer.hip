@@ -28,8 +28,28 @@ struct OptState {          // 16 words, see include/laenerf.h
     float bc2_sqrt;        // 6  sqrt(1 - beta2^step)
     float inv_scale;       // 7  1 / scale used by this step's gradients
     int32_t skipped_total; // 8  number of skipped steps (diagnostics)
-    int32_t pad[7];
+    // round 3: the bias corrections of the NEXT step, left by the update launch (k_apply*) so that k_begin -- a one-thread
+    // launch on the step's critical path -- needs no pow / sqrt / divide in double (it was ~5 us, most of it that arithmetic)
+    float next_inv_bc1;    // 9   1 / (1 - beta1^next_for)
+    float next_bc2_sqrt;   // 10  sqrt(1 - beta2^next_for)
+    int32_t next_for;      // 11  the step count words 9 / 10 are for (0 = none: k_begin computes them itself)
+    float next_beta1;      // 12  the betas they were computed with
+    float next_beta2;      // 13
+    int32_t pad[2];
 };
+
+__device__ __forceinline__ void bias_corrections(float beta1, float beta2, int step, float& inv_bc1, float& bc2_sqrt) {
+    inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+}
+// called by ONE thread of the update launch, which only READS words 3-7: the values for the step after the one being applied
+__device__ __forceinline__ void prepare_next_step(OptState* st, float beta1, float beta2) {
+    const int nxt = st->step + 1;
+    float a, b;
+    bias_corrections(beta1, beta2, nxt, a, b);
+    st->next_inv_bc1 = a; st->next_bc2_sqrt = b; st->next_beta1 = beta1; st->next_beta2 = beta2;
+    st->next_for = nxt;
+}
 
 template <typename G> __device__ __forceinline__ float ldg(const G* g, size_t i) { return (float)g[i]; }
 
@@ -72,8 +92,13 @@ __global__ void k_begin(OptState* __restrict__ st, float beta1, float beta2, int
         return;
     }
     st->step += 1;
-    st->inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)st->step)));
-    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st->step));
+    if (st->next_for == st->step && st->next_beta1 == beta1 && st->next_beta2 == beta2) {      // left by the previous update launch
+        st->inv_bc1 = st->next_inv_bc1; st->bc2_sqrt = st->next_bc2_sqrt;
+    } else {                                                                                   // first step, loaded checkpoint, ...
+        float a, b;
+        bias_corrections(beta1, beta2, st->step, a, b);
+        st->inv_bc1 = a; st->bc2_sqrt = b;
+    }
     if (use_scaler) {
         st->growth_tracker += 1;
         if (st->growth_tracker == growth_interval) { st->scale = st->scale * growth; st->growth_tracker = 0; }
@@ -93,10 +118,11 @@ __device__ __forceinline__ void adam1(float& p, float& m, float& v, float g, flo
 template <typename G>
 __global__ __launch_bounds__(256) void k_apply(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                G* __restrict__ grad, half_t* __restrict__ shadow, size_t n,
-                                               const OptState* __restrict__ st, const float* __restrict__ lr_ptr, AdamHyper h) {
+                                               OptState* __restrict__ st, const float* __restrict__ lr_ptr, AdamHyper h) {
     const bool skip = st->skip != 0;
     const float inv_scale = st->inv_scale, bc2_sqrt = st->bc2_sqrt;
     const float lr_over_bc1 = (float)((double)lr_ptr[0] * (double)st->inv_bc1);     // step_size = lr / bias_correction1
+    if (blockIdx.x == 0 && threadIdx.x == 0) prepare_next_step(st, h.beta1, h.beta2);
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 4 <= n) {
@@ -233,9 +259,11 @@ __device__ __forceinline__ void seg_apply(float* __restrict__ p, float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void k_apply_multi(ApplySegs sg, const OptState* __restrict__ st, AdamHyper h) {
+__global__ __launch_bounds__(256) void k_apply_multi(ApplySegs sg, OptState* __restrict__ st, AdamHyper h) {
     const bool skip = st->skip != 0;
     const float inv_scale = st->inv_scale, bc2_sqrt = st->bc2_sqrt;
+    // the LAST workgroup's first thread (the first workgroups carry the table's head, the longest work): words 9-13 only
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) prepare_next_step(st, h.beta1, h.beta2);
     for (int s = 0; s < sg.count; s++) {
         const float lr_over_bc1 = (float)((double)sg.lr[s][0] * (double)st->inv_bc1);
         if (sg.is_half[s]) seg_apply(sg.p[s], sg.m[s], sg.v[s], (half_t*)sg.grad[s], sg.shadow[s], sg.n[s], skip, inv_scale, bc2_sqrt, lr_over_bc1, h, sg.touched[s]);
@@ -339,7 +367,7 @@ int lae_adam_apply_multi(uint32_t n_tensors, float* const* params, float* const*
         biggest = std::max(biggest, (size_t)sizes[i]);
     }
     sg.count = (int)n_tensors;
-    k_apply_multi<<<stream_blocks(biggest, 4), 256, 0, STREAM(stream)>>>(sg, reinterpret_cast<const OptState*>(state),
+    k_apply_multi<<<stream_blocks(biggest, 4), 256, 0, STREAM(stream)>>>(sg, reinterpret_cast<OptState*>(const_cast<void*>(state)),
                                                                         AdamHyper{beta1, beta2, eps, weight_decay});
     return lae::check_launch("adam_apply_multi");
 }
@@ -360,7 +388,7 @@ int lae_adam_apply(float* param, float* exp_avg, float* exp_avg_sq, void* grad, 
                          reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(shadow_half);
     if (al & 15) return LAE_EINVAL;
     const AdamHyper h{beta1, beta2, eps, weight_decay};
-    const OptState* st = reinterpret_cast<const OptState*>(state);
+    OptState* st = reinterpret_cast<OptState*>(const_cast<void*>(state));
     if (grad_is_half)
         k_apply<half_t><<<stream_blocks(n, 4), 256, 0, STREAM(stream)>>>(param, exp_avg, exp_avg_sq, (half_t*)grad, (half_t*)shadow_half, n, st, lr, h);
     else

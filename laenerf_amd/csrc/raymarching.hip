@@ -664,7 +664,7 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_bwd(
 // k_mse_fwd and k_composite_train_bwd<true> (grad_scale = 1), statement for statement.  The loss VALUE needs all rays:
 // every workgroup leaves the sum of its rays' squared errors in partials[blockIdx.x], k_loss_finish adds them in a fixed
 // order (deterministic).
-struct StepLoss { const float* target; const float* scale; float* grad_image; float* partials; };
+struct StepLoss { const float* target; const float* scale; float* grad_image; float* partials; float* poison_loss; };
 
 __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
@@ -800,6 +800,9 @@ __global__ __launch_bounds__(COMP_BLOCK) void k_composite_train_step(
 #pragma unroll
         for (int w = 0; w < COMP_WAVES; w++) t += s_sq[w];
         sl.partials[blockIdx.x] = t;
+        // deferred loss value (lae_composite_rays_train_step with poison_loss): whoever reads it before the finishing
+        // launch (lae_loss_finish, or the extra block of lae_nerf_head_backward) sees NaN, not a stale number
+        if (blockIdx.x == 0 && sl.poison_loss) { sl.poison_loss[0] = __builtin_nanf(""); sl.poison_loss[1] = __builtin_nanf(""); }
     }
 }
 
@@ -1424,19 +1427,29 @@ int lae_composite_rays_train_step(const float* sigmas, const float* rgbs, const 
                                   float bg_g, float bg_b, const uint32_t* rows_end, const float* target, const float* scale,
                                   float* weights_sum, float* depth, float* image, float* depth_out, float* image_out,
                                   float* grad_image, float* grad_sigmas, float* grad_rgbs, float* loss_out, float* partials,
-                                  void* stream) {
+                                  int defer_loss, void* stream) {
     if (N == 0) return LAE_OK;
     if (!rays || !weights_sum || !depth || !image || !nears || !fars || !depth_out || !image_out || !rows_end || !target || !grad_image ||
         !loss_out || !partials)
         return LAE_ENULL;
     if (M > 0 && (!sigmas || !rgbs || !deltas || !grad_sigmas || !grad_rgbs)) return LAE_ENULL;
     const Blend bl{nears, fars, bg_rays, {bg_r, bg_g, bg_b}, image_out, depth_out};
-    const StepLoss sl{target, scale, grad_image, partials};
+    const StepLoss sl{target, scale, grad_image, partials, defer_loss ? loss_out : nullptr};
     const uint32_t nb = lae::cdiv(N, COMP_WAVES);
     k_composite_train_step<<<nb, COMP_BLOCK, 0, STREAM(stream)>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, bl,
                                                                  sl, rows_end, grad_sigmas, grad_rgbs);
-    k_loss_finish<<<1, 1024, 0, STREAM(stream)>>>(partials, nb, 3u * N, scale, loss_out);
+    // defer_loss: the one-block sum of the partials (5.5 us + a kernel boundary on the step's critical path for a number that
+    // feeds nothing on the device) is left to lae_loss_finish or to a later launch that takes it along
+    // (lae_nerf_head_backward); loss_out holds NaN until then
+    if (!defer_loss) k_loss_finish<<<1, 1024, 0, STREAM(stream)>>>(partials, nb, 3u * N, scale, loss_out);
     return lae::check_launch("composite_rays_train_step");
+}
+
+int lae_loss_finish(const float* partials, uint32_t n_part, uint32_t n_elem, const float* scale, float* loss_out, void* stream) {
+    if (!partials || !loss_out) return LAE_ENULL;
+    if (n_elem == 0) return LAE_EINVAL;
+    k_loss_finish<<<1, 1024, 0, STREAM(stream)>>>(partials, n_part, n_elem, scale, loss_out);
+    return lae::check_launch("loss_finish");
 }
 
 int lae_composite_rays_train_backward_blend_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,

@@ -96,6 +96,14 @@ class FusedAdam(torch.optim.Optimizer):
             from .raymarching.raymarching import register_unit_root_grad
             register_unit_root_grad(one)                   # the fused criterion node skips the multiplication by it
         loss.backward(gradient=one)
+        self.finish_loss()
+
+    @staticmethod
+    def finish_loss():
+        """a loss value deferred by the fused criterion (raymarching.composite_rays_train_blend_mse) that no backward kernel took
+        along is summed now; no-op otherwise"""
+        from .backend import flush_pending_loss
+        flush_pending_loss()
 
     def get_scale(self):
         return float(self._scale_view[0].item())
@@ -204,6 +212,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             raise RuntimeError("FusedAdam.step: closures are not supported")
         self.sync_lr()
+        self.finish_loss()
         lib, st, s = _lib.load(), self.dev_state.data_ptr(), _lib.stream()
         a = self._tables()
         for *_, shadow, _ in self.items:                     # an accumulator written by something that does not report where:

@@ -268,7 +268,7 @@ class _composite_rays_train_blend_mse(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh, target, scale):
+    def forward(ctx, sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg, rows_end, T_thresh, target, scale, defer_loss=False):
         sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
         M, N = sigmas.shape[0], rays.shape[0]
         dev, dt = sigmas.device, sigmas.dtype
@@ -284,7 +284,7 @@ class _composite_rays_train_blend_mse(Function):
         partials = torch.empty((N + 3) // 4, dtype=torch.float32, device=dev)
         _backend.composite_rays_train_step(sigmas, rgbs, deltas, rays, M, N, T_thresh, nears.contiguous(), fars.contiguous(), bg_rays,
                                            bg, rows_end, target, scale, weights_sum, depth, image, depth_out, image_out, grad_image,
-                                           grad_sigmas, grad_rgbs, out, partials)
+                                           grad_sigmas, grad_rgbs, out, partials, defer_loss=defer_loss)
         ctx.save_for_backward(grad_sigmas, grad_rgbs)
         ctx.mark_non_differentiable(weights_sum, depth_out, image_out, out)
         ctx.set_materialize_grads(False)                 # no zero-filled gradients for the four auxiliary outputs (4 fill launches)
@@ -294,17 +294,21 @@ class _composite_rays_train_blend_mse(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad_loss, *_):
         if grad_loss is None:
-            return (None,) * 12
+            return (None,) * 13
         grad_sigmas, grad_rgbs = ctx.saved_tensors
         if not _is_unit_root_grad(grad_loss):              # a general upstream gradient: d(loss) scales every sample gradient
             gl = grad_loss.float()
             grad_sigmas, grad_rgbs = grad_sigmas * gl, grad_rgbs * gl
-        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None
+        return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None, None
 
 
-def composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, target, bg_color=1, T_thresh=1e-4, scaler=None):
+def composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, target, bg_color=1, T_thresh=1e-4, scaler=None,
+                                   defer_loss=None):
     """-> (loss, weights_sum, depth, image): loss = MSE(image, target) times the loss scale of `scaler` (a FusedAdam, a
-    1-element fp32 cuda tensor, or None); `loss.unscaled` holds the plain MSE.  Only `loss` carries a gradient."""
+    1-element fp32 cuda tensor, or None); `loss.unscaled` holds the plain MSE.  Only `loss` carries a gradient.
+    defer_loss (default: True when `scaler` is a FusedAdam): the VALUE of loss / loss.unscaled is NaN until the backward pass
+    has run (the fused head's backward sums it in its reduction launch; FusedAdam.backward() / step() finish it otherwise) --
+    the gradients do not depend on it, and the trainer reads it after the step (nerf/utils.py `loss.item()` for logging)."""
     rows_end = getattr(rays, "rows_end", None)
     if rows_end is None:
         raise RuntimeError("composite_rays_train_blend_mse: `rays` must be the tensor returned by laenerf_amd march_rays_train")
@@ -312,8 +316,10 @@ def composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, targ
     scale = None
     if scaler is not None:
         scale = scaler if torch.is_tensor(scaler) else (scaler._scale_view[:1] if scaler.use_scaler else None)
+    if defer_loss is None:
+        defer_loss = scaler is not None and not torch.is_tensor(scaler) and hasattr(scaler, "finish_loss")
     loss, weights_sum, depth, image, both = _composite_rays_train_blend_mse.apply(sigmas, rgbs, deltas, rays, nears, fars, bg_rays, bg,
-                                                                                  rows_end, T_thresh, target, scale)
+                                                                                  rows_end, T_thresh, target, scale, bool(defer_loss))
     loss.unscaled = both[1]
     return loss, weights_sum, depth, image
 

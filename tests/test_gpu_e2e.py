@@ -218,6 +218,56 @@ def test_fused_criterion_equals_separate_loss():
     assert torch.equal(g0[2], g1[2])
 
 
+def test_deferred_loss_value_is_finished_by_the_backward_pass():
+    """with a FusedAdam as the scaler the criterion's final one-block sum is taken off the step's critical path: the loss VALUE is
+    NaN until the backward pass has run (the fused head's reduction launch carries it; FusedAdam.backward / step finish it
+    otherwise) and then holds the same bits as the immediate sum; gradients are unaffected"""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    torch.manual_seed(5)
+    net = NeRFNetwork(bound=1, log2_hashmap_size=14).to(DEV)
+    net.encoder.embeddings.data.uniform_(-0.3, 0.3)
+    r = NeRFRenderer(net, bound=1).to(DEV)
+    r.density_bitfield = T(S.pack_bits_np(S.sphere_density_grid(), 10.0))
+    opt = FusedAdam(net, param_groups=net.get_params(1e-2), init_scale=512.0)
+    o, d = S.lego_like_rays(1000, seed=6)
+    o, d = T(o), T(d)
+    gt = torch.rand(1000, 3, device=DEV)
+    net.train()
+    vals = []
+    for how in ("immediate", "head_backward", "optimizer_backward_without_head", "step_only"):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            marched = r.march_train(o, d, perturb=False)
+            if how == "immediate":
+                from laenerf_amd import raymarching as rm
+                xyzs, dirs, deltas, rays, nears, fars = marched[:6]
+                sigmas, rgbs = net(xyzs, dirs)
+                loss, *_ = rm.composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, gt, 1, 1e-4, opt, defer_loss=False)
+                assert torch.isfinite(loss).item() and torch.isfinite(loss.unscaled).item()
+            else:
+                loss = r.shade_train(marched, bg_color=1, gt=gt, scaler=opt)["loss"]
+                assert torch.isnan(loss).item() and torch.isnan(loss.unscaled).item()      # not summed yet: loudly so
+        if how in ("immediate", "head_backward"):
+            opt.backward(loss)                                   # the fused head's backward carries the sum
+        elif how == "optimizer_backward_without_head":
+            from laenerf_amd import backend
+            pend = list(backend._pending_loss); backend._pending_loss.clear()          # nobody takes it along ...
+            opt.backward(loss)
+            assert torch.isnan(loss).item()
+            backend._pending_loss[:] = pend
+            opt.finish_loss()                                    # ... FusedAdam finishes it
+        else:
+            loss.backward()                                      # plain autograd backward: the head's backward carries it
+        vals.append((loss.detach().clone(), loss.unscaled.clone(), net.sigma_net.shadow.grad_half.clone()))
+        opt.zero_grad()
+    for v in vals[1:]:
+        assert torch.equal(v[0], vals[0][0]) and torch.equal(v[1], vals[0][1]) and torch.equal(v[2], vals[0][2])
+    assert vals[0][0].item() == pytest.approx(512.0 * vals[0][1].item(), rel=1e-6)
+
+
 def test_cfg0_run_path_train_step():
     """BASELINE configs[0]: lego 64x64, 1024 rays, L=4 hash grid, nn.Linear nets, cuda_ray off -> NeRFRenderer.run with
     num_steps 512 / upsample_steps 0 (main_nerf.py:32-35), fp32, one train step (forward, MSE, backward) against the
