@@ -193,9 +193,18 @@ def frame_workload(args, world, rank, dev, backend_name):
     o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 
+    # rows per iteration of the device-resident loop: the reference's rule sizes an iteration by the rays of THE CALL
+    # (n_step = max(min(N // n_alive, 8), 1), renderer.py:363), so a rank holding 1/W of the rays would run the whole frame's
+    # iteration count on 1/W of the work per iteration -- 177 launch-chain latencies for a ninth of the samples (42 ms per shard
+    # against 72 ms for the whole frame on one GPU, `frame1080.shard_of_8` of the default line).  With W > 1 every rank
+    # therefore takes the WHOLE frame's row budget (row_budget = W x its rays): same per-ray sample sequences, <= 1e-5 image
+    # difference (rays_t rounding at other boundaries: tests/test_gpu_frame.py::test_frame_loop_row_budget), a few times
+    # fewer iterations.  LAE_FRAME_REFERENCE_SCHEDULE=1 keeps the reference's rule on every rank.
+    budget = 0 if (world == 1 or os.environ.get("LAE_FRAME_REFERENCE_SCHEDULE") == "1") else None
+
     def render(ro, rd):
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            return r.render_eval(ro, rd, bg_color=1, max_steps=1024)
+            return r.render_eval(ro, rd, bg_color=1, max_steps=1024, row_budget=(world * ro.shape[0] if budget is None else budget))
 
     def frame():
         return render_frame_sharded(render, o, d, rank, world)
@@ -251,9 +260,11 @@ def frame1080(dev, frames=5):
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
     stats = {}
 
+    budget = {"rows": 0}
+
     def render(ro, rd):
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            res = r.render_eval(ro, rd, bg_color=1, max_steps=1024, want_stats=True)
+            res = r.render_eval(ro, rd, bg_color=1, max_steps=1024, want_stats=True, row_budget=budget["rows"])
         stats.update(res["stats"])
         return res
 
@@ -267,12 +278,19 @@ def frame1080(dev, frames=5):
     t, res = timed(lambda: render_frame_sharded(render, o, d, 0, 1))
     whole = dict(stats)
     t8, _ = timed(lambda: render_shard(render, o, d, 0, 8))
+    ref8 = dict(stats)
+    budget["rows"] = H * W                                     # the whole frame's row budget on the shard (what --gpus 8 runs)
+    t8b, _ = timed(lambda: render_shard(render, o, d, 0, 8))
+    budget["rows"] = 0
     return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
             "iterations": whole["iterations"], "samples_through_network": whole["rows"],
             "Msamples_per_s": round(whole["rows"] / t / 1e6, 1),
             "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
-            "shard_of_8": {"ms": round(t8 * 1e3, 2), "rays": int(-(-(-(-H * W // 128)) // 8) * 128), "iterations": stats["iterations"],
-                           "note": "rank 0's tiles of an 8-way round-robin split rendered alone on this one GPU"},
+            "shard_of_8": {"ms": round(t8b * 1e3, 2), "iterations": stats["iterations"], "rays": int(-(-(-(-H * W // 128)) // 8) * 128),
+                           "reference_schedule_ms": round(t8 * 1e3, 2), "reference_schedule_iterations": ref8["iterations"],
+                           "note": "rank 0's tiles of an 8-way round-robin split rendered alone on this one GPU, with the whole frame's "
+                                   "row budget per iteration (what `--workload frame1080 --gpus 8` runs per rank) and with the "
+                                   "reference's per-call rule"},
             "gather_bytes_per_rank_at_8": int(-(-(-(-H * W // 128)) // 8) * 128 * 5 * 4),
             "note": "configs[3]-shaped (mip360/bonsai) 1080p inference frame, fixed eval model (seed 1234), device-resident loop, "
                     "through dist.render_frame_sharded (W = 1: no exchange); tests/test_gpu_frame1080.py checks the W = 2 / 8 "
