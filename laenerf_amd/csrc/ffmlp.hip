@@ -42,7 +42,15 @@ template <int KT, typename LoadA>
 __device__ __forceinline__ f4 mfma_ksteps(LoadA&& a_of, const h4* b, f4 acc) {
 #pragma unroll
     for (int kt = 0; kt + 1 < KT; kt += 2) acc = mfma32(a_of(kt), a_of(kt + 1), b[kt], b[kt + 1], acc);
-    if constexpr (KT & 1) acc = mfma16(a_of(KT - 1), b[KT - 1], acc);
+    // The odd tail is a K = 32 step with zeros in the upper k-slots, NOT the K = 16 instruction: a v_mfma_f32_16x16x16_f16
+    // whose accumulator input is the result of the v_mfma_f32_16x16x32_f16 issued just before it read a stale accumulator in
+    // k_mlp_bwd_wave<48, 1> (second tile's first-layer sums wrong, correct again with this form or with unrelated code moved:
+    // tests/test_gpu_ffmlp.py[*-48-64-2], tools/mlp_debug.py) -- the compiler's wait-state padding between the two shapes is
+    // not enough on gfx950.  Same cycles (the K = 16 form occupies the pipe as long as the K = 32 form), same sums.
+    if constexpr (KT & 1) {
+        const h4 z = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+        acc = mfma32(a_of(KT - 1), z, b[KT - 1], z, acc);
+    }
     return acc;
 }
 
@@ -473,10 +481,11 @@ __device__ __forceinline__ void layer64(const half_t* Wl, int ld, const h4 (&in)
             const half_t* wr = Wl + (mt * 16 + c) * ld + kt * 16 + 4 * g;
             acc[mt] = mfma32(*reinterpret_cast<const h4*>(wr), *reinterpret_cast<const h4*>(wr + 16), in[kt], in[kt + 1], acc[mt]);
         }
-    if constexpr (KT & 1) {                                  // odd tail: one K = 16 step
+    if constexpr (KT & 1) {                                  // odd tail: a K = 32 step with zero upper k-slots (see mfma_ksteps)
+        const h4 z = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
 #pragma unroll
         for (int mt = 0; mt < 4; mt++)
-            acc[mt] = mfma16(*reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + (KT - 1) * 16 + 4 * g), in[KT - 1], acc[mt]);
+            acc[mt] = mfma32(*reinterpret_cast<const h4*>(Wl + (mt * 16 + c) * ld + (KT - 1) * 16 + 4 * g), z, in[KT - 1], z, acc[mt]);
     }
 }
 // ReLU + fp16 rounding of a 64-wide layer.  round(max(x, 0)) == max(round(x), 0), so the maximum is taken on the packed
@@ -1147,10 +1156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const size_t Bn = (size_t)n_tiles * 16;
     // ---- inputs, requested one pair ahead (one wave per SIMD: nothing else hides a memory latency per pair)
     struct Req { h4 xf[2][KT0]; h4 gf[2]; h4 hq[2]; float dir[2][3], y[2][3], gy[2][3], gs[2]; };
-    // (requests ahead only for an even number of input k-steps: with KT0 = 3 the build with the loop-carried request gave wrong
-    // first-layer operands for the second tile -- same source, correct without the carry; found by tests/test_gpu_ffmlp.py
-    // [*-48-64-*], not understood, so that shape takes the plain path)
-    constexpr bool AHEAD = WPE == 1 && (KT0 % 2 == 0);
+    constexpr bool AHEAD = WPE == 1;
     Req nx = {};                                                         // (copied whole below: no member may be indeterminate)
     auto request = [&](uint32_t pair) {
 #pragma unroll
@@ -1249,35 +1255,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (!act[t]) gf[t] = zero4;
         }
         MLP_PHASE(blockIdx.x * 4 + w, 0);
-        // ---- recompute the hidden activations (post-ReLU) of both tiles; one fragment read serves both
+        // ---- recompute the hidden activations (post-ReLU) of both tiles; one fragment read serves both.  The fragments of a
+        // layer are requested one layer AHEAD (with one wave per SIMD nothing else covers an LDS latency: 42 % of the wave's
+        // cycles were s_waitcnt, profiles/r3a_sq_stall_breakdown.txt) and pinned there with a scheduling barrier.
         h4 h[2][NH + 1][4];
         {
+            auto load_w0 = [&](h4 (&a)[4][KT0]) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int kt = 0; kt < KT0; kt++) a[mt][kt] = *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g);
+            };
+            auto load_wh = [&](int l, h4 (&a)[4][4]) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++) a[mt][kt] = *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g);
+            };
             f4 acc[2][4];
+            h4 a0[4][KT0], a1[4][4], a2[4][4];
+            load_w0(a0);
+            load_wh(0, a1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                h4 a[KT0];
+            for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-                for (int kt = 0; kt < KT0; kt++) a[kt] = *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[t][mt] = mfma_ksteps<KT0>([&](int kt) { return a[kt]; }, xf[t], f4{0, 0, 0, 0});
-            }
+                for (int t = 0; t < 2; t++) acc[t][mt] = mfma_ksteps<KT0>([&](int kt) { return a0[mt][kt]; }, xf[t], f4{0, 0, 0, 0});
+            if constexpr (NH > 1) load_wh(1, a2);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 2; t++) relu4(acc[t], h[t][0]);
 #pragma unroll
             for (int l = 0; l < NH; l++) {
 #pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    h4 a[4];
+                for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-                    for (int kt = 0; kt < 4; kt++) a[kt] = *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g);
-#pragma unroll
-                    for (int t = 0; t < 2; t++) acc[t][mt] = mfma_ksteps<4>([&](int kt) { return a[kt]; }, h[t][l], f4{0, 0, 0, 0});
-                }
+                    for (int t = 0; t < 2; t++)
+                        acc[t][mt] = mfma_ksteps<4>([&](int kt) { return (l & 1) ? a2[mt][kt] : a1[mt][kt]; }, h[t][l], f4{0, 0, 0, 0});
+                static_assert(NH <= 2, "fragment double buffer: two hidden GEMMs at most");
 #pragma unroll
                 for (int t = 0; t < 2; t++) relu4(acc[t], h[t][l + 1]);
             }
         }
         MLP_PHASE(blockIdx.x * 4 + w, 1);
+        // transposed weight fragments (A[f][o] = W[o][f]) of the chain, likewise requested one step ahead
+        auto load_wt = [&](int l, h4 (&a)[4][4]) {               // W_l^T of hidden GEMM l (1-based)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int kt = 0; kt < 4; kt++) a[mt][kt] = lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp);
+        };
+        h4 wt[2][4][4];                                         // double buffer: hidden layer l uses wt[l & 1]
+        h4 wo[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) wo[mt] = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);            // A[f][o] = Wout[o][f]
+        load_wt(NH, wt[NH & 1]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- output layer: dWout += G^T H_NH over the 32 rows ; dH_NH = (Wout^T G) * relu'
         h4 d[2][4];
         {
@@ -1287,11 +1320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             for (int t = 0; t < 2; t++) mfma_transpose_n<4>(h[t][NH], ident, TH[t]);
             f4 da[2][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const h4 a = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);             // A[f][o] = Wout[o][f]
+            for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) da[t][mt] = mfma16(a, gf[t], f4{0, 0, 0, 0});
-            }
+                for (int t = 0; t < 2; t++) da[t][mt] = mfma16(wo[mt], gf[t], f4{0, 0, 0, 0});
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) dWo[nt] = mfma32(TG[0], TG[1], TH[0][nt], TH[1][nt], dWo[nt]);
 #pragma unroll
@@ -1301,20 +1332,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
         MLP_PHASE(blockIdx.x * 4 + w, 2);
         // ---- hidden layers, last to first: dW_l += D_l^T H_{l-1} ; dH_{l-1} = (W_l^T dH_l) * relu'
+        h4 wx[MODE == 1 ? 1 : KT0][4];                          // W0^T fragments of the dX product (MODE 1: features 16..31 only)
 #pragma unroll
         for (int l = NH; l >= 1; l--) {
+            if (l > 1) load_wt(l - 1, wt[(l - 1) & 1]);          // next step's fragments
+            else {
+#pragma unroll
+                for (int it = 0; it < (MODE == 1 ? 1 : KT0); it++)
+#pragma unroll
+                    for (int kt = 0; kt < 4; kt++)
+                        wx[it][kt] = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + (MODE == 1 ? 16 : it * 16) + 4 * tp);   // W0^T
+            }
+            __builtin_amdgcn_sched_barrier(0);
             h4 TD[2][4], TH[2][4];
 #pragma unroll
             for (int t = 0; t < 2; t++) { mfma_transpose_n<4>(d[t], ident, TD[t]); mfma_transpose_n<4>(h[t][l - 1], ident, TH[t]); }
             f4 da[2][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                h4 a[4];
+            for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-                for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp);   // W_l^T
-#pragma unroll
-                for (int t = 0; t < 2; t++) da[t][mt] = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
-            }
+                for (int t = 0; t < 2; t++) da[t][mt] = mfma_ksteps<4>([&](int kt) { return wt[l & 1][mt][kt]; }, d[t], f4{0, 0, 0, 0});
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -1336,12 +1373,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 for (int nt = 0; nt < KT0; nt++) dW0[mt][nt] = mfma32(TD[0][mt], TD[1][mt], TX[0][nt], TX[1][nt], dW0[mt][nt]);
         }
         if constexpr (MODE == 1) {
-            h4 a[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp);   // W0^T, features 16..31
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const f4 acc = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
+                const f4 acc = mfma_ksteps<4>([&](int kt) { return wx[0][kt]; }, d[t], f4{0, 0, 0, 0});
                 const half_t v3 = (half_t)acc[3];
                 const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
                 h4 v;
@@ -1353,12 +1387,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         } else if (grad_in) {
 #pragma unroll
             for (int it = 0; it < KT0; it++) {
-                h4 a[4];
-#pragma unroll
-                for (int kt = 0; kt < 4; kt++) a[kt] = lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp);   // W0^T
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const f4 acc = mfma_ksteps<4>([&](int kt) { return a[kt]; }, d[t], f4{0, 0, 0, 0});
+                    const f4 acc = mfma_ksteps<4>([&](int kt) { return wx[MODE == 1 ? 0 : it][kt]; }, d[t], f4{0, 0, 0, 0});
                     h4 v;
 #pragma unroll
                     for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];

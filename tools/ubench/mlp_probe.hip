@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DLAE_MLP_STAMPS \
 //         -I include tools/ubench/mlp_probe.hip laenerf_amd/csrc/lae_common.cpp -o tools/ubench/bin/mlp_probe
 #include "../../laenerf_amd/csrc/ffmlp.hip"
+extern "C" int lae_loss_finish(const float*, uint32_t, uint32_t, const float*, float*, void*) { return 0; }   // lives in raymarching.hip; not used here
 #include <stdio.h>
 #include <vector>
 #include <algorithm>
@@ -50,7 +51,7 @@ int main(int argc, char** argv) {
         hipMalloc(&gs, (size_t)M * 4); hipMalloc(&gr, (size_t)M * 12); hipMalloc(&gh, (size_t)M * 32); hipMalloc(&genc, (size_t)M * 64);
         hipMemset(gs, 0, (size_t)M * 4); hipMemset(gr, 0, (size_t)M * 12); hipMemset(gh, 0, (size_t)M * 32);
         k_nerf_head_fwd5<true, 8><<<256, 512, lds5>>>(enc, dirs, ws, wc, n_tiles, 1.0f, hout, sig, rgb, 1, nullptr, M);
-        const uint32_t nb = std::min(((n_tiles + 1) / 2 + 3) / 4, (uint32_t)p.multiProcessorCount * (variant == 100 ? 2 : 1));
+        const uint32_t nb = std::min(((n_tiles + 1) / 2 + 3) / 4, (uint32_t)p.multiProcessorCount);
         const uint32_t nWc = 64 * (32 + 128 + 16), nWs = 64 * (32 + 64 + 16);
         hipMalloc(&slabs, (size_t)nb * nWc * 4);
         HeadBwdArgs ha{dirs, rgb, gr, gs, 1.0f, 0}, hs{}; hs.level_major = 1;
