@@ -250,7 +250,46 @@ def make_ff_net(bound, seed):
     return net
 
 
+class half_table_path:
+    """the reference's `-O` precision path for the hash grid, on the CPU: under cuda autocast grid.py:41-44 casts the table to
+    half, the encoder accumulates and returns halves, and the backward receives a half gradient and adds halves into a half
+    gradient table (gridencoder.cu:325-331).  Without a GPU autocast is off, so the backend registered as `_gridencoder` does
+    those casts itself for the duration of this block (round 3: the GPU runs this very path, so the golden gradients can be
+    asserted at rounding level instead of 5-8 %)."""
+
+    def __enter__(self):
+        ge = sys.modules["_gridencoder"]
+        self.ge, self.fwd, self.bwd = ge, ge.grid_encode_forward, ge.grid_encode_backward
+        fwd, bwd = self.fwd, self.bwd
+
+        def forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
+            assert dy_dx is None
+            out_h = torch.empty(outputs.shape, dtype=torch.float16)
+            fwd(inputs, embeddings.to(torch.float16).contiguous(), offsets, out_h, B, D, C, L, S, H, None, gridtype, align_corners, interp)
+            outputs.copy_(out_h)
+
+        def backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp):
+            assert dy_dx is None and grad_inputs is None
+            ge_h = torch.zeros(grad_embeddings.shape, dtype=torch.float16)
+            bwd(grad.to(torch.float16).contiguous(), inputs, embeddings.to(torch.float16).contiguous(), offsets, ge_h, B, D, C, L, S, H, None,
+                None, gridtype, align_corners, interp)
+            grad_embeddings.add_(ge_h.float())
+        ge.grid_encode_forward, ge.grid_encode_backward = forward, backward
+        return self
+
+    def __exit__(self, *a):
+        self.ge.grid_encode_forward, self.ge.grid_encode_backward = self.fwd, self.bwd
+
+
+E2E_LOSS_SCALE = 1024.0      # the fp16 gradients need the loss scale the reference trains with (GradScaler); the stored gradients are unscaled
+
+
 def gen_e2e(tag, bound):
+    with half_table_path():
+        _gen_e2e(tag, bound)
+
+
+def _gen_e2e(tag, bound):
     C = 1 + int(np.ceil(np.log2(bound)))
     net = make_ff_net(bound, seed=11)
     grid = S.sphere_density_grid(cascade=C, bound=float(bound), radius=0.55)
@@ -268,13 +307,15 @@ def gen_e2e(tag, bound):
     net.train()
     res = net.render(ro, rd, staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=256)
     loss = ((res["image"][0] - target) ** 2).mean()
-    loss.backward()
+    (loss * E2E_LOSS_SCALE).backward()
+    gt = net.encoder.embeddings.grad / E2E_LOSS_SCALE
     out.update(train_image=res["image"][0].detach().numpy(), train_depth=res["depth"][0].detach().numpy(),
                train_ws=res["weights_sum"].detach().numpy(), train_counter=net.step_counter[0].numpy().copy(),
-               train_loss=np.float64(loss.item()),
-               g_sigma_w=net.sigma_net.weights.grad.numpy().copy(), g_color_w=net.color_net.weights.grad.numpy().copy(),
-               g_table_norm=np.float64(net.encoder.embeddings.grad.norm().item()),
-               g_table_sample=net.encoder.embeddings.grad.numpy()[::997].copy())
+               train_loss=np.float64(loss.item()), loss_scale=np.float64(E2E_LOSS_SCALE),
+               g_sigma_w=(net.sigma_net.weights.grad / E2E_LOSS_SCALE).numpy().copy(),
+               g_color_w=(net.color_net.weights.grad / E2E_LOSS_SCALE).numpy().copy(),
+               g_table_norm=np.float64(gt.norm().item()), g_table_sample=gt.numpy()[::997].copy(),
+               g_table_nonzero=np.int64((gt != 0).sum().item()))
     # --- steady-state mode: mean_count > 0 (M = mean_count rounded up, may drop rays that overflow)
     net.zero_grad()
     net.mean_count = int(net.step_counter[0, 0].item() * 0.6)        # deliberately too small: exercises the overflow drop
@@ -499,7 +540,29 @@ def gen_editgrid():
     save("editgrid", **cases)
 
 
+def gen_freq():
+    """K18: the reference ships a pure-torch frequency encoder (encoding.py:5-43; `get_encoder('frequency')` builds the CUDA
+    one, whose row layout -- inputs, then per frequency the sines followed by the cosines -- it shares): executed here"""
+    from encoding import FreqEncoder as RefFreq
+    gen = torch.Generator().manual_seed(3)
+    out = {}
+    for D, deg in ((3, 4), (3, 10), (2, 6), (5, 1)):
+        x = (torch.rand(257, D, generator=gen) * 2 - 1)
+        enc = RefFreq(input_dim=D, max_freq_log2=deg - 1, N_freqs=deg, log_sampling=True)
+        y = enc(x)
+        assert y.shape == (257, D + 2 * D * deg)
+        out[f"x_{D}_{deg}"] = x.numpy(); out[f"y_{D}_{deg}"] = y.numpy()
+    save("freq_encoder", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "freq":
+        gen_freq()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e":
+        gen_e2e("b1", 1)
+        gen_e2e("b2", 2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "editgrid":
         gen_editgrid()
         sys.exit(0)
@@ -521,3 +584,4 @@ if __name__ == "__main__":
     gen_e2e("b2", 2)
     gen_run_upsample()
     gen_density_grid()
+    gen_freq()

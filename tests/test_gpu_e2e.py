@@ -31,6 +31,10 @@ def build(g):
     return net, r
 
 
+# tolerances of the e2e pins (round 2: depth 2e-3 / 3e-3, MLP gradients 5 %, table gradients 8 %, norm 5 %)
+TOL = {"depth": 2e-5, "mlp_grad": 2e-3, "table_grad": 5e-3, "table_norm": 1e-3, "depth_distill": 1e-4}      # observed: 1.5e-7, 3e-4, 1.5e-3
+
+
 @pytest.mark.parametrize("tag", ["b1", "b2"])
 def test_train_render_and_gradients(tag):
     g = golden("e2e_" + tag)
@@ -45,19 +49,27 @@ def test_train_render_and_gradients(tag):
     assert np.abs(N(res["image"]) - g["train_image"]).max() < 1e-4
     assert np.abs(N(res["weights_sum"]) - g["train_ws"]).max() < 1e-4
     hit = g["train_ws"] > 0
-    assert np.abs(N(res["depth"])[hit] - g["train_depth"][hit]).max() < 2e-3
-    assert loss.item() == pytest.approx(float(g["train_loss"]), rel=2e-3)
+    assert np.abs(N(res["depth"])[hit] - g["train_depth"][hit]).max() < TOL["depth"]
+    assert loss.item() == pytest.approx(float(g["train_loss"]), rel=1e-4)
     # fp16 gradients need the loss scale the reference trains with (GradScaler): unscaled, the table gradients of this
-    # fixture are ~1e-6, i.e. a handful of fp16 subnormal steps
-    SCALE = 1024.0
+    # fixture are ~1e-6, i.e. a handful of fp16 subnormal steps.  Round 3: the golden ran the SAME precision path (fp16
+    # table, half accumulate, half gradients, this loss scale: make_golden.py::half_table_path), so the gradients are
+    # asserted at rounding level; what remains is the fused MLP's fp32 accumulate against the oracle FFMLP's and the order
+    # in which the half gradient table is summed (exact sum rounded once here, one rounding per add there).
+    SCALE = float(g["loss_scale"])
     (loss * SCALE).backward()
+    dev = {}
     for name, ref in (("sigma_net", g["g_sigma_w"]), ("color_net", g["g_color_w"])):
         got = N(getattr(net, name).weights.grad) / SCALE
-        assert np.abs(got - ref).max() < 0.05 * np.abs(ref).max() + 1e-6, name
+        dev[name] = np.abs(got - ref).max() / np.abs(ref).max()
+        assert dev[name] < TOL["mlp_grad"], (name, dev)
     gt = N(net.encoder.embeddings.grad) / SCALE
-    assert np.linalg.norm(gt) == pytest.approx(float(g["g_table_norm"]), rel=0.05)
-    # (golden: fp32 table on the CPU; here the fp16 table path with the reference's Half accumulate: 5.04 % observed)
-    assert np.abs(gt[::997] - g["g_table_sample"]).max() < 0.08 * np.abs(g["g_table_sample"]).max() + 1e-9
+    assert np.linalg.norm(gt) == pytest.approx(float(g["g_table_norm"]), rel=TOL["table_norm"])
+    dev["table"] = np.abs(gt[::997] - g["g_table_sample"]).max() / np.abs(g["g_table_sample"]).max()
+    assert dev["table"] < TOL["table_grad"], dev
+    assert abs(int((gt != 0).sum()) - int(g["g_table_nonzero"])) <= 0.002 * int(g["g_table_nonzero"])      # the same entries are touched
+    print("e2e deviations", tag, {k: float("%.3g" % v) for k, v in dev.items()},
+          "depth", float(np.abs(N(res["depth"])[hit] - g["train_depth"][hit]).max()))
     # steady-state sizing with an under-estimated mean_count: overflowing rays drop to background
     r.mean_count = int(g["train2_mean_count"])
     with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
@@ -77,12 +89,12 @@ def test_eval_and_distill_render(tag):
             ev = r.render_eval(o, d, bg_color=1, max_steps=256, device_compaction=dc)
             assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 1e-4
             hit = g["train_ws"] > 0
-            assert np.abs(N(ev["depth"])[hit] - g["eval_depth"][hit]).max() < 2e-3
+            assert np.abs(N(ev["depth"])[hit] - g["eval_depth"][hit]).max() < TOL["depth"]
         ds = r.render_distill(o, d, T(g["edit_bitfield"]), max_steps=256)
     for k, ref in (("image", "dist_image"), ("weights", "dist_weights"), ("weights_edit", "dist_weights_edit")):
         assert np.abs(N(ds[k]) - g[ref]).max() < 1e-4, k
     for k, ref in (("depth", "dist_depth"), ("depth_edit", "dist_depth_edit"), ("x_term", "dist_x_term")):
-        assert np.abs(N(ds[k]) - g[ref]).max() < 3e-3, k
+        assert np.abs(N(ds[k]) - g[ref]).max() < TOL["depth_distill"], k
 
 
 def test_reference_backend_installation():

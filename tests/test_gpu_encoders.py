@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import golden
+
 from gpu_util import DEV, N, T, bits_from_half, half_from_bits
 
 pytestmark = pytest.mark.gpu
@@ -291,6 +293,18 @@ def test_sh_all_degrees(O, degree):
         g = rng.standard_normal(ref.shape).astype(np.float32)
         y.backward(T(g))
         assert np.allclose(N(di.grad), O.sh_encode_backward(g, ref_dd, degree), rtol=1e-4, atol=1e-4 * (1 + np.abs(ref_dd).max()))
+
+
+def test_freq_encoder_matches_the_references_own_torch_encoder():
+    """K18 pinned by execution of the reference: its pure-torch FreqEncoder (encoding.py:5-43, run by make_golden.py::gen_freq)
+    has the row layout of the CUDA encoder (inputs, then per frequency sines | cosines)"""
+    from laenerf_amd.freqencoder import freq_encode
+    g = golden("freq_encoder")
+    for D, deg in ((3, 4), (3, 10), (2, 6), (5, 1)):
+        x, ref = g[f"x_{D}_{deg}"], g[f"y_{D}_{deg}"]
+        y = freq_encode(T(x), deg, D + 2 * D * deg)
+        assert y.shape == ref.shape
+        assert np.abs(N(y) - ref).max() < 2e-6 * 2 ** deg + 2e-6              # fast-sine error grows with the argument, as above
 
 
 @pytest.mark.parametrize("D,deg", [(3, 6), (3, 10), (2, 4), (5, 1)])

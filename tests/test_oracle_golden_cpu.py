@@ -268,3 +268,12 @@ def test_cfg0_run_step_forward_from_oracle_pieces(O):
     assert np.abs(ws - g["weights_sum"]).max() < 2e-5
     assert np.abs(image - g["image"]).max() < 2e-5
     assert ((image - g["target"]) ** 2).mean() == pytest.approx(float(g["loss"]), rel=1e-5)
+
+
+def test_freq_encoder_oracle_matches_the_references_torch_encoder(O):
+    """K18: the oracle's frequency encoder against vectors from the reference's own pure-torch FreqEncoder (encoding.py:5-43)"""
+    g = golden("freq_encoder")
+    for D, deg in ((3, 4), (3, 10), (2, 6), (5, 1)):
+        x, ref = g[f"x_{D}_{deg}"], g[f"y_{D}_{deg}"]
+        y = O.freq_encode_forward(x, deg)
+        assert y.shape == ref.shape and np.abs(y - ref).max() < 2e-6 * 2 ** deg + 2e-6
