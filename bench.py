@@ -41,9 +41,10 @@ def parse():
     p.add_argument("--no-style", action="store_true", help="skip the LAENeRF palette-network step timing (extra field style_step)")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
-    p.add_argument("--workload", choices=["train", "frame1080"], default="train",
+    p.add_argument("--workload", choices=["train", "frame1080", "flower"], default="train",
                    help="train (default): the BASELINE configs[1] train step.  frame1080: configs[3]-style whole-frame render, "
-                        "1920x1080 rays sharded over the ranks in 128-ray tiles, one all-gather (RCCL) per frame; a step is a frame")
+                        "1920x1080 rays sharded over the ranks in 128-ray tiles, one all-gather (RCCL) per frame; a step is a frame.  "
+                        "flower: only the configs[2]-shaped train step of the default line's `flower_step` (for profiling)")
     p.add_argument("--dp", action="store_true",
                    help="data-parallel training (not the default metric mode): every rank trains on its own ray batch, gradients "
                         "are averaged with ONE flat all-reduce (RCCL) per dtype before the Adam step (laenerf_amd/dist.py)")
@@ -365,12 +366,73 @@ def style_step(dev, P=100000, steps=30):
             "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam, HIP-graph replay"}
 
 
-def flower_step(dev, steps=30, n_rays=4096):
+def grouped_pipeline(r, opt, batches, G, groups_ahead=2):
+    """the headline's execution scheme for any renderer / optimizer pair (fused criterion): per group of G resident ray batches
+    two captured HIP graphs -- G x {ray/box, march, counting half of the grid backward} and G x {encoder, head, compositing +
+    criterion, backward, Adam} -- the first replayed on a side stream `groups_ahead` groups before the second (it reads no
+    weight).  Returns step(i) (i = consecutive step numbers; a replay is issued at every G-th) and the samples per batch."""
+    n_batches = len(batches)
+    assert n_batches % G == 0 and n_batches // G >= 2 * groups_ahead
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    P = n_batches // G
+    marched, n_samples, g_side, g_main = [], [], [], []
+    side.wait_stream(main)
+    for p_ in range(P):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=g_side[0].pool() if g_side else None):
+            for b in range(p_ * G, (p_ + 1) * G):
+                marched.append(r.march_train(batches[b][0], batches[b][1], perturb=True, max_steps=1024, plan_backward=True))
+        g_side.append(g)
+    for p_ in range(P):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=g_main[0].pool() if g_main else None):
+            for b in range(p_ * G, (p_ + 1) * G):
+                with torch.autocast("cuda", dtype=torch.float16):
+                    res = r.shade_train(marched[b], bg_color=1, gt=batches[b][2], scaler=opt)
+                opt.backward(res["loss"])
+                opt.step()
+                n_samples.append(res["n_samples"])
+        g_main.append(g)
+    ev_side = [torch.cuda.Event() for _ in range(P)]
+    ev_main = [torch.cuda.Event() for _ in range(P)]
+    state = {"primed": -1}
+    A = groups_ahead
+
+    def launch_side(p_):
+        with torch.cuda.stream(side):
+            g_side[p_].replay()
+            ev_side[p_].record(side)
+
+    def step(i):
+        b = i % n_batches
+        if b % G:
+            return n_samples[b]
+        p_ = b // G
+        if state["primed"] != p_:
+            side.wait_stream(main)
+            for a in range(A):
+                launch_side((p_ + a) % P)
+        if not ev_side[p_].query():
+            main.wait_event(ev_side[p_])
+        g_main[p_].replay()
+        ev_main[p_].record(main)
+        nxt = (p_ + A) % P
+        side.wait_event(ev_main[nxt]) if i >= G else None
+        launch_side(nxt)
+        state["primed"] = (p_ + 1) % P
+        return n_samples[b]
+    for p_ in range(P):
+        ev_main[p_].record(main)
+    return step, n_samples
+
+
+def flower_step(dev, steps=40, n_rays=4096, G=8):
     """configs[2] (llff/flower: scripts/configs_llff/flower.sh -- bound 2 -> 2 cascades, offset (0, 0, 1.5): cameras inside
     the box, min_near 0.2, table of 6 328 848 entries with finest resolution 4096): the same train step as the headline
-    (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam) on forward-facing synthetic rays, one captured HIP
-    graph replayed (no side-stream pipelining).  Extra field, not `value`."""
-    from laenerf_amd import synthetic as S
+    (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam) on forward-facing synthetic rays, through the headline's
+    grouped two-stream pipeline (round 3; round 2 replayed one un-pipelined graph per step).  Extra field, not `value`; also
+    reports the roofline figure of its hash-grid forward (HIP events around the call in 10 eager steps)."""
+    from laenerf_amd import backend, synthetic as S
     from laenerf_amd.network import NeRFNetwork
     from laenerf_amd.optim import FusedAdam
     from laenerf_amd.renderer import NeRFRenderer
@@ -379,39 +441,67 @@ def flower_step(dev, steps=30, n_rays=4096):
     r = NeRFRenderer(net, bound=2, min_near=0.2).to(dev)
     r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.flower_density_grid(), 10.0)).to(dev)
     opt = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-    o, d = S.flower_like_rays(n_rays, seed=5)
-    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-    gt = torch.rand(n_rays, 3, device=dev)
+    batches = []
+    for b in range(4 * G):
+        o, d = S.flower_like_rays(n_rays, seed=5 + b)
+        batches.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(n_rays, 3, device=dev)))
     net.train()
 
-    def body():
+    def body(b):
+        o, d, gt = batches[b % len(batches)]
         with torch.autocast("cuda", dtype=torch.float16):
             res = r.render_train(o, d, bg_color=1, perturb=True, max_steps=1024, gt=gt, scaler=opt)
         opt.backward(res["loss"])
         opt.step()
         return res["n_samples"]
     for i in range(17):                                       # mean_count mode needs 16 sized steps (renderer.py:644-647)
-        body()
+        body(i)
     r.update_mean_count()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            body()
+    with torch.cuda.stream(side):                             # warm-up on a capture-capable stream (allocations, workspaces)
+        for i in range(3):
+            body(i)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    # one un-pipelined graph (the round-2 figure, for comparison)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        n_samples = body()
+        n_one = body(0)
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         g.replay()
     torch.cuda.synchronize()
+    dt_one = (time.perf_counter() - t0) / steps
+    step, n_samples = grouped_pipeline(r, opt, batches, G)
+    steps = (steps + G - 1) // G * G
+    for i in range(4 * G):
+        step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        step(4 * G + i)
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(dt * 1e3, 4), "Mrays_per_s": round(n_rays / dt / 1e6, 3), "rays": n_rays, "samples_per_step": int(n_samples),
-            "note": "configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box, one graph per step (not pipelined)"}
+    backend.enable_kernel_timing(True, only=None)
+    for i in range(10):
+        body(i)
+    tm = backend.collect_kernel_timing()
+    backend.enable_kernel_timing(False)
+    gf = tm.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
+    per_launch = gf["units"] / max(gf["calls"], 1)
+    us = gf["ms"] / max(gf["calls"], 1) * 1e3
+    gbs = per_launch * GRID_FWD_BYTES_FP16 / (us * 1e-6) / 1e9 if gf["calls"] else float("nan")
+    return {"ms_per_step": round(dt * 1e3, 4), "Mrays_per_s": round(n_rays / dt / 1e6, 3), "rays": n_rays,
+            "samples_per_step": int(np.mean(n_samples)), "one_graph_per_step_ms": round(dt_one * 1e3, 4),
+            "steps_per_graph_replay": G,
+            "grid_forward": {"avg_launch_us": round(us, 2), "samples_per_launch": int(per_launch), "achieved_GBs": round(gbs, 1),
+                             "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": GRID_FWD_BYTES_FP16,
+                             "table_entries": int(net.encoder.embeddings.shape[0]), "finest_resolution": 4096},
+            "operator_ms_per_step": {k: round(v["ms"] / 10, 4) for k, v in sorted(tm.items())},
+            "note": "configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box; grouped two-stream pipeline like the "
+                    "headline (march + counting pass of step k+2 beside shading / backward / Adam of step k)"}
 
 
 def cpu_baseline_cfg1(n_threads, budget_s=8.0):
@@ -496,6 +586,9 @@ def main():
     if world > 1:
         dist.barrier()
 
+    if args.workload == "flower":
+        print(json.dumps({"flower_step": flower_step(dev)}), flush=True)
+        return
     if args.workload == "frame1080":
         if args.steps == 200 and args.warmup == 40:            # the train defaults are too long for whole frames
             args.steps, args.warmup = 20, 3
