@@ -422,7 +422,9 @@ LAE_API int lae_nerf_head_forward(const void* enc, const float* dirs, const void
 /* The density query of NeRFNetwork.density (nerf/network_ff.py:83-96) after the encoder: sigma FFMLP -> sigma =
  * density_scale * exp(h[0]); h_out [M,16] fp16 (h[1..15] = geo_feat) may be NULL.  Used by update_extra_state. */
 LAE_API int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_t M, float density_scale, void* h_out,
-                             float* sigmas, void* stream);
+                             float* sigmas, int enc_level_major, void* stream);
+/* enc_level_major (round 3): as in lae_nerf_head_forward -- the occupancy-grid maintenance queries the density of 2.1 M
+ * cells per cascade and needs neither the [M,32] transpose of the features nor h. */
 
 /* Backward of lae_nerf_head_forward: grad_sigmas [M], grad_rgbs [M,3] fp32 (as produced by
  * lae_composite_rays_train_backward) -> grad_enc [M,32] fp16 (may be NULL), grad_*_weights (fp16, flat FFMLP layout).

@@ -65,7 +65,7 @@ SIGNATURES = {
     "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],
     "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, i32, vp],
-    "lae_nerf_density_forward": [vp, vp, u32, f32, vp, vp, vp],
+    "lae_nerf_density_forward": [vp, vp, u32, f32, vp, vp, i32, vp],
     "lae_density_grid_positions": [vp, u32, u32, f32, vp, vp, vp, vp],
     "lae_density_grid_update": [vp, vp, u32, f32, f32, u32, vp, vp, vp],
     "lae_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, f32, i32, vp, vp],

@@ -480,11 +480,11 @@ class _FFMLP:
                                                 int(bool(level_major)), stream()), "nerf_head_forward")
 
     @staticmethod
-    def nerf_density_forward(enc, sigma_weights, M, density_scale, h_out, sigmas):
+    def nerf_density_forward(enc, sigma_weights, M, density_scale, h_out, sigmas, level_major=False):
         need_cuda(enc, sigma_weights, h_out, sigmas); need_contig(enc, sigma_weights, h_out, sigmas)
         _FFMLP._half(enc, sigma_weights, h_out)
         check(_lib.load().lae_nerf_density_forward(ptr(enc), ptr(sigma_weights), M, float(density_scale), ptr(h_out),
-                                                   ptr(sigmas), stream()), "nerf_density_forward")
+                                                   ptr(sigmas), int(bool(level_major)), stream()), "nerf_density_forward")
 
     @staticmethod
     def nerf_head_backward(grad_sigmas, grad_rgbs, enc, dirs, h, rgbs, sigma_weights, color_weights, M, density_scale,

@@ -2281,26 +2281,26 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
 }
 
 int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_t M, float density_scale, void* h_out,
-                             float* sigmas, void* stream) {
+                             float* sigmas, int enc_level_major, void* stream) {
     if (M == 0) return LAE_OK;
     if (!enc || !sigma_weights || !sigmas) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
     if (head_fwd_variant() == 2 && (reinterpret_cast<uintptr_t>(sigma_weights) & 15) == 0) {
         const int rc = launch_head_fwd5<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
-                                               (half_t*)h_out, sigmas, nullptr, 0, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+                                               (half_t*)h_out, sigmas, nullptr, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
         return rc != LAE_OK ? rc : lae::check_launch("nerf_density_forward");
     }
     if (head_fwd_variant() == 1) {
         launch_head_fwd4<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
-                                (half_t*)h_out, sigmas, nullptr, 0, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+                                (half_t*)h_out, sigmas, nullptr, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
         return lae::check_launch("nerf_density_forward");
     }
     const size_t lds_bytes = (size_t)HeadCfg::S_END * 2;                 // sigma-net image only (< 64 KiB)
     const uint32_t n_tiles = M / 16;
     const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
     k_nerf_head_fwd<false><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr, 0,
-        nullptr, M);
+        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr,
+        enc_level_major, nullptr, M);
     return lae::check_launch("nerf_density_forward");
 }
 

@@ -115,3 +115,25 @@ def field_backward_plan(x, enc, bound=1):
     return _grid.grid_backward_plan(x, enc.offsets, x.shape[0], 3, 2, enc.num_levels, np.log2(enc.per_level_scale), enc.base_resolution,
                                     enc.gridtype_id, enc.align_corners, enc.interp_id, True, in_map, offsets_host=enc.offsets_host,
                                     touched_lines=touched)
+
+
+@torch.no_grad()
+def field_density(x, enc, sigma_net, bound=1, density_scale=1.0):
+    """sigma [M] fp32 of the points x [M,3] -- what the occupancy-grid maintenance asks of NeRFNetwork.density
+    (nerf/renderer.py:594, 625: only `sigma` is read).  Encoder output stays level-major (no [M,32] transpose: 52 us per
+    2.1 M-cell sweep), the sigma net's h is not stored (67 MB per sweep)."""
+    M = x.shape[0]
+    Mp = (M + 15) // 16 * 16
+    x = x.float().contiguous()
+    if Mp != M:
+        x = torch.cat([x, x.new_zeros(Mp - M, 3)], dim=0)
+    table = enc.shadow.table_half(enc.embeddings) if enc.shadow is not None else enc.embeddings.detach().to(torch.half)
+    ws = sigma_net.shadow.table_half(sigma_net.weights) if sigma_net.shadow is not None else sigma_net.weights.detach().half().contiguous()
+    in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+    L = enc.num_levels
+    feats = torch.empty(L, Mp, 2, device=x.device, dtype=torch.half)
+    _grid.grid_encode_forward(x, table, enc.offsets, feats, Mp, 3, 2, L, np.log2(enc.per_level_scale), enc.base_resolution, None,
+                              enc.gridtype_id, enc.align_corners, enc.interp_id, blc=False, in_map=in_map, offsets_host=enc.offsets_host)
+    sigmas = torch.empty(Mp, device=x.device, dtype=torch.float32)
+    _mlp.nerf_density_forward(feats, ws, Mp, density_scale, None, sigmas, level_major=True)
+    return sigmas[:M]

@@ -11,7 +11,7 @@ import torch.nn as nn
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .ffmlp import FFMLP, nerf_density, nerf_head
-from .field import field_backward_plan, field_supported, nerf_field
+from .field import field_backward_plan, field_density, field_supported, nerf_field
 
 
 class NeRFNetwork(nn.Module):
@@ -77,6 +77,14 @@ class NeRFNetwork(nn.Module):
             return {"sigma": sigma, "geo_feat": h[..., 1:]}
         h = self.sigma_net(x)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    @torch.no_grad()
+    def density_sigma(self, x):
+        """MI355X-native: `density(x)["sigma"]` alone (what update_extra_state reads, nerf/renderer.py:594, 625) -- same bits,
+        without the feature transpose and without storing geo_feat"""
+        if self.fused_field and x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.half:
+            return field_density(x.view(-1, 3), self.encoder, self.sigma_net, self.bound)
+        return self.density(x)["sigma"]
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         """masked colour query of the `run` path (network_ff.py:98-139): rows outside `mask` stay zero"""

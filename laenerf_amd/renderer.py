@@ -147,7 +147,10 @@ class NeRFRenderer(nn.Module):
                         coords = torch.cat([coords, raymarching.morton3D_invert(occ.int())], dim=0)
                     xyzs, indices = raymarching.density_grid_positions(coords.shape[0], H, bound_c,
                                                                        noise=rand(coords.shape[0]), coords=coords)
-                sigmas = self.density(xyzs)["sigma"].reshape(-1).float()      # caller's autocast state, like the reference
+                if hasattr(self.model, "density_sigma"):                      # sigma alone: no feature transpose, no geo_feat store
+                    sigmas = self.model.density_sigma(xyzs).reshape(-1).float()
+                else:
+                    sigmas = self.density(xyzs)["sigma"].reshape(-1).float()  # caller's autocast state, like the reference
                 raymarching.density_grid_update(self.density_grid[cas], sigmas, indices, self._grid_tmp,
                                                 self.density_scale, decay)
         finally:

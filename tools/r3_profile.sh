@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_pmc_write -o benc
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d gpurun_out/${tag}_pmc_sq -o bench --output-format csv -- python3 bench.py --steps 40 --no-cpu-baseline --no-frame --no-style --no-graph > gpurun_out/${tag}_pmcsq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_flower -o flower -- python3 bench.py --workload flower > gpurun_out/${tag}_flower.json 2>gpurun_out/${tag}_flower.err
 find gpurun_out/${tag}_flower -name "*kernel_trace.csv" -delete
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_gridupd -o gu -- python3 tools/grid_update_bench.py > gpurun_out/${tag}_gridupd.log 2>&1
+find gpurun_out/${tag}_gridupd -name "*kernel_trace.csv" -delete
 # the per-dispatch counter tables are large: keep only what the summaries need (kernel name, counter, value)
 for d in pmc_fetch pmc_write pmc_sq; do
   for f in $(find gpurun_out/${tag}_${d} -name "*counter_collection.csv"); do
