@@ -189,6 +189,64 @@ __global__ __launch_bounds__(BLOCK) void k_fwd_lean(const float* __restrict__ xy
     out[(size_t)level * B + b] = h2;
 }
 
+// VAR 512 (round 3): the north star's "LDS-staged per-level features", measured instead of priced.  The tables
+// of the two coarsest levels (4920 + 13824 entries = 75 KB as half2) are copied into LDS by every workgroup (coalesced 16-byte
+// loads), then the workgroup walks its share of the samples and gathers the 2 x 8 corners with ds_read2_b32 (x and x + 1 are
+// adjacent on a dense level: one LDS instruction per corner row) -- same coordinate arithmetic, same accumulation order, so the
+// results are the same bits as the lean kernel's.  Persistent grid: `blocks` workgroups (1 or 2 per CU: 75 KB each).
+constexpr int LDS_LEVELS = 2;
+__global__ __launch_bounds__(BLOCK) void k_fwd_lds(const float* __restrict__ xyz, const half2_t* __restrict__ grid,
+                                                   const int32_t* __restrict__ offsets, half2_t* __restrict__ out, uint32_t B, Scales sc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    const uint32_t n_ent = (uint32_t)offsets[LDS_LEVELS];                       // levels 0 .. LDS_LEVELS-1 are contiguous from entry 0
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(grid);
+        u32x4* dst = reinterpret_cast<u32x4*>(tab);
+        for (uint32_t i = threadIdx.x; i < n_ent / 4; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    uint32_t s1[LDS_LEVELS], s2[LDS_LEVELS], off[LDS_LEVELS]; float scale[LDS_LEVELS];
+#pragma unroll
+    for (int l = 0; l < LDS_LEVELS; l++) {
+        scale[l] = sc.scale[l];
+        const uint32_t res = (uint32_t)ceilf(scale[l]) + 1;
+        s1[l] = res + 1; s2[l] = (res + 1) * (res + 1); off[l] = (uint32_t)offsets[l];
+    }
+    for (uint32_t b = blockIdx.x * BLOCK + threadIdx.x; b < B; b += gridDim.x * BLOCK) {
+        const F3 v3 = *reinterpret_cast<const F3*>(xyz + (size_t)b * 3);
+        const float xin[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+        for (int l = 0; l < LDS_LEVELS; l++) {
+            float fr[3]; uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float x01 = (xin[d] + 1.0f) * 0.5f;
+                const float p = fmaf(x01, scale[l], 0.5f);
+                const float fl = floorf(p);
+                pg[d] = (uint32_t)fl;
+                fr[d] = p - fl;
+            }
+            const uint32_t base = off[l] + pg[0] + pg[1] * s1[l] + pg[2] * s2[l];
+            uint32_t cw[8];
+#pragma unroll
+            for (int yz = 0; yz < 4; yz++) {
+                const uint32_t o0 = base + ((yz & 1) ? s1[l] : 0u) + ((yz >> 1) ? s2[l] : 0u);
+                cw[2 * yz] = tab[o0]; cw[2 * yz + 1] = tab[o0 + 1];          // adjacent dwords: the compiler emits ds_read2_b32
+            }
+            half_t r0 = (half_t)0.f, r1 = (half_t)0.f;
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                const float w = (((idx & 1) ? fr[0] : 1 - fr[0]) * ((idx & 2) ? fr[1] : 1 - fr[1])) * ((idx & 4) ? fr[2] : 1 - fr[2]);
+                const half2_t v = __builtin_bit_cast(half2_t, cw[idx]);
+                r0 = r0 + (half_t)(w * (float)v[0]);
+                r1 = r1 + (half_t)(w * (float)v[1]);
+            }
+            const half2_t h2 = {r0, r1};
+            out[(size_t)l * B + b] = h2;
+        }
+    }
+}
+
 static LevelMap map_levels(const std::vector<std::vector<int>>& per_xcd, uint32_t interleave = 0) {
     LevelMap m; memset(&m, 0, sizeof(m)); m.interleave = interleave;
     for (int x = 0; x < 8; x++) { m.n[x] = (uint8_t)per_xcd[x].size(); for (size_t i = 0; i < per_xcd[x].size(); i++) m.lv[x][i] = (uint8_t)per_xcd[x][i]; }
@@ -286,6 +344,43 @@ int main(int argc, char** argv) {
     full(256, m_prod, 1, "prod map, LEAN kernel");
     { std::vector<std::vector<int>> v(8); for (int x = 0; x < 8; x++) v[x] = {x + 8, x}; full(0, map_levels(v), 1, "(l+8, l) fine first");
       full(256, map_levels(v), 1, "(l+8, l) fine first, LEAN"); }
+    {   // ---- LDS staging of levels 0 + 1 (VAR 512) against the lean kernel on the same two levels
+        // lean kernel, levels 0 and 1 on EVERY XCD (8x the work of the two levels): time / 8 = their cost spread over the chip,
+        // which is how the production schedule deals them (eighths of the dense levels fill the XCDs' gaps)
+        std::vector<std::vector<int>> v(8); for (int x = 0; x < 8; x++) v[x] = {0, 1};
+        const float t8 = run(256, map_levels(v), 1, d_out, "LEAN, levels 0+1 on every XCD (8x work)", 16);
+        printf("    -> levels 0+1 spread over the chip: %.2f us\n", t8 / 8);
+        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+        const size_t lds_bytes = (size_t)offs[LDS_LEVELS] * 4;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        for (int per_cu : {1, 2}) {
+            const uint32_t blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+            CK(hipMemset(d_out, 0, (size_t)L * B * 4));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                for (int i = 0; i < 5; i++) k_fwd_lds<<<blocks, BLOCK, lds_bytes>>>(d_xyz, d_tab, d_off, d_out, B, sc);
+                CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+                for (int i = 0; i < 40; i++) k_fwd_lds<<<blocks, BLOCK, lds_bytes>>>(d_xyz, d_tab, d_off, d_out, B, sc);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms * 25.f < best ? ms * 25.f : best;
+            }
+            CK(hipGetLastError());
+            CK(hipMemcpy(hout.data(), d_out, (size_t)L * B * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t i = 0; i < (size_t)LDS_LEVELS * B; i++) bad += hout[i] != href[i];
+            printf("LDS-staged levels 0+1 (%zu KB per workgroup), %u workgroups (%d per CU): %7.1f us  %s\n", lds_bytes / 1024, blocks, per_cu, best,
+                   bad ? "MISMATCH" : "same bits as the reference kernel");
+        }
+        // the same kernel without any sample (staging only): what the 75 KB copy per workgroup costs
+        for (int per_cu : {1, 2}) {
+            const uint32_t blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+            for (int i = 0; i < 5; i++) k_fwd_lds<<<blocks, BLOCK, lds_bytes>>>(d_xyz, d_tab, d_off, d_out, 0, sc);
+            CK(hipDeviceSynchronize()); CK(hipEventRecord(e0));
+            for (int i = 0; i < 40; i++) k_fwd_lds<<<blocks, BLOCK, lds_bytes>>>(d_xyz, d_tab, d_off, d_out, 0, sc);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("    staging alone (no samples), %d per CU: %7.1f us\n", per_cu, ms * 25.f);
+        }
+    }
     for (int var : {0, 256}) {
         for (int l : {0, 3, 5, 8, 11, 15}) {
             std::vector<std::vector<int>> v(8); v[l & 7] = {l};
