@@ -492,6 +492,7 @@ constexpr uint32_t KEY_SINGLE = 15u;                           // key code: 0..1
 constexpr int ACC_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
+constexpr bool WIDE_COARSE_UNITS = false;                      // true: 16 samples per lane on those levels (round 3 experiment: accumulate 62.4 -> 58.4 us, but fill 58.3 -> 80.1 and count 27.5 -> 38.0 -- the wide blocks walk four dependent load groups and form the pass's tail; step 0.356 -> 0.433 ms)
 constexpr uint32_t SUB_RECS = 16;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
 constexpr uint32_t TICKET_WORDS = TICKET_ARRIVALS + MAX_LEVELS * SUB_RECS;
@@ -551,7 +552,22 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     if (!FILL && touched) { for (uint32_t k = tid; k < line_words; k += FILL_THREADS) s_lines[k] = 0u; }
     // a lane walks SPT * SEGS consecutive samples; every segment of SPT samples per lane is a UNIT with its own counter
     // row / queue runs (the staging area holds one unit), the cell a lane is in is carried from segment to segment
-    const uint32_t b0 = (chunk * FILL_THREADS + tid) * (SPT * SEGS);
+    // Round 3: on the levels coarser than COARSE_RES a lane walks 16 consecutive samples (four groups of SPT), not four: a cell
+    // of such a level holds ~10-40 consecutive samples of a ray, so the per-lane merge of same-cell samples yields up to four
+    // times fewer items -- and those items' same-address LDS atomics are the chain that sets the accumulate pass's duration
+    // (DESIGN.md 4d).  A unit of a coarse level is then 4096 samples; it lives in the unit slot of its first 1024 (slots
+    // u % 4 != 0 stay empty: zero counters, nothing filled), so the plan's layout does not change.
+    const bool wide = li.resolution < COARSE_RES && WIDE_COARSE_UNITS;
+    const uint32_t NSUB = wide ? 4u : 1u;
+    if (wide && (chunk & 3u)) {
+        if constexpr (!FILL) {                                   // an empty unit slot: its counters must still read zero
+            const uint32_t u_e = chunk * SEGS, unit_e = level * U + u_e;
+            for (uint32_t k = tid; k < BK_MAX / 2; k += FILL_THREADS) reinterpret_cast<uint32_t*>(plan.cnt + (size_t)unit_e * BK_MAX)[k] = 0u;
+            for (uint32_t k = tid; k < P; k += FILL_THREADS) plan.part_cnt[((size_t)level * BK_MAX + k) * U + u_e] = 0u;
+        }
+        return;
+    }
+    const uint32_t b0 = wide ? ((chunk >> 2) * (UNIT_SAMPLES * 4u) + tid * (SPT * 4u)) : (chunk * FILL_THREADS + tid) * (SPT * SEGS);
     // few partitions: all lanes of a wave count into the same one or two counters, and same-address LDS atomics of one
     // instruction serialise -> NC copies per partition, lane l uses copy l mod NC (sub-runs inside the partition's run).
     // Coarse levels keep arrival order instead: the accumulate pass merges neighbouring repeats.
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
         // returns zeros past the end of the batch (no ragged-tail path for the compiler to blend into the wide one)
         static_assert(SPT == 4, "the wide reads below take 4 samples per lane");
         float xs[SPT][3], g0[SPT], g1[SPT];
-        {
+        auto load_group = [&](uint32_t bs) {
             using u4 = __attribute__((__vector_size__(16))) uint32_t;
             // (the range check is all-or-nothing per 16-byte load: the records end with the last whole group of 4 samples,
             // the one lane that holds the batch's last 1-3 samples reads them with plain loads below)
@@ -672,13 +688,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 else if constexpr (FILL) { g0[s_] = __builtin_bit_cast(float, gw[2 * s_]); g1[s_] = __builtin_bit_cast(float, gw[2 * s_ + 1]); }
                 else { g0[s_] = 0.f; g1[s_] = 0.f; }
             }
-        }
+        };
+        load_group(bs);
         if constexpr (FILL) {
             hist[2 * tid] = w_cnt & 0xffffu; hist[2 * tid + 1] = w_cnt >> 16;
 #pragma unroll
             for (int i = 0; i < 2; i++) { const uint32_t k = tid + i * FILL_THREADS; if (k < P) gbase[k] = gb_off[i] + gb_cnt[i]; }
         }
         uint32_t pgs[SPT][3]; float frs[SPT][3]; bool oks[SPT];
+        auto place_group = [&](uint32_t bs) {
 #pragma unroll
         for (int s_ = 0; s_ < SPT; s_++) {
             bool ok = bs + s_ < B;
@@ -695,6 +713,8 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
             }
             oks[s_] = ok;
         }
+        };
+        place_group(bs);
         __syncthreads();
         if constexpr (!FILL) {
             // ---- how many items does each (partition, copy) counter get from this unit
@@ -718,12 +738,15 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                     for (int yz = 0; yz < 4; yz++) if (!r.pair[yz]) atomicAdd(&hist[r.c1[yz]], 1u);
                 }
             };
+            for (uint32_t sub = 0; sub < NSUB; sub++) {
+                if (sub) { load_group(bs + sub * SPT); place_group(bs + sub * SPT); }
 #pragma unroll
-            for (int s_ = 0; s_ < SPT; s_++) {
-                if (!oks[s_]) continue;
-                if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
-                    if (have) count_cell();
-                    cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
+                for (int s_ = 0; s_ < SPT; s_++) {
+                    if (!oks[s_]) continue;
+                    if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
+                        if (have) count_cell();
+                        cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
+                    }
                 }
             }
             if (last && have) count_cell();
@@ -805,17 +828,20 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
 #pragma unroll
                 for (int c = 0; c < 8; c++) { a0[c] = 0.f; a1[c] = 0.f; }
             };
+            for (uint32_t sub = 0; sub < NSUB; sub++) {
+                if (sub) { load_group(bs + sub * SPT); place_group(bs + sub * SPT); }
 #pragma unroll
-            for (int s_ = 0; s_ < SPT; s_++) {
-                if (!oks[s_]) continue;
-                if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
-                    if (have) emit_cell();
-                    cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
-                }
+                for (int s_ = 0; s_ < SPT; s_++) {
+                    if (!oks[s_]) continue;
+                    if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
+                        if (have) emit_cell();
+                        cpg[0] = pgs[s_][0]; cpg[1] = pgs[s_][1]; cpg[2] = pgs[s_][2]; have = true;
+                    }
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const float w = (((c & 1) ? frs[s_][0] : 1 - frs[s_][0]) * ((c & 2) ? frs[s_][1] : 1 - frs[s_][1])) * ((c & 4) ? frs[s_][2] : 1 - frs[s_][2]);
-                    a0[c] = fmaf(w, g0[s_], a0[c]); a1[c] = fmaf(w, g1[s_], a1[c]);
+                    for (int c = 0; c < 8; c++) {
+                        const float w = (((c & 1) ? frs[s_][0] : 1 - frs[s_][0]) * ((c & 2) ? frs[s_][1] : 1 - frs[s_][1])) * ((c & 4) ? frs[s_][2] : 1 - frs[s_][2]);
+                        a0[c] = fmaf(w, g0[s_], a0[c]); a1[c] = fmaf(w, g1[s_], a1[c]);
+                    }
                 }
             }
             if (last && have) emit_cell();
