@@ -37,13 +37,14 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("LAE_BUILD_EXTRA_FLAGS", "").split()      # probes only (e.g. -DLAE_GRID_STAMPS, tools/grid_bwd_stamps.py)
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -35,6 +35,17 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 __constant__ uint32_t k_primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 
+// in-kernel phase stamps of the binned backward for tools/grid_bwd_stamps.py (compiled in only with -DLAE_GRID_STAMPS: the
+// 100 MHz wall clock as thread 0 of a block passes each phase; slot = block, 32 stamps each)
+#ifdef LAE_GRID_STAMPS
+__device__ unsigned long long g_grid_stamps[8192 * 32];
+#define GRID_STAMP(slot, i) do { if (threadIdx.x == 0 && (uint32_t)(i) < 32u) g_grid_stamps[(size_t)(slot) * 32 + (i)] = wall_clock64(); } while (0)
+#define GRID_NOTE(slot, i, v) do { if (threadIdx.x == 0 && (uint32_t)(i) < 32u) g_grid_stamps[(size_t)(slot) * 32 + (i)] = (v); } while (0)
+#else
+#define GRID_STAMP(slot, i) do { } while (0)
+#define GRID_NOTE(slot, i, v) do { } while (0)
+#endif
+
 // block-uniform description of one level (all derived from scalars -> SGPRs)
 template <int D>
 struct LevelInfo {
@@ -523,6 +534,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
     const uint32_t gridtype = PLAIN ? 0u : gridtype_, interp = PLAIN ? 0u : interp_;
     const bool align_corners = PLAIN ? false : align_corners_;
     using V = typename BVal<T>::type;
+    if constexpr (FILL) GRID_STAMP(blockIdx.x, 0);
     const uint32_t NBLK = U / SEGS;                           // U is a multiple of SEGS
     const uint32_t level = blockIdx.x / NBLK, chunk = blockIdx.x % NBLK;
     if (FILL && blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < TICKET_WORDS; k += FILL_THREADS) plan.tickets[k] = 0;   // work queue / arrival counters of the accumulate pass
@@ -715,7 +727,9 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
         }
         };
         place_group(bs);
+        if constexpr (FILL) GRID_STAMP(blockIdx.x, 1);
         __syncthreads();
+        if constexpr (FILL) GRID_STAMP(blockIdx.x, 2);
         if constexpr (!FILL) {
             // ---- how many items does each (partition, copy) counter get from this unit
             auto count_cell = [&]() {
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 if (tid == 63) start[BK_MAX] = run;
             }
             __syncthreads();
+            GRID_STAMP(blockIdx.x, 3);
             const uint32_t total = start[BK_MAX];
             const bool staged = total <= STAGE_CAP;
             // ---- sums + emission, sorted by partition (slot = sub-run start + arrival order inside it)
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                 if (sub) { load_group(bs + sub * SPT); place_group(bs + sub * SPT); }
 #pragma unroll
                 for (int s_ = 0; s_ < SPT; s_++) {
+                    GRID_STAMP(blockIdx.x, 8 + s_);
                     if (!oks[s_]) continue;
                     if (!have || pgs[s_][0] != cpg[0] || pgs[s_][1] != cpg[1] || pgs[s_][2] != cpg[2]) {
                         if (have) emit_cell();
@@ -844,8 +860,11 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                     }
                 }
             }
+            GRID_STAMP(blockIdx.x, 12);
             if (last && have) emit_cell();
+            GRID_STAMP(blockIdx.x, 4);
             __syncthreads();
+            GRID_STAMP(blockIdx.x, 5);
             if (staged) {
                 // ---- the staged runs leave for the queue, one partition at a time per wave: consecutive lanes, consecutive slots
                 // a wave owns a contiguous range of partitions; the (start, end, queue base) triples of up to 64 of them are
@@ -868,6 +887,8 @@ __global__ __launch_bounds__(FILL_THREADS) void k_bwd_walk(
                     }
                 }
             }
+            GRID_STAMP(blockIdx.x, 6);
+            GRID_NOTE(blockIdx.x, 7, total);
             __syncthreads();                                   // staging / counters are reused by the next segment
         }
     }
@@ -1011,12 +1032,16 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     // the first task of every workgroup is its own index (gridDim.x same-address atomics at launch would queue up behind one
     // another); later tasks are drawn from the ticket counter, which therefore counts from gridDim.x
     bool first_task = true;
+    [[maybe_unused]] uint32_t stamp_task = 0;
+    GRID_STAMP(4096 + blockIdx.x, 0);
     for (;;) {
         if (tid == 0) s_ticket = first_task ? blockIdx.x : atomicAdd(&plan.tickets[0], 1u) + gridDim.x;
         first_task = false;
         __syncthreads();
         const uint32_t t = __builtin_amdgcn_readfirstlane(s_ticket);       // scalar: everything derived from it is wave-uniform
+        GRID_STAMP(4096 + blockIdx.x, 1 + stamp_task * 6);                   // ticket in hand
         if (t >= total_buckets) break;
+        GRID_NOTE(4096 + blockIdx.x, 2 + stamp_task * 6, t);
         const uint32_t item = t;                                // coarse levels first: their sub-ranges + merge are the longest chains
         uint32_t level = 0;
         while (level + 1 < L && item >= s_first[level + 1]) level++;
@@ -1040,6 +1065,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
         for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = 0ull;
         if (tid < PART / 32) poison[tid] = 0u;
         __syncthreads();
+        GRID_STAMP(4096 + blockIdx.x, 3 + stamp_task * 6);                   // zeroed
         const uint32_t scale_res = (uint32_t)ceilf(sc.scale[level]) + 1;
         const V* __restrict__ pv = qvals + q0;
         const uint16_t* __restrict__ pk = qkeys + q0;
@@ -1135,7 +1161,9 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 }
             }
         }
+        GRID_STAMP(4096 + blockIdx.x, 4 + stamp_task * 6);                   // thread 0 out of the items
         __syncthreads();
+        GRID_STAMP(4096 + blockIdx.x, 5 + stamp_task * 6);                   // every wave out of the items
         if (SUB > 1) {
             // ---- sub-ranges of one partition: every one ADDS its exact partial sums (int64: the adds commute, so the
             // result has the same bits whatever the order) into the partition's merge record with device-scope atomics;
@@ -1158,7 +1186,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
             __syncthreads();
             if (tid == 0) s_arr = atomicAdd(&plan.tickets[TICKET_ARRIVALS + level * SUB_RECS + p], 1u);
             __syncthreads();
-            if (s_arr != SUB - 1) { __syncthreads(); continue; }
+            if (s_arr != SUB - 1) { GRID_STAMP(4096 + blockIdx.x, 6 + stamp_task * 6); stamp_task++; __syncthreads(); continue; }
             for (uint32_t i = tid; i < ACCW; i += ACC_THREADS) acc64[i] = atomicExch(rec + i, 0ull);
             if (tid < PART / 32) poison[tid] = atomicExch(rec_poison + tid, 0u);
             __syncthreads();
@@ -1198,6 +1226,8 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
                 if (nf_flag && !(isfinite(o.x) && isfinite(o.y))) atomicOr(nf_flag, 1);
             }
         }
+        GRID_STAMP(4096 + blockIdx.x, 6 + stamp_task * 6);                   // flushed
+        stamp_task++;
         __syncthreads();
     }
 }
@@ -1873,3 +1903,10 @@ int lae_grad_total_variation(const void* inputs, const void* embeddings, void* g
 }
 
 }  // extern "C"
+
+#ifdef LAE_GRID_STAMPS
+extern "C" __attribute__((visibility("default"))) int lae_debug_grid_stamps(void* out, size_t bytes) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grid_stamps), bytes) == hipSuccess ? 0 : 1;
+}
+#endif
