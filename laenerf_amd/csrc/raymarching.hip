@@ -212,6 +212,36 @@ __device__ __forceinline__ Probe probe_at(const Ray& r, const MarchCfg& c, const
     return p;
 }
 
+// the geometry of a visit without its occupancy probe: bit index of the cell, the step there, and where the walker lands if the
+// cell turns out EMPTY (probe_at's arithmetic, statement for statement).  None of it depends on the bitfield, so a lane can lay
+// out the next few visits of a walk through empty space and have all their probes in flight at once (k_frame_lookahead).
+struct VisitGeom { uint32_t index; float dt, tt_empty; };
+__device__ __forceinline__ VisitGeom visit_geom(const Ray& r, const MarchCfg& c, float t) {
+    VisitGeom v;
+    const float x = clampf(fmaf(t, r.dx, r.ox), -c.bound, c.bound);
+    const float y = clampf(fmaf(t, r.dy, r.oy), -c.bound, c.bound);
+    const float z = clampf(fmaf(t, r.dz, r.oz), -c.bound, c.bound);
+    v.dt = clampf(t * c.dt_gamma, c.dt_min, c.dt_max);
+    const float amax = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    const int lp = cascade_of(amax, c.Cf);
+    const int ld = cascade_of(v.dt * c.Hf * 0.5f, c.Cf);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+    const int nx = (int)clampf((0.5f * fmaf(x, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    const int ny = (int)clampf((0.5f * fmaf(y, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    const int nz = (int)clampf((0.5f * fmaf(z, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
+    v.index = (uint32_t)level * c.H3 + morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+    const float ax = (float)nx + 0.5f + 0.5f * copysignf(1.0f, r.dx);
+    const float ay = (float)ny + 0.5f + 0.5f * copysignf(1.0f, r.dy);
+    const float az = (float)nz + 0.5f + 0.5f * copysignf(1.0f, r.dz);
+    const float tx = fmaf((ax * c.rH) * 2 - 1, mip_bound, -x) * r.rdx;
+    const float ty = fmaf((ay * c.rH) * 2 - 1, mip_bound, -y) * r.rdy;
+    const float tz = fmaf((az * c.rH) * 2 - 1, mip_bound, -z) * r.rdz;
+    v.tt_empty = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    return v;
+}
+
 __device__ __forceinline__ float skip_to(const MarchCfg& c, float t, float tt) {   // :396-398
     do { t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
     return t;
@@ -974,9 +1004,9 @@ constexpr uint32_t FRAME_LA = 8;               // recorded samples per ray (>= m
 __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const float* __restrict__ nears,
                              float* __restrict__ rays_t, float* __restrict__ tc, float* __restrict__ weights_sum,
                              float* __restrict__ depth, float* __restrict__ image, float* __restrict__ weights_edit,
-                             float* __restrict__ depth_edit) {
+                             float* __restrict__ depth_edit, uint32_t* __restrict__ q_counts) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0) ctrl[0] = FrameCtrl{};                    // state "before iteration 0": step = 0, nothing issued
+    if (n == 0) { ctrl[0] = FrameCtrl{}; q_counts[0] = 0u; q_counts[1] = 0u; }   // state "before iteration 0": step = 0, nothing issued, no straggler queued
     if (n >= N) return;
     rays_t[n] = nears[n];
     tc[n] = nears[n];
@@ -1068,7 +1098,20 @@ __device__ __forceinline__ float perturbed_start(const MarchCfg& cfg, float t, c
 // iteration p -- first advance tc[ray] (this loop's copy of rays_t) over the n_step samples that iteration consumes, with
 // the compositing kernel's arithmetic (t += deltas[1]), then walk on from there (march_rays restarts from rays_t,
 // raymarching.cu:736).  Records la_t[ray][0..cnt) = sample times, la_e = edit flags, la_cnt[ray] = cnt <= max_n_step.
+// in-kernel stamps of the lookahead for tools/frame_look_stamps.py (compiled in only with -DLAE_FRAME_STAMPS): per wave of ONE
+// launch (phase == g_look_phase): wall clock at start / state loaded / lane rounds done / end, lane rounds, coop rays, coop passes
+#ifdef LAE_FRAME_STAMPS
+__device__ unsigned long long g_look_stamps[16384 * 8];
+__device__ int g_look_phase = 20;
+#define LOOK_NOTE(i, v) do { if (phase == g_look_phase && lane == 0) { const uint32_t w_ = blockIdx.x * (FRAME_BLOCK / 64) + (threadIdx.x >> 6); if (w_ < 16384u) g_look_stamps[(size_t)w_ * 8 + (i)] = (v); } } while (0)
+#else
+#define LOOK_NOTE(i, v) do { } while (0)
+#endif
 constexpr uint32_t FRAME_LANE_VISITS = 8;      // visits a lane walks alone before the wave decides how to continue
+constexpr int FRAME_QUEUE_MAX = 16;            // the bound when the stragglers go to the finishing kernel (8 / 16 / 24 / 32 / 48: 12.07 / 11.86 / 11.88 / 11.98 / 12.14 ms per frame)
+constexpr int FRAME_SPEC = 4;                  // visits of a walk through empty space laid out (and probed) together
+struct LookTask { uint32_t index, step; float t; };   // a ray the lane phase hands to k_frame_lookahead_finish
+constexpr uint32_t FRAME_FINISH_BLOCKS = 1024; // x 4 waves: more than one wave per SIMD, tasks dealt round-robin
 constexpr int FRAME_COOP_MAX = 8;              // unfinished lanes per wave up to which they are finished cooperatively
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
@@ -1076,17 +1119,21 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     float* __restrict__ tc, float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt,
     float* __restrict__ la_tend,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
-    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises) {
+    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
+    uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max) {
     const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
     const uint32_t n = blockIdx.x * FRAME_BLOCK + threadIdx.x;
     bool has_ray = n < n_alive;
     const int lane = threadIdx.x & 63;
+    LOOK_NOTE(0, wall_clock64());
+    [[maybe_unused]] uint32_t st_rounds = 0, st_coop = 0, st_passes = 0;
     uint32_t index = 0;
     Ray r{};
     float t = 0.f, far = 0.f;
+    uint32_t cnt0 = 0;
     if (has_ray) {
         index = phase < 0 ? n : (uint32_t)alive[n];
-        if (phase >= 0 && la_cnt[index] < n_consumed) has_ray = false;          // the ray ends in this iteration
+        if (phase >= 0) { cnt0 = la_cnt[index]; if (cnt0 < n_consumed) has_ray = false; }   // the ray ends in this iteration
     }
     if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
     float* out_t = la_t + (size_t)index * FRAME_LA;
@@ -1098,45 +1145,129 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         t = tc[index];
         if (phase < 0) t = perturbed_start(cfg, t, noises, n);
         else {
+            // the ray's record travels as two 16-byte loads (and, if part of it is kept, two stores): a load per consumed
+            // sample and a load + store per kept one, each waited for in turn inside its loop, were a dozen dependent round
+            // trips through a memory system the encoder kernel next door keeps saturated -- the kernel's 110-150 us
+            static_assert(FRAME_LA == 8, "the record is handled as 2 x float4 / one 64-bit word");
+            const float4 ra = reinterpret_cast<const float4*>(out_t)[0], rb = reinterpret_cast<const float4*>(out_t)[1];
+            float rec[FRAME_LA] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            unsigned long long rece = 0ull;
+            if (EDIT) rece = *reinterpret_cast<const unsigned long long*>(out_e);
+            const float tend0 = la_tend[index];
             float last = phase == 0 ? perturbed_start(cfg, t, noises, n) : t;   // iteration 0 lists rays in identity order
-            for (uint32_t j = 0; j < n_consumed; j++) {
-                const float tj = out_t[j];
-                const float tn = tj + step_of(cfg, tj);
-                t += tn - last;                            // composite: t += deltas[1], deltas[1] = t_next - last_t
-                last = tn;
+#pragma unroll
+            for (uint32_t j = 0; j < FRAME_LA; j++) {
+                if (j < n_consumed) {                      // n_consumed is uniform over the launch
+                    const float tj = rec[j];
+                    const float tn = tj + step_of(cfg, tj);
+                    t += tn - last;                        // composite: t += deltas[1], deltas[1] = t_next - last_t
+                    last = tn;
+                }
             }
             tc[index] = t;
             // The samples recorded beyond the consumed ones are exactly what a walk restarted at t would find, provided the
             // compositing kernel's running t equals the walker's own t after the last consumed sample (it does unless the
             // float subtraction / addition pair above rounded: then everything is walked again from t, like the reference).
             if (n_consumed > 0 && t == last) {
-                const uint32_t keep = la_cnt[index] - n_consumed;
-                for (uint32_t j = 0; j < keep; j++) {
-                    out_t[j] = out_t[j + n_consumed];
-                    if (EDIT) out_e[j] = out_e[j + n_consumed];
+                const uint32_t keep = cnt0 - n_consumed;
+                if (keep) {                                // shift by the uniform n_consumed: three conditional register moves
+                    if (n_consumed & 1u) {
+#pragma unroll
+                        for (int j = 0; j < 7; j++) rec[j] = rec[j + 1];
+                    }
+                    if (n_consumed & 2u) {
+#pragma unroll
+                        for (int j = 0; j < 6; j++) rec[j] = rec[j + 2];
+                    }
+                    if (n_consumed & 4u) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) rec[j] = rec[j + 4];
+                    }
+                    reinterpret_cast<float4*>(out_t)[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+                    reinterpret_cast<float4*>(out_t)[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+                    if (EDIT) *reinterpret_cast<unsigned long long*>(out_e) = rece >> (8u * n_consumed);
                 }
                 step = keep;
-                t = la_tend[index];
+                t = tend0;
             }
         }
     }
+    LOOK_NOTE(1, wall_clock64());
     for (;;) {
+        st_rounds++;
         uint32_t visits = 0;                               // lane phase: the reference's walk
+        // A lane crossing empty space pays one DEPENDENT bitfield probe per visit, and a wave with more than FRAME_COOP_MAX
+        // such lanes keeps walking (8-13 rounds of 8 visits: the slowest waves once the few-straggler case went to the
+        // finishing kernel).  The visits of an empty stretch do not depend on what the probes return as long as they
+        // return "empty": after a first ordinary visit that found nothing, a lane lays out the next FRAME_SPEC visits
+        // under that assumption, requests their probes together and takes them in order; the first occupied one is the
+        // sample, what was laid out behind it is dropped.  Same visits, same arithmetic (visit_geom).
+        bool plain = true;
         while (has_ray && t < far && step < max_n_step && visits < FRAME_LANE_VISITS) {
-            const Probe p = probe_at(r, cfg, grid, t);
-            if (p.occ) {
-                out_t[step] = t;
-                if (EDIT) out_e[step] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
-                t += p.dt;
-                step++;
-            } else t = skip_to(cfg, t, p.tt);
-            visits++;
+            if (plain || !spec) {
+                const Probe p = probe_at(r, cfg, grid, t);
+                if (p.occ) {
+                    out_t[step] = t;
+                    if (EDIT) out_e[step] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
+                    t += p.dt;
+                    step++;
+                } else t = skip_to(cfg, t, p.tt);
+                visits++;
+                plain = p.occ;                             // inside the surface: keep walking visit by visit
+                continue;
+            }
+            float ts[FRAME_SPEC], dts[FRAME_SPEC];
+            uint32_t idx[FRAME_SPEC];
+            uint8_t byte[FRAME_SPEC];
+            float tn = t;
+            int nv = 0;
+#pragma unroll
+            for (int j = 0; j < FRAME_SPEC; j++) {
+                if (tn < far) {
+                    const VisitGeom v = visit_geom(r, cfg, tn);
+                    ts[j] = tn; dts[j] = v.dt; idx[j] = v.index;
+                    byte[j] = grid[v.index >> 3];
+                    tn = skip_to(cfg, tn, v.tt_empty);
+                    nv = j + 1;
+                } else { ts[j] = tn; dts[j] = 0.f; idx[j] = 0; byte[j] = 0; }
+            }
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < FRAME_SPEC; j++) {
+                if (!hit && j < nv && ((byte[j] >> (idx[j] & 7u)) & 1u)) {
+                    out_t[step] = ts[j];
+                    if (EDIT) out_e[step] = (edit_grid[idx[j] >> 3] >> (idx[j] & 7u)) & 1u;
+                    t = ts[j] + dts[j];
+                    step++;
+                    hit = true;
+                    plain = true;
+                }
+            }
+            if (!hit) t = tn;
+            visits += (uint32_t)nv;
         }
         const bool unfinished = has_ray && t < far && step < max_n_step;
         unsigned long long um = __ballot(unfinished);
         if (um == 0ull) break;
-        if (__builtin_popcountll(um) > FRAME_COOP_MAX) continue;   // most of the wave is in transit: lanes are well used
+        if (__builtin_popcountll(um) > coop_max) continue;   // most of the wave is in transit: lanes are well used
+        LOOK_NOTE(2, wall_clock64());
+        if (q_tasks) {
+            // few stragglers: hand them to k_frame_lookahead_finish (one wave per ray, every SIMD of the chip) instead of
+            // finishing them here one after another: a ray leaving the surface for `far` is ~15 candidate passes of ~1 us,
+            // up to 8 such rays in one wave were the kernel's 110-150 us while 80 % of its waves had left after 10
+            uint32_t base = 0;
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(um);
+            if (lane == 0) base = atomicAdd(q_count, cnt);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (unfinished) {
+                const uint32_t slot = base + (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull));
+                q_tasks[slot] = LookTask{index, step, t};
+                has_ray = false;                           // its count / end time are the finishing kernel's to write
+            }
+            break;
+        }
         while (um) {                                       // few stragglers: finish each with the whole wave
+            st_coop++;
             const int L = __builtin_ctzll(um);
             um &= um - 1ull;
             Ray rl;
@@ -1154,6 +1285,33 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         break;
     }
     if (has_ray) { la_cnt[index] = step; la_tend[index] = t; }
+    LOOK_NOTE(3, wall_clock64());
+    LOOK_NOTE(4, (unsigned long long)st_rounds | ((unsigned long long)st_coop << 16) | ((unsigned long long)__builtin_popcountll(__ballot(has_ray)) << 32));
+}
+
+// the stragglers of one k_frame_lookahead launch, one wave per ray (frame_lookahead_coop); workgroup 0 also clears the OTHER
+// task counter for the next iteration's lane phase
+template <bool EDIT>
+__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
+    uint32_t max_n_step, const uint32_t* __restrict__ q_count, uint32_t* __restrict__ q_count_next, const LookTask* __restrict__ q_tasks,
+    float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt, float* __restrict__ la_tend,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
+    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *q_count_next = 0u;
+    const uint32_t n_tasks = *q_count;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (uint32_t i = wave; i < n_tasks; i += gridDim.x * (FRAME_BLOCK / 64)) {
+        const LookTask tk = q_tasks[i];
+        const uint32_t index = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.index), step = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.step);
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tk.t)));
+        const Ray r = load_ray(rays_o, rays_d, index);
+        float t_end;
+        const uint32_t got = frame_lookahead_coop<EDIT>(r, cfg, grid, edit_grid, t, fars[index], max_n_step - step,
+                                                        la_t + (size_t)index * FRAME_LA + step,
+                                                        EDIT ? la_e + (size_t)index * FRAME_LA + step : nullptr, lane, t_end);
+        if (lane == 0) { la_cnt[index] = step + got; la_tend[index] = t_end; }
+    }
 }
 
 // march_rays (raymarching.cu:700-805 / :811-926) as a replay of the recorded sample times; see the section comment
@@ -1216,9 +1374,16 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     const uint32_t have = min(la_cnt[index], n_step);
     float last_t = tc[index];
     if (nb_prev == 0) last_t = perturbed_start(cfg, last_t, noises, n);
-    const float* st = la_t + (size_t)index * FRAME_LA;
+    // the record as two 16-byte loads (+ one 8-byte load of the edit flags), not a dependent load per sample
+    const float4 ra = reinterpret_cast<const float4*>(la_t + (size_t)index * FRAME_LA)[0];
+    const float4 rb = reinterpret_cast<const float4*>(la_t + (size_t)index * FRAME_LA)[1];
+    const float st[FRAME_LA] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    unsigned long long ste = 0ull;
+    if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(la_e + (size_t)index * FRAME_LA);
     size_t row = (size_t)n * n_step;
-    for (uint32_t j = 0; j < n_step; j++, row++) {
+#pragma unroll
+    for (uint32_t j = 0; j < FRAME_LA; j++, row++) {
+        if (j >= n_step) break;                            // uniform
         if (j < have) {                                    // :761-790 with the recorded time
             const float t = st[j], dt = step_of(cfg, t), tn = t + dt;
             xyzs[3 * row] = clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound);
@@ -1226,7 +1391,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
             xyzs[3 * row + 2] = clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound);
             dirs[3 * row] = r.dx; dirs[3 * row + 1] = r.dy; dirs[3 * row + 2] = r.dz;
             deltas[2 * row] = dt; deltas[2 * row + 1] = tn - last_t; last_t = tn;
-            if (EDIT) edit_occ[row] = la_e[(size_t)index * FRAME_LA + j];
+            if (EDIT) edit_occ[row] = (uint8_t)(ste >> (8u * j));
         } else {                                           // the reference's buffers are torch.zeros
             xyzs[3 * row] = 0.f; xyzs[3 * row + 1] = 0.f; xyzs[3 * row + 2] = 0.f;
             dirs[3 * row] = 0.f; dirs[3 * row + 1] = 0.f; dirs[3 * row + 2] = 0.f;
@@ -1583,7 +1748,8 @@ uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_b
            2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + 4 * al256(4ull * N) /*rays_t, tc, nears, fars*/ +
            al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 2 * al256(4ull * N) /*lookahead times, edit flags, counts, end t*/ +
            2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
-           al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ + al256(4 * cap) /*sigmas*/ + al256(12 * cap) /*rgbs*/;
+           al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ + al256(4 * cap) /*sigmas*/ + al256(12 * cap) /*rgbs*/ +
+           256 /*straggler task counters x2*/ + al256(12ull * N) /*straggler tasks*/;
 }
 
 namespace {
@@ -1607,9 +1773,18 @@ struct FrameHost {                                        // process-wide helper
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess) return false;
+        // The events only order this device's two streams (the host learns the loop state from the mirror, which the emit kernel
+        // publishes with its own system-scope fence): no system-scope fence at the record -- 13.75 -> 13.30 ms per 800x800
+        // frame.  LAE_FRAME_EVENT_FLAGS=0 restores the default flags, 2 = device-scope release (13.7 ms) for A/B.
+        unsigned ev_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+        if (const char* e = getenv("LAE_FRAME_EVENT_FLAGS")) {
+            const int m = atoi(e);
+            if (m == 0) ev_flags = hipEventDisableTiming;
+            if (m == 2) ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
+        }
         for (int i = 0; i < NEV; i++) {
-            if (hipEventCreateWithFlags(&ev_emit[i], hipEventDisableTiming) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&ev_look[i], hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev_emit[i], ev_flags) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&ev_look[i], ev_flags) != hipSuccess) return false;
         }
         ok = true;
         return true;
@@ -1681,21 +1856,39 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     void* feats = take((uint64_t)L * cap * 4);
     float* sigmas = reinterpret_cast<float*>(take(4 * cap));
     float* rgbs = reinterpret_cast<float*>(take(12 * cap));
+    uint32_t* q_counts = reinterpret_cast<uint32_t*>(take(256));            // [2], used alternately by consecutive lookaheads
+    LookTask* q_tasks = reinterpret_cast<LookTask*>(take(12ull * N));
+    static_assert(sizeof(LookTask) == 12, "LookTask layout");
+    static const bool finish_queue = [] { const char* e = getenv("LAE_FRAME_FINISH_QUEUE"); return !e || atoi(e) != 0; }();   // 0: stragglers finished inside the lane kernel (A/B)
+    static const int spec_visits = [] { const char* e = getenv("LAE_FRAME_SPEC"); return e ? atoi(e) : 1; }();   // 0: every visit waits for its own probe (A/B)
+    static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
+    const int coop_max = coop_max_env >= 0 ? coop_max_env : (finish_queue ? FRAME_QUEUE_MAX : FRAME_COOP_MAX);
+    uint32_t look_no = 0;
 
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
     const float in_shift = bound, in_scale = 1.0f / (2.0f * bound);        // grid.py:149 (torch multiplies by the fp32 reciprocal)
     auto lookahead = [&](int phase, const FrameCtrl* c, uint32_t n_bound, hipStream_t q) {
         const uint32_t blocks = lae::cdiv(n_bound, FRAME_BLOCK);
-        if (edit_grid)
+        uint32_t* qc = q_counts + (look_no & 1u);
+        uint32_t* qc_next = q_counts + ((look_no + 1u) & 1u);
+        look_no++;
+        LookTask* qt = finish_queue ? q_tasks : nullptr;
+        const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
+        if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, la_tend, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises);
-        else
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max);
+            if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, la_e, la_cnt, la_tend, rays_o,
+                                                                                        rays_d, fars, cfg, grid, edit_grid);
+        } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, la_tend, rays_o, rays_d,
-                                                                  fars, cfg, grid, nullptr, noises);
+                                                                  fars, cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max);
+            if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, nullptr, la_cnt, la_tend, rays_o,
+                                                                                         rays_d, fars, cfg, grid, nullptr);
+        }
     };
     k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
     k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, rays_t, tc, weights_sum, depth, image,
-                                                    edit_grid ? weights_edit : nullptr, edit_grid ? depth_edit : nullptr);
+                                                    edit_grid ? weights_edit : nullptr, edit_grid ? depth_edit : nullptr, q_counts);
     lookahead(-1, nullptr, N, s);
     uint32_t bound_alive = N, seen_iter = 0;
     bool done = false;
@@ -1795,3 +1988,11 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
 }
 
 }  // extern "C"
+
+#ifdef LAE_FRAME_STAMPS
+extern "C" __attribute__((visibility("default"))) int lae_debug_look_stamps(void* out, size_t bytes, int phase) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (phase >= 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_look_phase), &phase, sizeof(int)) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_look_stamps), bytes) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -11,6 +11,9 @@ r = NeRFRenderer(net, bound=1).to(dev).eval()
 r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
 o, d = S.frame_rays(800, 800)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+if os.environ.get("LAE_FRAME_OVERLAP") == "0":              # lookahead in line on the caller's stream (A/B)
+    from laenerf_amd.backend import raymarching_backend as _rb
+    _rb.render_frame_set_overlap(False)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 budget = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 for it in range(n):

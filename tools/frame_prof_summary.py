@@ -18,3 +18,34 @@ for it, i in enumerate(range(0, len(last), 4)):
     if it < 8 or it % 10 == 0:
         gap = (last[i + 4][3] - grp[0][3]) / 1e3 if i + 4 < len(last) else 0
         print(it, ' '.join(f"{k}:{d / 1e3:6.1f}(g{g})" for k, d, g, s in grp), f"iter wall {gap:.1f}us")
+
+# ---- critical path of an iteration: does the next emit wait for the main stream's compositing or for the lookahead?
+look = [(s, s + d) for (n, s, d, g) in rows if 'k_frame_lookahead' in n]
+main = [(k, s, s + d) for (n, s, d, g) in rows for k, v in names.items() if v in n]
+emits = [i for i, m in enumerate(main) if m[0] == 'emit']
+wait_comp = wait_look = 0.0
+n_it = 0
+gaps = {'emit->grid': 0.0, 'grid->head': 0.0, 'head->comp': 0.0}
+for a, b in zip(emits[:-1], emits[1:]):
+    grp = main[a:b]
+    if [m[0] for m in grp] != ['emit', 'grid', 'head', 'comp']:
+        continue
+    nxt_start = main[b][1]
+    comp_end = grp[3][2]
+    la = [l for l in look if grp[0][2] <= l[0] < nxt_start]          # the lookahead launched after this emit
+    la_end = la[0][1] if la else comp_end
+    wait_comp += (nxt_start - comp_end) / 1e3
+    wait_look += max(0.0, (la_end - comp_end)) / 1e3
+    gaps['emit->grid'] += (grp[1][1] - grp[0][2]) / 1e3
+    gaps['grid->head'] += (grp[2][1] - grp[1][2]) / 1e3
+    gaps['head->comp'] += (grp[3][1] - grp[2][2]) / 1e3
+    n_it += 1
+if n_it:
+    print(f"\n{n_it} iterations: next emit starts {wait_comp / n_it:.1f} us after the compositing kernel ends on average; "
+          f"the lookahead of the iteration ends {wait_look / n_it:.1f} us AFTER it (0 = earlier); "
+          "gaps inside an iteration: " + ", ".join(f"{k} {v / n_it:.1f} us" for k, v in gaps.items()))
+
+la = [(s, d) for (n, s, d, g) in rows if 'k_frame_lookahead' in n]
+per_la = len(la) // frames
+last_la = la[-per_la:]
+print("lookahead durations of the last frame (us), every 5th launch: " + " ".join(f"{d / 1e3:.0f}" for s, d in last_la[::5]))
