@@ -268,3 +268,39 @@ def test_frame_loop_ends_when_every_ray_dies_at_once(kind):
                 b = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=True, want_stats=(rep % 2 == 0))
                 assert np.array_equal(N(a["image"]), N(b["image"]))
                 assert np.array_equal(N(a["weights_sum"]), N(b["weights_sum"]))
+
+
+_AB_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import test_gpu_frame as F
+net, r = F.make(bound={bound})
+o, d = F.rays({n}, seed=5, bound={bound})
+with torch.autocast("cuda", dtype=torch.float16):
+    a = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=True)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for k in ("image", "depth", "weights_sum"):
+    h.update(a[k].float().contiguous().cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("bound,n", [(1, 40000), (2, 20011)])
+def test_lookahead_variants_render_the_same_bits(bound, n):
+    """the lookahead's A/B switches (stragglers finished by the finishing kernel or inside the lane kernel, visits of an empty
+    stretch probed together or one by one, event flags) change WHEN probes are issued and WHO walks a ray, never a sample: the
+    frame must come out bit for bit the same.  The switches are read once per process: fresh child processes."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hashes = {}
+    for name, env in (("default", {}), ("in-wave stragglers", {"LAE_FRAME_FINISH_QUEUE": "0"}), ("plain visits", {"LAE_FRAME_SPEC": "0"}),
+                      ("queue everything up to 48", {"LAE_FRAME_COOP_MAX": "48"}), ("default event flags", {"LAE_FRAME_EVENT_FLAGS": "0"})):
+        e = dict(os.environ, **env)
+        out = subprocess.run([sys.executable, "-c", _AB_SCRIPT.format(root=ROOT, bound=bound, n=n)], capture_output=True, text=True, timeout=600, env=e)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("HASH ")]
+        assert out.returncode == 0 and len(lines) == 1, (name, out.stdout[-1000:], out.stderr[-2000:])
+        hashes[name] = lines[0]
+    assert len(set(hashes.values())) == 1, hashes
