@@ -46,6 +46,7 @@ __device__ unsigned long long g_grid_stamps[8192 * 32];
 #define GRID_NOTE(slot, i, v) do { } while (0)
 #endif
 
+
 // block-uniform description of one level (all derived from scalars -> SGPRs)
 template <int D>
 struct LevelInfo {
@@ -298,6 +299,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
     const uint32_t* __restrict__ B_dev) {
     const uint32_t xcd = blockIdx.x & 7u;
+#ifdef LAE_GRID_STAMPS
+    const unsigned long long st_t0 = wall_clock64();
+#endif
     uint32_t j = blockIdx.x >> 3, level = 0xffffffffu, chunk = 0;
     const uint32_t ns = sched.nseg[xcd];
     for (uint32_t q = 0; q < ns; q++) {
@@ -378,6 +382,11 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     }
     const half2_t h2 = {r0, r1};
     *out = h2;
+#ifdef LAE_GRID_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
+        g_grid_stamps[(size_t)blockIdx.x * 4] = st_t0; g_grid_stamps[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_grid_stamps[(size_t)blockIdx.x * 4 + 2] = level;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- K14
@@ -1356,6 +1365,10 @@ struct FwdArgs {
 // bench batches (tools/ubench/grid_fwd_variants.hip, then a sweep with tools/grid_fwd_bench.py on one-view and 16-view
 // batches): dense 1; hashed 1.25 up to resolution ~80, rising with log2(resolution) to 2.3 at ~550 (consecutive samples of a
 // ray stop sharing cache lines) and 4.5 from ~1000 on (every corner row is its own L2 request).  Only the balance depends on it, never a result.
+// (round 3, tools/grid_fwd_spans.py -- per-block stamps of one launch: with this table the XCDs end at 38.5-41 us (one finest level
+// each) and 45-47 us (two middle levels + dense eighths); a table re-fitted to those spans (middle levels 2.0-2.9 instead of
+// 1.4-2.4) moves the late end to the XCDs that carry levels 11 / 12 + dense eighths and the launch still spans 46.5 us: two levels
+// sharing an XCD overlap better than their solo costs add up, and the dense eighths run last on every XCD.  Kept as calibrated.)
 static float fwd_level_cost(bool hashed, uint32_t resolution) {
     if (!hashed) return 1.0f;
     const float lr = log2f((float)resolution);
