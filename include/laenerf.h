@@ -554,9 +554,9 @@ LAE_API int lae_ema_update_multi(uint32_t n_tensors, float* const* shadows, cons
 /* MI355X-native: 0 (default) = fused backward (activations recomputed in registers, forward_buffer /
  * backward_buffer untouched: both are scratch the reference's Python never reads), every wave accumulating all dW tiles
  * over its own rows, operands transposed on the matrix cores (round 3); 1 = always the three-kernel path that fills both
- * buffers exactly like the reference; 2 = the first fused design (wave-private dW, transposes through LDS); 3 = dW tiles
- * divided among the waves of a workgroup (the round-2 default).  16 / 17 / 18 select the fused-head forward kernel
- * (round 2 / registers / LDS image = default); all kept for A/B. */
+ * buffers exactly like the reference; 3 = fused backward with the dW tiles divided among the waves of a workgroup (the
+ * round-2 kernel, kept as the one A/B predecessor).  Any other value: LAE_EINVAL (round 4 removed the first fused design,
+ * mode 2, and the superseded fused-head forward kernels, modes 16-18). */
 LAE_API int lae_ffmlp_set_mode(int mode);
 
 /* ffmlp.cu:721-740: the reference keeps process-global side streams for its

@@ -507,8 +507,7 @@ class _FFMLP:
     @staticmethod
     def ffmlp_set_mode(mode):
         """0 = fused backward, wave-private dW with MFMA transposes (default); 1 = buffer-faithful three-kernel backward (fills
-        forward/backward buffers); 2 = wave-private dW with LDS transposes; 3 = workgroup-cooperative dW; 16-18 = fused-head
-        forward kernels (include/laenerf.h)"""
+        forward/backward buffers); 3 = fused backward with the round-2 workgroup-cooperative dW kernel (include/laenerf.h)"""
         check(_lib.load().lae_ffmlp_set_mode(int(mode)), "ffmlp_set_mode")
 
     @staticmethod

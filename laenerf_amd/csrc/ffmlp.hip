@@ -14,6 +14,7 @@
 // is bit-for-bit the B fragment of K-step t of the next layer, so activations
 // chain through all layers in registers: no LDS, no shuffles.  Accumulation is
 // fp32 (the reference accumulates in fp16 fragments, ffmlp.cu:68).
+#include <string>
 #include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
@@ -451,15 +452,6 @@ __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce2(const float* __r
 // Saved for the backward: h [M,16] fp16 (32 B/row) and rgb; nothing else touches HBM.
 #include "sh_table.inc"
 
-struct HeadCfg {
-    static constexpr int LDX = 40, LDH = 72;
-    // sigma net image
-    static constexpr int S0 = 0, S1 = S0 + 64 * LDX, SO = S1 + 64 * LDH, S_END = SO + 16 * LDH;
-    // colour net image
-    static constexpr int C0 = S_END, C1 = C0 + 64 * LDX, C2 = C1 + 64 * LDH, CO = C2 + 64 * LDH, C_END = CO + 16 * LDH;
-    static constexpr int LDS_HALVES = C_END;
-};
-
 __device__ __forceinline__ void stage_rows(half_t* dst, int ld, const half_t* __restrict__ src, int rows, int cols) {
     for (uint32_t e = threadIdx.x; e < (uint32_t)rows * cols / 4; e += blockDim.x) {
         const uint32_t r = (e * 4) / cols, k = (e * 4) % cols;
@@ -554,27 +546,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int IN, int NH>
-struct FusedCfg {
-    static constexpr int KT0 = IN / 16;                    // k-steps of the input layer
-    static constexpr int LDX = IN + 8;                     // padded LDS row strides (halves); multiples of 4 -> 8-byte rows
-    static constexpr int LDH = 72;
-    static constexpr int LDG = 24;
-    // weight image (halves)
-    static constexpr int W0_OFF = 0;
-    static constexpr int WH_OFF = 64 * LDX;
-    static constexpr int WO_OFF = WH_OFF + NH * 64 * LDH;
-    static constexpr int W_HALVES = WO_OFF + 16 * LDH;
-    // per-wave tile region: X | H[0..NH] | D (one tile, reused per layer) | G
-    static constexpr int X_OFF = 0;
-    static constexpr int H_OFF = 16 * LDX;
-    static constexpr int D_OFF = H_OFF + (NH + 1) * 16 * LDH;
-    static constexpr int G_OFF = D_OFF + 16 * LDH;
-    static constexpr int WAVE_HALVES = G_OFF + 16 * LDG;
-    static constexpr int N_TILES = 4 * KT0 + NH * 16 + 4; // 16x16 dW tiles: W0 | hidden | Wout
-    static constexpr int LDS_HALVES = W_HALVES + 4 * WAVE_HALVES;
-};
-
 // B fragments of a 32-wide encoder row.  Row-major [M,32]: features 16kt + 4g .. +3 are one 8-byte load.  Level-major
 // [16][M][2] (the grid kernels' native layout): the same four features are the channel pairs of levels 8kt + 2g and
 // 8kt + 2g + 1 -- two 4-byte loads, 64 contiguous bytes per level for the 16 rows of a tile.
@@ -600,239 +571,6 @@ struct HeadBwdArgs {
     const float* dirs; const float* rgbs; const float* grad_rgbs; const float* grad_sigmas; float density_scale;
     int level_major;        // MODE 0, IN = 32: x and grad_in are [16][B][2] (the grid kernels' layout) instead of [B,32]
 };
-
-template <int IN, int NH, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp_bwd_fused(
-    const half_t* __restrict__ grad, const half_t* __restrict__ x, const half_t* __restrict__ W, uint32_t n_tiles,
-    half_t* __restrict__ grad_in, float* __restrict__ slabs, uint32_t nW, HeadBwdArgs ha) {
-    using C = FusedCfg<IN, NH>;
-    constexpr int KT0 = C::KT0;
-    extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    half_t* Wl = lds;                                          // weight image
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: per-wave branches stay uniform
-    half_t* T = lds + C::W_HALVES + w * C::WAVE_HALVES;        // this wave's tiles
-    // transposed-read lane address inside a [16 x ld] tile: group g reads rows 4g..4g+3, lane i=4q+p supplies row q, cols 4p..
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-
-    // ---- stage the weights row-major (padded) once per workgroup
-    for (uint32_t e = threadIdx.x; e < 64u * IN / 4; e += 256) {
-        const uint32_t r = (e * 4) / IN, k = (e * 4) % IN;
-        *reinterpret_cast<h4*>(Wl + C::W0_OFF + r * C::LDX + k) = *reinterpret_cast<const h4*>(W + (size_t)r * IN + k);
-    }
-    for (uint32_t e = threadIdx.x; e < (uint32_t)NH * 64 * 64 / 4; e += 256) {
-        const uint32_t m = (e * 4) / 4096, r = ((e * 4) % 4096) / 64, k = (e * 4) % 64;
-        *reinterpret_cast<h4*>(Wl + C::WH_OFF + (m * 64 + r) * C::LDH + k) =
-            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)m * 4096 + r * 64 + k);
-    }
-    for (uint32_t e = threadIdx.x; e < 16u * 64 / 4; e += 256) {
-        const uint32_t r = (e * 4) / 64, k = (e * 4) % 64;
-        *reinterpret_cast<h4*>(Wl + C::WO_OFF + r * C::LDH + k) =
-            *reinterpret_cast<const h4*>(W + 64 * IN + (size_t)NH * 4096 + r * 64 + k);
-    }
-    __syncthreads();
-
-    f4 dW0[4][KT0], dWh[NH][4][4], dWo[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < KT0; j++) dW0[i][j] = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int m = 0; m < NH; m++)
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) dWh[m][i][j] = f4{0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; j++) dWo[j] = f4{0, 0, 0, 0};
-
-    const uint32_t wave0 = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
-    for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
-        const size_t row = (size_t)tile * 16 + c;
-        // ---- inputs: B fragments + X tile
-        h4 xf[KT0];
-        h4 gf, hq;
-        if constexpr (MODE == 1) {
-            static_assert(MODE == 0 || KT0 == 2, "head colour net has a 32-wide input");
-            hq = *reinterpret_cast<const h4*>(x + row * 16 + 4 * g);
-            color_inputs(ha.dirs, row, hq, g, xf);
-            gf = h4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
-            if (g == 0) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const float y = ha.rgbs[row * 3 + r];
-                    gf[r] = (half_t)(ha.grad_rgbs[row * 3 + r] * y * (1.0f - y));
-                }
-            }
-        } else {
-            if constexpr (KT0 == 2) {
-                load_enc_frags(x, row, (size_t)n_tiles * 16, g, ha.level_major, xf);
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < KT0; kt++) xf[kt] = *reinterpret_cast<const h4*>(x + row * IN + kt * 16 + 4 * g);
-            }
-            gf = *reinterpret_cast<const h4*>(grad + row * 16 + 4 * g);
-        }
-#pragma unroll
-        for (int kt = 0; kt < KT0; kt++) *reinterpret_cast<h4*>(T + C::X_OFF + c * C::LDX + kt * 16 + 4 * g) = xf[kt];
-        *reinterpret_cast<h4*>(T + C::G_OFF + c * C::LDG + 4 * g) = gf;
-        // ---- recompute the hidden activations (post-ReLU), keep them in registers and in the H tiles
-        h4 h[NH + 1][4];
-        {
-            f4 acc[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-                acc[mt] = mfma_ksteps<KT0>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::W0_OFF + (mt * 16 + c) * C::LDX + kt * 16 + 4 * g); },
-                                           xf, f4{0, 0, 0, 0});
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) h[0][mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
-                *reinterpret_cast<h4*>(T + C::H_OFF + c * C::LDH + mt * 16 + 4 * g) = h[0][mt];
-            }
-#pragma unroll
-            for (int l = 0; l < NH; l++) {
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++)
-                    acc[mt] = mfma_ksteps<4>([&](int kt) { return *reinterpret_cast<const h4*>(Wl + C::WH_OFF + (l * 64 + mt * 16 + c) * C::LDH + kt * 16 + 4 * g); },
-                                             h[l], f4{0, 0, 0, 0});
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) h[l + 1][mt][r] = (half_t)fmaxf(acc[mt][r], 0.0f);
-                    *reinterpret_cast<h4*>(T + C::H_OFF + (l + 1) * 16 * C::LDH + c * C::LDH + mt * 16 + 4 * g) = h[l + 1][mt];
-                }
-            }
-        }
-        wave_lds_fence();
-        // ---- output layer: dWout += G^T H_NH ;  dH_NH = (Wout^T G) * relu'
-        {
-            const h4 a = lds_tr_read(T + C::G_OFF + (4 * g + tq) * C::LDG + 4 * tp);                         // A[o][b]
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) {
-                const h4 b = lds_tr_read(T + C::H_OFF + NH * 16 * C::LDH + (4 * g + tq) * C::LDH + nt * 16 + 4 * tp);   // B[b][i]
-                dWo[nt] = mfma16(a, b, dWo[nt]);
-            }
-        }
-        h4 d[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const h4 a = lds_tr_read(Wl + C::WO_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);             // A[f][o] = Wout[o][f]
-            const f4 acc = mfma16(a, gf, f4{0, 0, 0, 0});
-#pragma unroll
-            for (int r = 0; r < 4; r++) d[mt][r] = ((float)h[NH][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
-        }
-        // ---- hidden layers, last to first: dW_l += D_l^T H_{l-1} ; dH_{l-1} = (W_l^T dH_l) * relu'
-#pragma unroll
-        for (int l = NH; l >= 1; l--) {
-            wave_lds_fence();                               // previous readers of the D tile are done
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(T + C::D_OFF + c * C::LDH + mt * 16 + 4 * g) = d[mt];
-            wave_lds_fence();
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const h4 a = lds_tr_read(T + C::D_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) {
-                    const h4 b = lds_tr_read(T + C::H_OFF + (l - 1) * 16 * C::LDH + (4 * g + tq) * C::LDH + nt * 16 + 4 * tp);
-                    dWh[l - 1][mt][nt] = mfma16(a, b, dWh[l - 1][mt][nt]);
-                }
-            }
-            h4 dn[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::WH_OFF + ((l - 1) * 64 + kt * 16 + 4 * g + tq) * C::LDH + mt * 16 + 4 * tp); },   // W_l^T
-                                              d, f4{0, 0, 0, 0});
-#pragma unroll
-                for (int r = 0; r < 4; r++) dn[mt][r] = ((float)h[l - 1][mt][r] > 0.0f) ? (half_t)acc[r] : (half_t)0.0f;
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) d[mt] = dn[mt];
-        }
-        // ---- input layer: dW0 += D_0^T X ; dX = W0^T dH_0
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) *reinterpret_cast<h4*>(T + C::D_OFF + c * C::LDH + mt * 16 + 4 * g) = d[mt];
-        wave_lds_fence();
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const h4 a = lds_tr_read(T + C::D_OFF + (4 * g + tq) * C::LDH + mt * 16 + 4 * tp);
-#pragma unroll
-            for (int nt = 0; nt < KT0; nt++) {
-                const h4 b = lds_tr_read(T + C::X_OFF + (4 * g + tq) * C::LDX + nt * 16 + 4 * tp);
-                dW0[mt][nt] = mfma16(a, b, dW0[mt][nt]);
-            }
-        }
-        if constexpr (MODE == 1) {
-            const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + 16 + 4 * tp); },   // W0^T, features 16..31
-                                          d, f4{0, 0, 0, 0});
-            const half_t v3 = (half_t)acc[3];
-            const half_t prev = __builtin_bit_cast(half_t, (uint16_t)__shfl_up((int)__builtin_bit_cast(uint16_t, v3), 16, 64));
-            h4 v;
-            v[0] = prev;
-            if (g == 0) v[0] = (half_t)(ha.grad_sigmas[row] * ha.density_scale * expf(lae::clampf((float)hq[0], -15.0f, 15.0f)));
-            v[1] = (half_t)acc[0]; v[2] = (half_t)acc[1]; v[3] = (half_t)acc[2];
-            *reinterpret_cast<h4*>(grad_in + row * 16 + 4 * g) = v;
-        } else if (grad_in) {
-#pragma unroll
-            for (int it = 0; it < KT0; it++) {
-                const f4 acc = mfma_ksteps<4>([&](int kt) { return lds_tr_read(Wl + C::W0_OFF + (kt * 16 + 4 * g + tq) * C::LDX + it * 16 + 4 * tp); },   // W0^T
-                                              d, f4{0, 0, 0, 0});
-                h4 v;
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = (half_t)acc[r];
-                if (KT0 == 2 && ha.level_major) {           // two level planes, 64 contiguous bytes per plane and tile
-                    const uint2 u = __builtin_bit_cast(uint2, v);
-                    const size_t Bn = (size_t)n_tiles * 16;
-                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g) * Bn + row) * 2) = u.x;
-                    *reinterpret_cast<uint32_t*>(grad_in + ((size_t)(8 * it + 2 * g + 1) * Bn + row) * 2) = u.y;
-                } else
-                    *reinterpret_cast<h4*>(grad_in + row * IN + it * 16 + 4 * g) = v;
-            }
-        }
-        wave_lds_fence();                                   // tiles are rewritten by the next iteration
-    }
-
-    // ---- sum the 4 waves' dW tiles through LDS in wave order (deterministic), store one slab per workgroup
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);             // N_TILES * 256 floats (<= 45 KiB), reuses the LDS
-    auto put = [&](int t, const f4& v, bool first) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float* p = red + t * 256 + (4 * g + r) * 16 + c;
-            *p = first ? v[r] : (*p + v[r]);
-        }
-    };
-    for (int ww = 0; ww < 4; ww++) {
-        if (w == ww) {
-            int t = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < KT0; j++) put(t++, dW0[i][j], ww == 0);
-#pragma unroll
-            for (int m = 0; m < NH; m++)
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) put(t++, dWh[m][i][j], ww == 0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) put(t++, dWo[j], ww == 0);
-        }
-        __syncthreads();
-    }
-    float* slab = slabs + (size_t)blockIdx.x * nW;
-    for (uint32_t e = threadIdx.x; e < (uint32_t)C::N_TILES * 256; e += 256) {
-        const uint32_t t = e >> 8, rr = (e >> 4) & 15, cc = e & 15;
-        size_t idx;
-        if (t < 4u * KT0) idx = (size_t)((t / KT0) * 16 + rr) * IN + (t % KT0) * 16 + cc;
-        else if (t < 4u * KT0 + NH * 16u) {
-            const uint32_t u = t - 4 * KT0, m = u / 16, i = (u % 16) / 4, j = u % 4;
-            idx = (size_t)64 * IN + (size_t)m * 4096 + (i * 16 + rr) * 64 + j * 16 + cc;
-        } else idx = (size_t)64 * IN + (size_t)NH * 4096 + rr * 64 + (t - 4 * KT0 - NH * 16) * 16 + cc;
-        slab[idx] = red[e];
-    }
-}
 
 // ---------------------------------------------------------------- fused backward, workgroup-cooperative dW
 // Same mathematics as k_mlp_bwd_fused, different ownership of the weight-gradient tiles.  There every wave accumulates
@@ -1445,10 +1183,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     MLP_STAMP(blockIdx.x * 4 + w, 15);
 }
 
-// 0 = workgroup-cooperative dW (default), 1 = wave-private dW (k_mlp_bwd_fused); A/B switch, see lae_ffmlp_set_mode
+// 2 = wave-private dW with MFMA transposes (k_mlp_bwd_wave, default), 0 = workgroup-cooperative dW (k_mlp_bwd_coop, round 2), 3 = wave-private
+// for one hidden GEMM and cooperative for two; A/B switch, see lae_ffmlp_set_mode
 int g_bwd_fused_variant = -1;
 static int bwd_fused_variant() {
-    if (g_bwd_fused_variant < 0) { const char* e = getenv("LAE_MLP_BWD_VARIANT"); g_bwd_fused_variant = e ? atoi(e) : 2; if (g_bwd_fused_variant < 0 || g_bwd_fused_variant > 3) g_bwd_fused_variant = 2; }
+    if (g_bwd_fused_variant < 0) { const char* e = getenv("LAE_MLP_BWD_VARIANT"); g_bwd_fused_variant = e ? atoi(e) : 2; if (g_bwd_fused_variant != 0 && g_bwd_fused_variant != 3) g_bwd_fused_variant = 2; }
     return g_bwd_fused_variant;
 }
 
@@ -1476,7 +1215,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
         ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_wave<IN, NH, MODE, WPE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
-    } else if (variant == 0) {
+    } else {                                               // the round-2 kernel, kept as the A/B predecessor
         constexpr int WAVES = 8;
         using C = CoopCfg<IN, NH, WAVES>;
         const size_t lds_bytes = (size_t)C::LDS_HALVES * 2;
@@ -1490,261 +1229,28 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
         ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
         if (!ws) return LAE_ELAUNCH;
         k_mlp_bwd_coop<IN, NH, MODE, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
-    } else {
-        using C = FusedCfg<IN, NH>;
-        const size_t lds_bytes = std::max((size_t)C::LDS_HALVES * 2, (size_t)C::N_TILES * 1024);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_bwd_fused<IN, NH, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
-            attr_set = true;
-        }
-        blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 2));
-        ws = slabs ? slabs : reinterpret_cast<float*>(lae::workspace(lae::WS_FFMLP_SLABS, (size_t)blocks * nW * sizeof(float), s));
-        if (!ws) return LAE_ELAUNCH;
-        k_mlp_bwd_fused<IN, NH, MODE><<<blocks, 256, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     }
     if (n_slices_out) *n_slices_out = blocks;
     if (!slabs) k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
     return LAE_OK;
 }
 
-template <bool COLOR>
-__global__ __launch_bounds__(256) void k_nerf_head_fwd(
-    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
-    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
-    int level_major, const uint32_t* __restrict__ n_rows_dev, uint32_t lm_rows) {
-    using C = HeadCfg;
-    // frame loop: live row count from the device (rounded up to whole 16-row tiles, the producer keeps those rows benign);
-    // lm_rows = row capacity of the level-major feature image
-    if (n_rows_dev) n_tiles = min(n_tiles, (*n_rows_dev + 15u) / 16u);
-    if (n_tiles == 0) return;
-    extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    stage_rows(lds + C::S0, C::LDX, Ws, 64, 32);
-    stage_rows(lds + C::S1, C::LDH, Ws + 64 * 32, 64, 64);
-    stage_rows(lds + C::SO, C::LDH, Ws + 64 * 32 + 4096, 16, 64);
-    if constexpr (COLOR) {
-        stage_rows(lds + C::C0, C::LDX, Wc, 64, 32);
-        stage_rows(lds + C::C1, C::LDH, Wc + 64 * 32, 64, 64);
-        stage_rows(lds + C::C2, C::LDH, Wc + 64 * 32 + 4096, 64, 64);
-        stage_rows(lds + C::CO, C::LDH, Wc + 64 * 32 + 8192, 16, 64);
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * 4;   // scalar tile loop
-    // software pipeline: the inputs of the wave's NEXT tile are requested before the current tile's MFMA chain (two
-    // waves per SIMD do not hide a global-load latency per tile on their own; measured neutral on the 248 k-sample step,
-    // the kernel is VALU-bound: ~700 VALU instructions per 36 MFMAs per tile)
-    h4 xf_n[2] = {};
-    float d_n[3] = {0.f, 0.f, 0.f};
-    auto request = [&](uint32_t t) {
-        const size_t r = (size_t)t * 16 + c;
-        load_enc_frags(enc, r, (size_t)lm_rows, g, level_major, xf_n);
-        if constexpr (COLOR) { d_n[0] = dirs[3 * r]; d_n[1] = dirs[3 * r + 1]; d_n[2] = dirs[3 * r + 2]; }
-    };
-    if (wave0 < n_tiles) request(wave0);
-    for (uint32_t tile = wave0; tile < n_tiles; tile += nwaves) {
-        const size_t row = (size_t)tile * 16 + c;
-        h4 xf[2] = {xf_n[0], xf_n[1]};
-        const float dx = d_n[0], dy = d_n[1], dz = d_n[2];
-        if (tile + nwaves < n_tiles) request(tile + nwaves);
-        f4 acc[4];
-        h4 a0[4], a1[4];
-        layer64<2>(lds + C::S0, C::LDX, xf, c, g, acc); relu4(acc, a0);
-        layer64<4>(lds + C::S1, C::LDH, a0, c, g, acc); relu4(acc, a1);
-        const f4 so = out16(lds + C::SO, C::LDH, a1, c, g);
-        h4 hq;
-#pragma unroll
-        for (int r = 0; r < 4; r++) hq[r] = (half_t)so[r];
-        if (h_out) *reinterpret_cast<h4*>(h_out + row * 16 + 4 * g) = hq;
-        if (g == 0) sigmas[row] = density_scale * expf((float)hq[0]);                    // trunc_exp forward (activation.py:9)
-        if constexpr (!COLOR) continue;
-        h4 cin[2];
-        color_inputs(dx, dy, dz, hq, g, cin);
-        layer64<2>(lds + C::C0, C::LDX, cin, c, g, acc); relu4(acc, a0);
-        layer64<4>(lds + C::C1, C::LDH, a0, c, g, acc); relu4(acc, a1);
-        layer64<4>(lds + C::C2, C::LDH, a1, c, g, acc); relu4(acc, a0);
-        const f4 co = out16(lds + C::CO, C::LDH, a0, c, g);
-        if (g == 0) {
-#pragma unroll
-            // sigmoid of the fp16 output, rounded to fp16 like torch.sigmoid on a half tensor (network_ff.py:79 under autocast)
-            for (int r = 0; r < 3; r++) rgbs[row * 3 + r] = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)co[r])));
-        }
-    }
-}
+struct Head4Scratch { half_t sh[64][16]; float q[64][4]; };             // per wave: SH block and logits on their way between row-per-lane and fragment layout
 
-// ---------------------------------------------------------------- fused NeRF head, round-3 form
-// Same arithmetic as k_nerf_head_fwd (results are the same bits), different schedule.  What the round-2 kernel cost
-// (rocprof 24.7 us for 258 k rows = 15 % of the MFMA rate) and what this form does about it:
-//  * prologue: the seven weight matrices were staged through LDS by loops of ONE 8-byte load per thread and iteration, each
-//    waited for before the next was issued (18 serial L2 round trips per workgroup), then read back into 144 registers.
-//    Here every wave loads its A fragments straight from global memory (L2 / L1 resident, 72 independent 8-byte loads in
-//    flight) -- no LDS image, no barrier.
-//  * one 16-row tile per wave iteration is a single dependency chain (MFMA -> cvt / relu -> MFMA ...; DESIGN 4d: the
-//    kernel waited on that chain, not on issue slots).  Here a wave owns FOUR tiles (64 rows) per iteration and every
-//    layer is issued for all four before its activations are needed: four independent chains per wave, one wave per SIMD
-//    (the 144 weight registers + 4 x 32 activation registers fit the 512-register budget of a one-wave SIMD).
-//  * per-row scalar work was replicated by the four lane groups of a 16-row tile (SH polynomials, exp, three sigmoids with
-//    an IEEE division each: ~170 of the ~300 VALU instructions per tile, three quarters of them discarded).  With 64 rows
-//    per iteration lane L does that work for row L once; the values reach / leave the MFMA fragment layout through a
-//    wave-private 3 KB LDS scratch (2 wide stores + 4 fragment reads for the SH block; one masked store per tile + one
-//    read for the density logit and the colour logits).  sigma / rgb leave as one coalesced row-per-lane store.
-struct Head4Scratch { half_t sh[64][16]; float q[64][4]; };             // per wave
-
-// 64-wide layer on NT tiles from register-resident A fragments; ReLU + fp16 rounding like relu4
-template <int KT, int NT>
-__device__ __forceinline__ void layer64x(const h4 (&w)[4][KT], const h4 (&in)[NT][KT], h4 (&out)[NT][4]) {
-    static_assert(KT % 2 == 0, "k-steps in pairs (K = 32 MFMA)");
-    f4 acc[NT][4];
-#pragma unroll
-    for (int kt = 0; kt < KT; kt += 2)
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-                acc[t][mt] = mfma32(w[mt][kt], w[mt][kt + 1], in[t][kt], in[t][kt + 1], kt == 0 ? f4{0, 0, 0, 0} : acc[t][mt]);
-#pragma unroll
-    for (int t = 0; t < NT; t++) relu4(acc[t], out[t]);
-}
-template <int NT>
-__device__ __forceinline__ void out16x(const h4 (&w)[4], const h4 (&in)[NT][4], f4 (&o)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) o[t] = mfma32(w[0], w[1], in[t][0], in[t][1], f4{0, 0, 0, 0});
-#pragma unroll
-    for (int t = 0; t < NT; t++) o[t] = mfma32(w[2], w[3], in[t][2], in[t][3], o[t]);
-}
-// A fragments of a row-major [rows, K] weight matrix: fragment (mt, kt) of lane (c, g) = W[16 mt + c][16 kt + 4 g .. + 3]
-template <int MT, int KT>
-__device__ __forceinline__ void load_a_frags(const half_t* __restrict__ W, int c, int g, h4 (&w)[MT][KT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) w[mt][kt] = *reinterpret_cast<const h4*>(W + (size_t)(mt * 16 + c) * (KT * 16) + kt * 16 + 4 * g);
-}
-
-template <bool COLOR>
-__global__ __launch_bounds__(256) void k_nerf_head_fwd4(
-    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
-    uint32_t n_tiles, float density_scale, half_t* __restrict__ h_out, float* __restrict__ sigmas, float* __restrict__ rgbs,
-    int level_major, const uint32_t* __restrict__ n_rows_dev, uint32_t lm_rows) {
-    constexpr int NT = 4;
-    if (n_rows_dev) n_tiles = min(n_tiles, (*n_rows_dev + 15u) / 16u);
-    if (n_tiles == 0) return;
-    extern __shared__ __attribute__((aligned(16))) half_t lds[];
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    Head4Scratch* sc = reinterpret_cast<Head4Scratch*>(lds) + w;
-
-    // ---- weights: every wave keeps the A fragments of both nets in registers
-    h4 wS0[4][2], wS1[4][4], wSo[1][4], wC0[4][2], wC1[4][4], wC2[4][4], wCo[1][4];
-    MLP_STAMP(blockIdx.x * 4 + w, 0);
-    load_a_frags<4, 2>(Ws, c, g, wS0);
-    load_a_frags<4, 4>(Ws + 64 * 32, c, g, wS1);
-    load_a_frags<1, 4>(Ws + 64 * 32 + 4096, c, g, wSo);
-    if constexpr (COLOR) {
-        load_a_frags<4, 2>(Wc, c, g, wC0);
-        load_a_frags<4, 4>(Wc + 64 * 32, c, g, wC1);
-        load_a_frags<4, 4>(Wc + 64 * 32 + 4096, c, g, wC2);
-        load_a_frags<1, 4>(Wc + 64 * 32 + 8192, c, g, wCo);
-    }
-
-    const uint32_t n_groups = (n_tiles + NT - 1) / NT;
-    const uint32_t wave0 = blockIdx.x * 4 + (uint32_t)w, nwaves = gridDim.x * 4;
-    const uint32_t n_rows = n_tiles * 16u;
-    // software pipeline: the inputs of the wave's next group are requested before the current group's chains
-    h4 xf_n[NT][2] = {};
-    float d_n[3] = {0.f, 0.f, 0.f};
-    auto request = [&](uint32_t grp) {
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const uint32_t tile = grp * NT + t;
-            if (tile < n_tiles) load_enc_frags(enc, (size_t)tile * 16 + c, (size_t)lm_rows, g, level_major, xf_n[t]);
-            else { xf_n[t][0] = h4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}; xf_n[t][1] = xf_n[t][0]; }
-        }
-        if constexpr (COLOR) {
-            const uint32_t r = grp * 64u + (uint32_t)lane;
-            if (r < n_rows) { d_n[0] = dirs[3 * (size_t)r]; d_n[1] = dirs[3 * (size_t)r + 1]; d_n[2] = dirs[3 * (size_t)r + 2]; }
-            else { d_n[0] = 0.f; d_n[1] = 0.f; d_n[2] = 0.f; }
-        }
-    };
-    if (wave0 < n_groups) request(wave0);
-    [[maybe_unused]] int stamp_i = 1;
-    for (uint32_t grp = wave0; grp < n_groups; grp += nwaves) {
-        MLP_STAMP(blockIdx.x * 4 + w, stamp_i); stamp_i++;
-        h4 xf[NT][2];
-#pragma unroll
-        for (int t = 0; t < NT; t++) { xf[t][0] = xf_n[t][0]; xf[t][1] = xf_n[t][1]; }
-        const float dx = d_n[0], dy = d_n[1], dz = d_n[2];
-        if (grp + nwaves < n_groups) request(grp + nwaves);
-        const uint32_t row_l = grp * 64u + (uint32_t)lane;               // the row this lane does the per-row work for
-        // ---- direction encoding of the 64 rows, one row per lane -> scratch (fragment reads below)
-        if constexpr (COLOR) {
-            float o[16], gx[1], gy[1], gz[1];
-            sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
-            h8 lo, hi;
-#pragma unroll
-            for (int j = 0; j < 8; j++) { lo[j] = (half_t)o[j]; hi[j] = (half_t)o[8 + j]; }
-            *reinterpret_cast<h8*>(&sc->sh[lane][0]) = lo;
-            *reinterpret_cast<h8*>(&sc->sh[lane][8]) = hi;
-        }
-        // ---- sigma net, four tiles side by side
-        h4 a0[NT][4], a1[NT][4];
-        layer64x<2, NT>(wS0, xf, a0);
-        layer64x<4, NT>(wS1, a0, a1);
-        f4 so[NT];
-        out16x<NT>(wSo[0], a1, so);
-        h4 hq[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) hq[t][r] = (half_t)so[t][r];
-            const uint32_t tile = grp * NT + t;
-            if (h_out && tile < n_tiles) *reinterpret_cast<h4*>(h_out + ((size_t)tile * 16 + c) * 16 + 4 * g) = hq[t];
-            if (g == 0) sc->q[t * 16 + c][0] = (float)hq[t][0];         // density logit of row (t, c) -> lane 16 t + c
-        }
-        wave_lds_fence();
-        if (row_l < n_rows) sigmas[row_l] = density_scale * expf(sc->q[lane][0]);        // trunc_exp forward (activation.py:9)
-        if constexpr (!COLOR) { wave_lds_fence(); continue; }
-        // ---- colour net
-        h4 cin[NT][2];
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            cin[t][0] = *reinterpret_cast<const h4*>(&sc->sh[t * 16 + c][4 * g]);
-            const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[t][0]), 16, 64));
-            cin[t][1][0] = hq[t][1]; cin[t][1][1] = hq[t][2]; cin[t][1][2] = hq[t][3];
-            cin[t][1][3] = g == 3 ? (half_t)0.0f : nxt;
-        }
-        layer64x<2, NT>(wC0, cin, a0);
-        layer64x<4, NT>(wC1, a0, a1);
-        layer64x<4, NT>(wC2, a1, a0);
-        f4 co[NT];
-        out16x<NT>(wCo[0], a0, co);
-        wave_lds_fence();                                                // the logit reads above are done
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-            if (g == 0) *reinterpret_cast<f4*>(&sc->q[t * 16 + c][0]) = co[t];
-        wave_lds_fence();
-        if (row_l < n_rows) {
-            const f4 v = *reinterpret_cast<const f4*>(&sc->q[lane][0]);
-            // sigmoid of the fp16 output, rounded to fp16 like torch.sigmoid on a half tensor (network_ff.py:79 under autocast)
-            struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
-            F3 out;
-            out.x = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[0])));
-            out.y = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[1])));
-            out.z = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[2])));
-            *reinterpret_cast<F3*>(rgbs + (size_t)row_l * 3) = out;
-        }
-        wave_lds_fence();                                                // scratch is rewritten by the next group
-    }
-    MLP_STAMP(blockIdx.x * 4 + w, 15);
-}
-
-// ---- third form (the one that ships): as k_nerf_head_fwd4, but the A fragments are re-read from a pre-swizzled LDS image
-// (one conflict-free ds_read_b128 per fragment PAIR and four tiles) instead of being held in 144 registers: in-kernel stamps
-// (tools/ubench/mlp_probe.hip) showed that (i) 1024 waves each pulling 37 KB of fragments from L2 take 7.5 us before the first
-// row is touched, and (ii) one wave alone on a SIMD issues an instruction every ~5 cycles whatever it is, so the register-
-// resident form (286 VGPRs, one wave per SIMD) ran a 64-row group in 7300 cycles: the rate of this kernel is instructions
-// per row x issue interval, and the issue interval halves with a second wave on the SIMD.
+// ---------------------------------------------------------------- fused NeRF head, the kernel that ships
+// (round 1-2: one 16-row tile per wave iteration, weights row-major in LDS; round 3 first form: fragments in 144 registers,
+// one wave per SIMD -- both removed in round 4, their measurements are in DESIGN.md appendix A.)
+//  * a wave owns FOUR tiles (64 rows) per iteration and every layer is issued for all four before its activations are
+//    needed: four independent MFMA -> cvt / relu -> MFMA chains per wave instead of one;
+//  * per-row scalar work (SH polynomials, exp, three sigmoids with an IEEE division each) is done by lane L for row L once,
+//    not by the four lane groups of a 16-row tile; the values reach / leave the MFMA fragment layout through a wave-private
+//    3 KB LDS scratch (2 wide stores + 4 fragment reads for the SH block; one masked store per tile + one read for the
+//    density logit and the colour logits).  sigma / rgb leave as one coalesced row-per-lane store;
+//  * the A fragments are re-read from a pre-swizzled LDS image (one conflict-free ds_read_b128 per fragment PAIR and four
+//    tiles) instead of being held in registers: in-kernel stamps (tools/ubench/mlp_probe.hip) showed that 1024 waves each
+//    pulling 37 KB of fragments from L2 take 7.5 us before the first row is touched, and that one wave alone on a SIMD
+//    issues an instruction every ~5 cycles whatever it is -- the rate of this kernel is instructions per row x issue
+//    interval, and the issue interval halves with a second wave on the SIMD.
 // LDS image of a [16 MT, 32 KP] weight matrix: fragment pair (mt, p) of lane l = 16 bytes at ((mt * KP + p) * 64 + l) * 16:
 // halves 0-3 = W[16 mt + c][32 p + 4 g ..], halves 4-7 = W[16 mt + c][32 p + 16 + 4 g ..] (the two operands of one K = 32 MFMA).
 template <int MT, int KP, int NTH>
@@ -2097,23 +1603,9 @@ int backward_w(const half_t* grad, const half_t* in, const half_t* W, const half
 
 }  // namespace
 
-// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], live rows = *n_rows_dev
 static uint32_t head_blocks_per_cu() {
     static int v = 0;
-    if (v == 0) { const char* e = getenv("LAE_HEAD_BLOCKS_PER_CU"); v = e ? atoi(e) : 2; if (v < 1 || v > 8) v = 2; }
-    return (uint32_t)v;
-}
-// 2 (default): k_nerf_head_fwd5 (64 rows per wave iteration, fragments from a swizzled LDS image); 1: k_nerf_head_fwd4 (the same
-// with the fragments in registers, one wave per SIMD); 0: the round-2 kernel.  A/B switch: LAE_HEAD_FWD_VARIANT or
-// lae_ffmlp_set_mode(16 + v).  The 16-byte staging loads of form 2 need 16-byte aligned weight pointers (else form 0).
-int g_head_fwd_variant = -1;
-static int head_fwd_variant() {
-    if (g_head_fwd_variant < 0) { const char* e = getenv("LAE_HEAD_FWD_VARIANT"); g_head_fwd_variant = e ? atoi(e) : 2; if (g_head_fwd_variant < 0 || g_head_fwd_variant > 2) g_head_fwd_variant = 2; }
-    return g_head_fwd_variant;
-}
-static uint32_t head4_blocks_per_cu() {
-    static int v = 0;
-    if (v == 0) { const char* e = getenv("LAE_HEAD4_BLOCKS_PER_CU"); v = e ? atoi(e) : 1; if (v < 1 || v > 4) v = 1; }
+    if (v == 0) { const char* e = getenv("LAE_HEAD_BLOCKS_PER_CU"); v = e ? atoi(e) : 1; if (v < 1 || v > 4) v = 1; }
     return (uint32_t)v;
 }
 static int head5_waves() {
@@ -2133,7 +1625,7 @@ static int launch_head_fwd5_w(const half_t* enc, const float* dirs, const half_t
         attr_set = true;
     }
     const uint32_t n_groups = lae::cdiv(launch_tiles, 4);
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_groups, WAVES), (uint32_t)lae::num_cus() * head4_blocks_per_cu()));
+    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_groups, WAVES), (uint32_t)lae::num_cus() * head_blocks_per_cu()));
     k_nerf_head_fwd5<COLOR, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(enc, dirs, Ws, Wc, n_tiles, density_scale, h_out, sigmas, rgbs,
                                                                         level_major, n_rows_dev, lm_rows);
     return LAE_OK;
@@ -2148,43 +1640,29 @@ static int launch_head_fwd5(const half_t* enc, const float* dirs, const half_t* 
         default: return launch_head_fwd5_w<COLOR, 8>(enc, dirs, Ws, Wc, n_tiles, launch_tiles, density_scale, h_out, sigmas, rgbs, level_major, n_rows_dev, lm_rows, s);
     }
 }
-template <bool COLOR>
-static void launch_head_fwd4(const half_t* enc, const float* dirs, const half_t* Ws, const half_t* Wc, uint32_t n_tiles, uint32_t launch_tiles,
-                             float density_scale, half_t* h_out, float* sigmas, float* rgbs, int level_major,
-                             const uint32_t* n_rows_dev, uint32_t lm_rows, hipStream_t s) {
-    const uint32_t n_groups = lae::cdiv(launch_tiles, 4);
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_groups, 4), (uint32_t)lae::num_cus() * (COLOR ? head4_blocks_per_cu() : 2u)));
-    k_nerf_head_fwd4<COLOR><<<blocks, 256, 4 * sizeof(Head4Scratch), s>>>(enc, dirs, Ws, Wc, n_tiles, density_scale, h_out, sigmas, rgbs,
-                                                                         level_major, n_rows_dev, lm_rows);
+// k_nerf_head_fwd5 stages the weights with 16-byte loads and addresses rows through buffer descriptors with 32-bit byte
+// offsets (row * 64, lm_rows * 64, row * 12): both are preconditions of every entry point below
+static int head_args_ok(const void* ws, const void* wc, uint64_t rows, const char* who) {
+    if (((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(wc)) & 15) != 0) {
+        lae::set_last_error_str((std::string(who) + ": the weight pointers must be 16-byte aligned").c_str());
+        return LAE_EINVAL;
+    }
+    if (rows * 64ull > 0xffffffffull) {
+        lae::set_last_error_str((std::string(who) + ": more than 2^26 - 1 rows per call (32-bit row offsets); split the batch").c_str());
+        return LAE_EINVAL;
+    }
+    return LAE_OK;
 }
 
+// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], live rows = *n_rows_dev
 int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
                                  uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
                                  float* rgbs, hipStream_t stream) {
     if (M_launch == 0) return LAE_OK;
     if (M_cap % 16 != 0) return LAE_EINVAL;
-    const bool al16 = ((reinterpret_cast<uintptr_t>(sigma_weights) | reinterpret_cast<uintptr_t>(color_weights)) & 15) == 0;
-    if (head_fwd_variant() == 2 && al16)
-        return launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
-                                      lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
-    if (head_fwd_variant() == 1) {
-        launch_head_fwd4<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
-                               lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
-        return LAE_OK;
-    }
-    const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
-        attr_set = true;
-    }
-    const uint32_t n_tiles = M_cap / 16, launch_tiles = lae::cdiv(std::min(M_launch, M_cap), 16);
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(launch_tiles, 4), (uint32_t)lae::num_cus() * head_blocks_per_cu()));
-    k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, stream>>>((const half_t*)enc, dirs, (const half_t*)sigma_weights,
-                                                            (const half_t*)color_weights, n_tiles, density_scale, nullptr, sigmas,
-                                                            rgbs, 1, n_rows_dev, M_cap);
-    return LAE_OK;
+    if (const int rc = head_args_ok(sigma_weights, color_weights, M_cap, "nerf_head_forward_frame")) return rc;
+    return launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
+                                  lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
 }
 
 extern "C" {
@@ -2253,31 +1731,11 @@ int lae_nerf_head_forward(const void* enc, const float* dirs, const void* sigma_
     if (M == 0) return LAE_OK;
     if (!enc || !dirs || !sigma_weights || !color_weights || !h_out || !sigmas || !rgbs) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
-    const bool al16 = ((reinterpret_cast<uintptr_t>(sigma_weights) | reinterpret_cast<uintptr_t>(color_weights)) & 15) == 0;
-    if (head_fwd_variant() == 2 && al16) {
-        const int rc = launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M / 16, M / 16,
-                                              density_scale, (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M,
-                                              reinterpret_cast<hipStream_t>(stream));
-        return rc != LAE_OK ? rc : lae::check_launch("nerf_head_forward");
-    }
-    if (head_fwd_variant() == 1) {
-        launch_head_fwd4<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M / 16, M / 16,
-                               density_scale, (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
-        return lae::check_launch("nerf_head_forward");
-    }
-    const size_t lds_bytes = (size_t)HeadCfg::LDS_HALVES * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_head_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
-        attr_set = true;
-    }
-    const uint32_t n_tiles = M / 16;
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * head_blocks_per_cu()));
-    k_nerf_head_fwd<true><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, n_tiles, density_scale,
-        (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M);
-    return lae::check_launch("nerf_head_forward");
+    if (const int rc = head_args_ok(sigma_weights, color_weights, M, "nerf_head_forward")) return rc;
+    const int rc = launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M / 16, M / 16,
+                                          density_scale, (half_t*)h_out, sigmas, rgbs, enc_level_major, nullptr, M,
+                                          reinterpret_cast<hipStream_t>(stream));
+    return rc != LAE_OK ? rc : lae::check_launch("nerf_head_forward");
 }
 
 int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_t M, float density_scale, void* h_out,
@@ -2285,23 +1743,10 @@ int lae_nerf_density_forward(const void* enc, const void* sigma_weights, uint32_
     if (M == 0) return LAE_OK;
     if (!enc || !sigma_weights || !sigmas) return LAE_ENULL;
     if (M % 16 != 0) return LAE_EINVAL;
-    if (head_fwd_variant() == 2 && (reinterpret_cast<uintptr_t>(sigma_weights) & 15) == 0) {
-        const int rc = launch_head_fwd5<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
-                                               (half_t*)h_out, sigmas, nullptr, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
-        return rc != LAE_OK ? rc : lae::check_launch("nerf_density_forward");
-    }
-    if (head_fwd_variant() == 1) {
-        launch_head_fwd4<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
-                                (half_t*)h_out, sigmas, nullptr, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
-        return lae::check_launch("nerf_density_forward");
-    }
-    const size_t lds_bytes = (size_t)HeadCfg::S_END * 2;                 // sigma-net image only (< 64 KiB)
-    const uint32_t n_tiles = M / 16;
-    const uint32_t blocks = std::max(1u, std::min(lae::cdiv(n_tiles, 4), (uint32_t)lae::num_cus() * 4));
-    k_nerf_head_fwd<false><<<blocks, 256, lds_bytes, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, n_tiles, density_scale, (half_t*)h_out, sigmas, nullptr,
-        enc_level_major, nullptr, M);
-    return lae::check_launch("nerf_density_forward");
+    if (const int rc = head_args_ok(sigma_weights, sigma_weights, M, "nerf_density_forward")) return rc;
+    const int rc = launch_head_fwd5<false>((const half_t*)enc, nullptr, (const half_t*)sigma_weights, nullptr, M / 16, M / 16, density_scale,
+                                           (half_t*)h_out, sigmas, nullptr, enc_level_major, nullptr, M, reinterpret_cast<hipStream_t>(stream));
+    return rc != LAE_OK ? rc : lae::check_launch("nerf_density_forward");
 }
 
 int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, const void* enc, const float* dirs, const void* h,
@@ -2350,11 +1795,11 @@ int lae_nerf_head_backward(const float* grad_sigmas, const float* grad_rgbs, con
 }
 
 int lae_ffmlp_set_mode(int mode) {
-    if (mode >= 16 && mode <= 18) { g_head_fwd_variant = mode - 16; return LAE_OK; }      // fused head forward: round-2 kernel / round-3 forms
-    if (mode >= 32 && mode <= 35) { g_bwd_fused_variant = mode - 32; return LAE_OK; }      // fused backward: 32 coop, 33 wave-private + LDS transposes, 34 wave-private + MFMA transposes
-    if (mode < 0 || mode > 3) return LAE_EINVAL;
-    g_ffmlp_mode = mode == 1 ? 1 : 0;                       // 1: buffer-faithful three-kernel backward
-    g_bwd_fused_variant = mode == 2 ? 1 : mode == 3 ? 0 : 2; // 0: wave-private dW + MFMA transposes (default); 2: wave-private dW + LDS transposes; 3: cooperative dW
+    // 0: default (fused backward, wave-private dW with MFMA transposes); 1: buffer-faithful three-kernel backward (the reference's
+    // forward / backward buffers); 3: fused backward with the round-2 workgroup-cooperative dW kernel (the one A/B predecessor)
+    if (mode != 0 && mode != 1 && mode != 3) return LAE_EINVAL;
+    g_ffmlp_mode = mode == 1 ? 1 : 0;
+    g_bwd_fused_variant = mode == 3 ? 0 : 2;
     return LAE_OK;
 }
 

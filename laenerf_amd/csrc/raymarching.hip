@@ -1109,6 +1109,7 @@ __device__ int g_look_phase = 20;
 #endif
 constexpr uint32_t FRAME_LANE_VISITS = 8;      // visits a lane walks alone before the wave decides how to continue
 constexpr int FRAME_QUEUE_MAX = 16;            // the bound when the stragglers go to the finishing kernel (8 / 16 / 24 / 32 / 48: 12.07 / 11.86 / 11.88 / 11.98 / 12.14 ms per frame)
+constexpr int FRAME_MAX_ROUNDS = 1 << 30;      // lane rounds after which ALL unfinished lanes of a wave go to the finishing kernel: never (2: 800x800 11.9 -> 15.1 ms, 1080p 71 -> 92 ms)
 constexpr int FRAME_SPEC = 4;                  // visits of a walk through empty space laid out (and probed) together
 struct LookTask { uint32_t index, step; float t; };   // a ray the lane phase hands to k_frame_lookahead_finish
 constexpr uint32_t FRAME_FINISH_BLOCKS = 1024; // x 4 waves: more than one wave per SIMD, tasks dealt round-robin
@@ -1120,40 +1121,50 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     float* __restrict__ la_tend,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
-    uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max) {
-    const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
+    uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds) {
     const uint32_t n = blockIdx.x * FRAME_BLOCK + threadIdx.x;
-    bool has_ray = n < n_alive;
     const int lane = threadIdx.x & 63;
     LOOK_NOTE(0, wall_clock64());
-    [[maybe_unused]] uint32_t st_rounds = 0, st_coop = 0, st_passes = 0;
-    uint32_t index = 0;
+    // Two dependent round trips before the walk instead of four (beside the encoder a wave's state loads were 5.4 of its
+    // 7.9 us, stamps of round 4): alive[n] is requested together with the loop state -- the list has N slots whatever
+    // n_alive turns out to be -- and everything the ray's index addresses (count, ray, far, t, record) together, before
+    // the count decides whether the ray goes on.
+    uint32_t index = (phase >= 0 && n < N) ? (uint32_t)alive[n] : n;
+    const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
+    bool has_ray = n < n_alive;
+    if (__ballot(has_ray) == 0ull) return;
+    if (!has_ray) index = 0;                               // slots past n_alive hold stale entries
+    uint32_t st_rounds = 0;
+    [[maybe_unused]] uint32_t st_coop = 0, st_passes = 0;
     Ray r{};
-    float t = 0.f, far = 0.f;
+    float t = 0.f, far = 0.f, tend0 = 0.f;
     uint32_t cnt0 = 0;
-    if (has_ray) {
-        index = phase < 0 ? n : (uint32_t)alive[n];
-        if (phase >= 0) { cnt0 = la_cnt[index]; if (cnt0 < n_consumed) has_ray = false; }   // the ray ends in this iteration
-    }
-    if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
     float* out_t = la_t + (size_t)index * FRAME_LA;
     uint8_t* out_e = EDIT ? la_e + (size_t)index * FRAME_LA : nullptr;
-    uint32_t step = 0;
+    // the ray's record travels as two 16-byte loads (and, if part of it is kept, two stores): a load per consumed sample
+    // and a load + store per kept one, each waited for in turn inside its loop, were a dozen dependent round trips
+    // through a memory system the encoder kernel next door keeps saturated -- the kernel's 110-150 us
+    static_assert(FRAME_LA == 8, "the record is handled as 2 x float4 / one 64-bit word");
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    unsigned long long rece = 0ull;
     if (has_ray) {
         r = load_ray(rays_o, rays_d, index);
         far = fars[index];
         t = tc[index];
+        if (phase >= 0) {
+            cnt0 = la_cnt[index];
+            ra = reinterpret_cast<const float4*>(out_t)[0]; rb = reinterpret_cast<const float4*>(out_t)[1];
+            if (EDIT) rece = *reinterpret_cast<const unsigned long long*>(out_e);
+            tend0 = la_tend[index];
+        }
+    }
+    if (phase >= 0 && cnt0 < n_consumed) has_ray = false;  // the ray ends in this iteration
+    if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
+    uint32_t step = 0;
+    if (has_ray) {
         if (phase < 0) t = perturbed_start(cfg, t, noises, n);
         else {
-            // the ray's record travels as two 16-byte loads (and, if part of it is kept, two stores): a load per consumed
-            // sample and a load + store per kept one, each waited for in turn inside its loop, were a dozen dependent round
-            // trips through a memory system the encoder kernel next door keeps saturated -- the kernel's 110-150 us
-            static_assert(FRAME_LA == 8, "the record is handled as 2 x float4 / one 64-bit word");
-            const float4 ra = reinterpret_cast<const float4*>(out_t)[0], rb = reinterpret_cast<const float4*>(out_t)[1];
             float rec[FRAME_LA] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-            unsigned long long rece = 0ull;
-            if (EDIT) rece = *reinterpret_cast<const unsigned long long*>(out_e);
-            const float tend0 = la_tend[index];
             float last = phase == 0 ? perturbed_start(cfg, t, noises, n) : t;   // iteration 0 lists rays in identity order
 #pragma unroll
             for (uint32_t j = 0; j < FRAME_LA; j++) {
@@ -1249,7 +1260,12 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         const bool unfinished = has_ray && t < far && step < max_n_step;
         unsigned long long um = __ballot(unfinished);
         if (um == 0ull) break;
-        if (__builtin_popcountll(um) > coop_max) continue;   // most of the wave is in transit: lanes are well used
+        // most of the wave is in transit: lanes are well used.  (A wave whose 64 neighbouring rays all leave a surface
+        // together walks on for 16-25 rounds, 130-200 us, while the median wave is done after 11 us -- but handing such
+        // waves to the finishing kernel after max_rounds rounds costs more than it saves: one wave per ray there is ~7x
+        // the work of a lane here.  Round 4, LAE_FRAME_MAX_ROUNDS = 1 / 2 / 3: 15.3 / 15.1 / 14.5 ms per 800x800 frame
+        // against 11.9, 92 against 71 ms at 1080p.)
+        if (__builtin_popcountll(um) > coop_max && !(q_tasks && st_rounds >= (uint32_t)max_rounds)) continue;
         LOOK_NOTE(2, wall_clock64());
         if (q_tasks) {
             // few stragglers: hand them to k_frame_lookahead_finish (one wave per ray, every SIMD of the chip) instead of
@@ -1863,6 +1879,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     static const int spec_visits = [] { const char* e = getenv("LAE_FRAME_SPEC"); return e ? atoi(e) : 1; }();   // 0: every visit waits for its own probe (A/B)
     static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
     const int coop_max = coop_max_env >= 0 ? coop_max_env : (finish_queue ? FRAME_QUEUE_MAX : FRAME_COOP_MAX);
+    static const int max_rounds = [] { const char* e = getenv("LAE_FRAME_MAX_ROUNDS"); return e ? atoi(e) : FRAME_MAX_ROUNDS; }();
     uint32_t look_no = 0;
 
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
@@ -1876,12 +1893,12 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, la_tend, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max);
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max, max_rounds);
             if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, la_e, la_cnt, la_tend, rays_o,
                                                                                         rays_d, fars, cfg, grid, edit_grid);
         } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, la_tend, rays_o, rays_d,
-                                                                  fars, cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max);
+                                                                  fars, cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds);
             if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, nullptr, la_cnt, la_tend, rays_o,
                                                                                          rays_d, fars, cfg, grid, nullptr);
         }

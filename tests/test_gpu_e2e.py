@@ -6,6 +6,7 @@ import torch
 
 from conftest import golden
 from gpu_util import DEV, N, T
+from laenerf_amd.field import _nerf_field
 
 pytestmark = pytest.mark.gpu
 
@@ -19,13 +20,9 @@ def build(g):
     net.encoder.embeddings.data = T(g["table"])
     net.sigma_net.weights.data = T(g["sigma_w"])
     net.color_net.weights.data = T(g["color_w"])
-    # the golden run had no autocast on CPU: table in fp32, MLPs in fp16 -> keep the encoder out of autocast
-    enc_fwd = net.encoder.forward
-
-    def fp32_encoder(x, bound=1):
-        with torch.autocast("cuda", enabled=False):
-            return enc_fwd(x.float(), bound=bound)
-    net.encoder.forward = fp32_encoder
+    # the goldens ran the fp16-table path (make_golden.py::half_table_path) = what the fused field op computes; nothing is
+    # patched here, and every test below asserts that the fused op (field._nerf_field) is what rendered
+    assert net.fused_field
     r = NeRFRenderer(net, bound=bound, min_near=0.2).to(DEV)
     r.density_bitfield = T(g["bitfield"])
     return net, r
@@ -41,9 +38,11 @@ def test_train_render_and_gradients(tag):
     net, r = build(g)
     o, d = T(g["rays_o"]), T(g["rays_d"])
     net.train()
+    calls0 = _nerf_field.calls
     with torch.autocast("cuda", dtype=torch.float16):
         res = r.render_train(o, d, bg_color=1, perturb=False, max_steps=256)
         loss = ((res["image"] - T(g["target"])) ** 2).mean()
+    assert _nerf_field.calls == calls0 + 1                                     # the fused field op rendered, not the operator chain
     assert np.array_equal(N(r.step_counter[0]), g["train_counter"])            # sample count / ray count: exact
     # north_star tolerance: 1e-4 RGB at the golden run's settings (fp32 table, fp16 MLP weights)
     assert np.abs(N(res["image"]) - g["train_image"]).max() < 1e-4
@@ -85,8 +84,14 @@ def test_eval_and_distill_render(tag):
     o, d = T(g["rays_o"]), T(g["rays_d"])
     net.eval()
     with torch.autocast("cuda", dtype=torch.float16):
-        for dc in (True, False):                                        # device-side compaction == host boolean mask
-            ev = r.render_eval(o, d, bg_color=1, max_steps=256, device_compaction=dc)
+        for dc in (True, False, None):                                  # device-side compaction == host boolean mask == frame loop
+            calls0 = _nerf_field.calls
+            if dc is None:                                              # lae_render_frame: one backend call, no autograd op at all
+                ev = r.render_eval(o, d, bg_color=1, max_steps=256, want_stats=True)
+                assert _nerf_field.calls == calls0 and ev["stats"]["iterations"] > 0
+            else:
+                ev = r.render_eval(o, d, bg_color=1, max_steps=256, device_compaction=dc, frame_loop=False)
+                assert _nerf_field.calls > calls0                       # every iteration of the operator loop used the fused field op
             assert np.abs(N(ev["image"]) - g["eval_image"]).max() < 1e-4
             hit = g["train_ws"] > 0
             assert np.abs(N(ev["depth"])[hit] - g["eval_depth"][hit]).max() < TOL["depth"]

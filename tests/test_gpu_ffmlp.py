@@ -40,7 +40,7 @@ def test_ffmlp_forward_backward(O, IN, H, NL, B):
     # mode 1: the buffer-faithful path (fills backward_buffer like the reference); mode 0: fused path where available
     # (recomputes the activations, needs neither buffer)
     try:
-        for mode in (1, 0, 2, 3):
+        for mode in (1, 0, 3):
             F.ffmlp_set_mode(mode)
             fused = mode != 1 and F.fused_backward_available(IN, H, NL, 0)
             gi.zero_(); gw.zero_()
@@ -152,11 +152,11 @@ def test_nerf_head_matches_operator_chain_and_oracle(O, M):
 @pytest.mark.parametrize("M", [16, 48, 4096 + 16, 64 * 1031])
 @pytest.mark.parametrize("level_major", [False, True])
 def test_nerf_head_kernel_variants_agree(M, level_major):
-    """the fused head's forward kernels (round-2 one-tile-per-wave kernel / 64 rows per wave with the fragments in registers /
-    the same from the swizzled LDS image = default) and backward kernels (cooperative dW / wave-private dW with LDS transposes /
-    wave-private dW with MFMA transposes = default) on the same inputs: forward outputs the same bits up to the rounding of the
-    sigmoid (<= one fp16 ulp on rare elements), input gradients the same bits, weight gradients equal to fp32 summation order.
-    Row counts with an odd number of 16-row tiles, fewer rows than one 64-row group, and more groups than waves."""
+    """the fused head on row counts with an odd number of 16-row tiles, fewer rows than one 64-row group, and more groups than
+    waves.  Forward: a row's outputs do not depend on how many other rows share the launch (the first rows evaluated alone give
+    the same bits) -- the operator-chain / fixture comparison is test_nerf_head_matches_operator_chain.  Backward: the two
+    kernels that ship (wave-private dW with MFMA transposes = default / workgroup-cooperative dW, round 2) give the same input
+    gradients bit for bit and weight gradients equal up to fp32 summation order."""
     from laenerf_amd.backend import ffmlp_backend as F
     g = torch.Generator(device=DEV).manual_seed(M)
     enc = ((torch.randn(16, M, 2, device=DEV, generator=g) if level_major else torch.randn(M, 32, device=DEV, generator=g)) * 0.5).half()
@@ -165,20 +165,21 @@ def test_nerf_head_kernel_variants_agree(M, level_major):
     wc = ((torch.rand(64 * (32 + 128 + 16), device=DEV, generator=g) * 2 - 1) * 0.2165).half()
     gs = torch.randn(M, device=DEV, generator=g) * 1e-2
     gr = torch.randn(M, 3, device=DEV, generator=g) * 1e-2
+
+    def fwd(enc_, dirs_, m):
+        h = torch.full((m, 16), float("nan"), dtype=torch.half, device=DEV)
+        sig = torch.full((m,), float("nan"), device=DEV); rgb = torch.full((m, 3), float("nan"), device=DEV)
+        F.nerf_head_forward(enc_, dirs_, ws, wc, m, 1.0, h, sig, rgb, level_major=level_major)
+        return h, sig, rgb
+    h, sig, rgb = fwd(enc, dirs, M)
+    assert torch.isfinite(h.float()).all() and torch.isfinite(sig).all() and torch.isfinite(rgb).all()
+    m = min(M, 32)
+    sub = enc[:, :m].contiguous() if level_major else enc[:m].contiguous()
+    h2, sig2, rgb2 = fwd(sub, dirs[:m].contiguous(), m)
+    assert torch.equal(h2, h[:m]) and torch.equal(sig2, sig[:m]) and torch.equal(rgb2, rgb[:m])
     try:
-        outs = []
-        for mode in (16, 17, 18):
-            F.ffmlp_set_mode(mode)
-            h = torch.full((M, 16), float("nan"), dtype=torch.half, device=DEV)
-            sig = torch.full((M,), float("nan"), device=DEV); rgb = torch.full((M, 3), float("nan"), device=DEV)
-            F.nerf_head_forward(enc, dirs, ws, wc, M, 1.0, h, sig, rgb, level_major=level_major)
-            outs.append((h, sig, rgb))
-        for h, sig, rgb in outs[1:]:
-            assert torch.equal(h, outs[0][0]) and torch.equal(sig, outs[0][1])
-            assert float((rgb - outs[0][2]).abs().max()) <= 4.9e-4 and float((rgb != outs[0][2]).float().mean()) < 1e-3
-        h, sig, rgb = outs[2]
         grads = []
-        for mode in (3, 2, 0):
+        for mode in (3, 0):
             F.ffmlp_set_mode(mode)
             gh = torch.full((M, 16), float("nan"), dtype=torch.half, device=DEV)
             genc = torch.full(enc.shape, float("nan"), dtype=torch.half, device=DEV)
@@ -190,7 +191,7 @@ def test_nerf_head_kernel_variants_agree(M, level_major):
             for a, b in ((gws, grads[0][2]), (gwc, grads[0][3])):
                 assert float((a.float() - b.float()).abs().max()) <= 2e-3 * float(b.float().abs().max()) + 1e-7
     finally:
-        F.ffmlp_set_mode(18); F.ffmlp_set_mode(0)
+        F.ffmlp_set_mode(0)
 
 
 def test_nerf_head_rejects_bad_shapes():

@@ -1,5 +1,6 @@
 """where the waves of ONE k_frame_lookahead launch spend their time (needs -DLAE_FRAME_STAMPS, see tools/grid_bwd_stamps.py):
-    LAE_BUILD_EXTRA_FLAGS=-DLAE_FRAME_STAMPS python -m laenerf_amd.build --force; gpurun -- python tools/frame_look_stamps.py [iteration]"""
+    LAE_BUILD_EXTRA_FLAGS=-DLAE_FRAME_STAMPS python -m laenerf_amd.build --force; gpurun -- python tools/frame_look_stamps.py [iteration ...]
+LAE_STAMPS_SCENE=whole|shard: the configs[3]-shaped 1080p frame / rank 0's shard of 8 instead of the 800x800 lego-shaped frame"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
@@ -7,12 +8,25 @@ from laenerf_amd import _lib, synthetic as S
 from laenerf_amd.network import NeRFNetwork
 from laenerf_amd.renderer import NeRFRenderer
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
-net = NeRFNetwork(bound=1).to(dev).eval()
-r = NeRFRenderer(net, bound=1).to(dev).eval()
-r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-o, d = S.frame_rays(800, 800)
-o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+scene = os.environ.get("LAE_STAMPS_SCENE", "800")
+budget = 0
+if scene == "800":
+    torch.manual_seed(0)
+    net = NeRFNetwork(bound=1).to(dev).eval()
+    r = NeRFRenderer(net, bound=1).to(dev).eval()
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    o, d = S.frame_rays(800, 800)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+else:
+    import bench
+    from laenerf_amd.dist import shard_indices_device
+    net, r = bench.eval_model(dev, bound=2, seed=1234)
+    o, d = S.frame_rays(1080, 1920, focal=1111.1 * 1080 / 800, radius=1.6)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    if scene == "shard":
+        idx = shard_indices_device(o.shape[0], 0, 8, dev)
+        o, d = o[idx].contiguous(), d[idx].contiguous()
+        budget = 1080 * 1920
 lib = _lib.load()
 fn = lib.lae_debug_look_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]; fn.restype = ctypes.c_int
@@ -20,7 +34,7 @@ for phase in ([int(a) for a in sys.argv[1:]] or [5, 30, 60]):
     assert fn(None, 0, phase) == 0
     for _ in range(2):
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            r.render_eval(o, d, bg_color=1, max_steps=1024)
+            r.render_eval(o, d, bg_color=1, max_steps=1024, row_budget=budget)
     torch.cuda.synchronize()
     buf = np.zeros((16384, 8), dtype=np.uint64)
     assert fn(buf.ctypes.data, buf.nbytes, -1) == 0

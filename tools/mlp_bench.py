@@ -57,7 +57,7 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-fwd_modes = [int(x) for x in os.environ.get("MLP_BENCH_FWD", "16,17,18").split(",") if x]
+fwd_modes = [0]                     # one forward kernel ships (round 4 removed modes 16-18)
 bwd_modes = [int(x) for x in os.environ.get("MLP_BENCH_BWD", "3,0").split(",") if x]
 ref = None
 for mode in fwd_modes:
