@@ -75,10 +75,10 @@ extern "C" {
 
 /* library identification: returns the static string "laenerf-hip gfx950 " LAE_ABI_TAG.  The tag changes whenever a
  * signature of this header changes incompatibly (abi2: round 2 added pointer arguments in the middle of the optimizer /
- * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step).  A binding compares
+ * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step; abi4: round 4, lae_ffmlp_set_mode values 2 and 16-18 removed).  A binding compares
  * it with the tag it was written against BEFORE the first call: a stale .so used through newer prototypes would misalign
  * arguments silently (laenerf_amd/_lib.py does, and rebuilds or raises). */
-#define LAE_ABI_TAG "abi3"
+#define LAE_ABI_TAG "abi4"
 LAE_API const char* lae_version(void);
 /* last HIP error string recorded by a failed launch in this thread (or "") */
 LAE_API const char* lae_last_error(void);

@@ -107,7 +107,7 @@ _RESTYPES = {
 }
 
 _lib = None
-ABI_TAG = b"abi3"            # include/laenerf.h LAE_ABI_TAG: the prototypes in SIGNATURES are written against this tag
+ABI_TAG = b"abi4"            # include/laenerf.h LAE_ABI_TAG: the prototypes in SIGNATURES are written against this tag
 
 
 def _abi_of(path):

@@ -1463,6 +1463,206 @@ __global__ __launch_bounds__(64 * WAVES) void k_nerf_head_fwd5(
     MLP_STAMP(blockIdx.x * WAVES + w, 15);
 }
 
+// ---------------------------------------------------------------- frame loop: head + composite_rays in one launch
+// k_nerf_head_fwd5<true> followed, inside the wave, by composite_rays / composite_rays_distill (raymarching.cu:948-1035 /
+// :1037-1142) for the rays whose rows the wave just shaded.  Rows are ray-major in 64-row groups of whole rays
+// (lae_common.h FrameCtrl), lane L of a wave does the per-row work of row L of its group, so the sigma / rgb of a ray's
+// n_step rows sit in n_step consecutive lanes: they go through the wave's LDS scratch to the lane of the ray's first row,
+// which runs the reference's serial loop (same operations in the same order: the image is the same bits as the two-kernel
+// form's) on the ray's 32-byte accumulator record.  sigmas / rgbs never reach memory (16 B written + 16 B read per row) and
+// the compositing launch with its 40-56 B per ray of scattered accumulator traffic is gone: 9 / 29 us per iteration of the
+// 800x800 / 1080p frame (profiles/r4_*).
+// Work is dealt in CONTIGUOUS runs of groups, one run per wave (unit u = blockIdx.x * WAVES + wave), and a wave appends the
+// rays that go on to its own survivor segment [u * R, ...) + count (+ the workgroup's sum of counts): the next iteration's
+// per-ray kernels walk the segments in unit order (raymarching.hip frame_locate), so the alive list keeps its order -- stable
+// compaction, no atomics, the same list every run.  (Compacting inside this launch -- every workgroup publishing its count
+// and waiting for the counts of the workgroups before it -- was built and measured in round 4: 12.65 against 12.26 ms per
+// 800x800 frame, and two processes sharing one GPU crawl when spinning workgroups keep each other's predecessors out.)
+struct FrameHeadScratch { float dl[64][2]; uint32_t eo[64]; };         // per wave, behind its Head4Scratch
+
+template <bool EDIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_frame_head(
+    const half_t* __restrict__ enc, const float* __restrict__ dirs, const half_t* __restrict__ Ws, const half_t* __restrict__ Wc,
+    float density_scale, uint32_t lm_rows, lae::FrameHeadArgs fa) {
+    constexpr int NT = 4, NTH = 64 * WAVES;
+    using I = Head5Img;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t unit = blockIdx.x * WAVES + (uint32_t)w, n_units = gridDim.x * WAVES;
+    const lae::FrameCtrl ctl = *fa.cur;
+    const uint32_t n_alive = ctl.n_alive, n_step = max(ctl.n_step, 1u);
+    const uint32_t rpg = lae::frame_rays_per_group(n_step);
+    const uint32_t n_groups = (n_alive + rpg - 1) / rpg;
+    const uint32_t per_unit = (n_groups + n_units - 1) / n_units;
+    // the block's first unit decides whether the block has any work (units are dealt in order)
+    if (min(n_groups, blockIdx.x * WAVES * per_unit) >= n_groups) {
+        if (lane == 0) fa.seg_counts_next[unit] = 0u;
+        if (threadIdx.x == 0) fa.blk_counts_next[blockIdx.x] = 0u;
+        return;
+    }
+    __shared__ uint32_t wave_kept[WAVES];
+    uint32_t kept = 0;                                                   // survivors this wave has appended (uniform)
+    int32_t* seg = fa.seg_next + (size_t)unit * fa.R;
+    const uint32_t g_lo = min(n_groups, unit * per_unit), g_hi = min(n_groups, g_lo + per_unit);
+    extern __shared__ __attribute__((aligned(16))) half_t lds[];
+    half_t* img = lds;
+    Head4Scratch* sc = reinterpret_cast<Head4Scratch*>(lds + I::END) + w;
+    FrameHeadScratch* fs = reinterpret_cast<FrameHeadScratch*>(reinterpret_cast<Head4Scratch*>(lds + I::END) + WAVES) + w;
+    {   // weights -> swizzled LDS image (k_nerf_head_fwd5)
+        constexpr int N1 = (4 * 1 * 64 + NTH - 1) / NTH, N2 = (4 * 2 * 64 + NTH - 1) / NTH, NO = (1 * 2 * 64 + NTH - 1) / NTH;
+        uint4 b0[N1], b1[N2], b2[NO], c0[N1], c1[N2], c2[N2], c3[NO];
+        stage_swizzled_issue<4, 1, NTH>(Ws, b0);
+        stage_swizzled_issue<4, 2, NTH>(Ws + 64 * 32, b1);
+        stage_swizzled_issue<1, 2, NTH>(Ws + 64 * 32 + 4096, b2);
+        stage_swizzled_issue<4, 1, NTH>(Wc, c0);
+        stage_swizzled_issue<4, 2, NTH>(Wc + 64 * 32, c1);
+        stage_swizzled_issue<4, 2, NTH>(Wc + 64 * 32 + 4096, c2);
+        stage_swizzled_issue<1, 2, NTH>(Wc + 64 * 32 + 8192, c3);
+        stage_swizzled_store<4, 1, NTH>(img + I::C0, c0);
+        stage_swizzled_store<4, 2, NTH>(img + I::C1, c1);
+        stage_swizzled_store<4, 2, NTH>(img + I::C2, c2);
+        stage_swizzled_store<1, 2, NTH>(img + I::CO, c3);
+        stage_swizzled_store<4, 1, NTH>(img + I::S0, b0);
+        stage_swizzled_store<4, 2, NTH>(img + I::S1, b1);
+        stage_swizzled_store<1, 2, NTH>(img + I::SO, b2);
+    }
+    const uint32_t n_rows = (ctl.n_rows + 15u) & ~15u;                 // rows the emit kernel wrote (pad rows of the last tile are zeros)
+    const __amdgpu_buffer_rsrc_t rs_enc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(enc), 0, (int)(lm_rows * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dir = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dirs), 0, (int)(n_rows * 12u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fa.deltas), 0, (int)(n_rows * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_eo = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(EDIT ? fa.edit_occ : reinterpret_cast<const uint8_t*>(fa.deltas)), 0, (int)n_rows, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_alive = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(fa.alive), 0, (int)(n_alive * 4u), 0x00020000);
+    const uint32_t plane = lm_rows * 4u;
+    // the lane of a ray's first row owns the ray
+    const uint32_t slot = (uint32_t)lane / n_step;
+    const bool own = slot * n_step == (uint32_t)lane && slot < rpg;
+    h4 xf_n[NT][2] = {};
+    float d_n[3] = {0.f, 0.f, 0.f}, dl_n[2] = {0.f, 0.f};
+    uint32_t eo_n = 0, idx_n = 0;
+    auto request = [&](uint32_t grp) {
+        const uint32_t row0 = grp * 64u;
+        const uint32_t vo = ((uint32_t)(2 * g) * lm_rows + row0 + (uint32_t)c) * 4u;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                const uint32_t lo = __builtin_amdgcn_raw_buffer_load_b32(rs_enc, (int)(vo + t * 64u), (int)((8u * kt) * plane), 0);
+                const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rs_enc, (int)(vo + t * 64u), (int)((8u * kt + 1u) * plane), 0);
+                xf_n[t][kt] = __builtin_bit_cast(h4, uint2{lo, hi});
+            }
+        const uint32_t r = row0 + (uint32_t)lane;
+#pragma unroll
+        for (int k = 0; k < 3; k++) d_n[k] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_dir, (int)(r * 12u + 4u * k), 0, 0));
+#pragma unroll
+        for (int k = 0; k < 2; k++) dl_n[k] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_dl, (int)(r * 8u + 4u * k), 0, 0));
+        if (EDIT) eo_n = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs_eo, (int)r, 0, 0);
+        idx_n = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_alive, (int)((grp * rpg + slot) * 4u), 0, 0);   // 0 past the list
+    };
+    if (g_lo < g_hi) request(g_lo);
+    __syncthreads();                                                     // the image is complete
+    for (uint32_t grp = g_lo; grp < g_hi; grp++) {
+        h4 xf[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) { xf[t][0] = xf_n[t][0]; xf[t][1] = xf_n[t][1]; }
+        const float dx = d_n[0], dy = d_n[1], dz = d_n[2], d0 = dl_n[0], d1 = dl_n[1];
+        const uint32_t eo = eo_n, idx = idx_n;
+        if (grp + 1 < g_hi) request(grp + 1);
+        const bool valid = own && grp * rpg + slot < n_alive;
+        // the ray's accumulators: requested now, needed after the two networks
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        lae::RayAcc* ap = fa.acc + idx;
+        if (valid) { a0 = reinterpret_cast<const float4*>(ap)[0]; a1 = reinterpret_cast<const float4*>(ap)[1]; }
+        {
+            float o[16], gx[1], gy[1], gz[1];
+            sh_eval<4, false>(dx, dy, dz, o, gx, gy, gz);
+            h8 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { lo[j] = (half_t)o[j]; hi[j] = (half_t)o[8 + j]; }
+            *reinterpret_cast<h8*>(&sc->sh[lane][0]) = lo;
+            *reinterpret_cast<h8*>(&sc->sh[lane][8]) = hi;
+        }
+        h4 a0h[NT][4], a1h[NT][4];
+        layer64s<1, NT>(img + I::S0, lane, xf, a0h);
+        layer64s<2, NT>(img + I::S1, lane, a0h, a1h);
+        f4 so[NT];
+        out16s<NT>(img + I::SO, lane, a1h, so);
+        h4 hq[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) hq[t][r] = (half_t)so[t][r];
+            if (g == 0) sc->q[t * 16 + c][0] = (float)hq[t][0];
+        }
+        wave_lds_fence();
+        const float sig = density_scale * expf(sc->q[lane][0]);          // trunc_exp forward (activation.py:9), renderer.py:370
+        h4 cin[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            cin[t][0] = *reinterpret_cast<const h4*>(&sc->sh[t * 16 + c][4 * g]);
+            const half_t nxt = __builtin_bit_cast(half_t, (uint16_t)__shfl_down((int)__builtin_bit_cast(uint16_t, hq[t][0]), 16, 64));
+            cin[t][1][0] = hq[t][1]; cin[t][1][1] = hq[t][2]; cin[t][1][2] = hq[t][3];
+            cin[t][1][3] = g == 3 ? (half_t)0.0f : nxt;
+        }
+        layer64s<1, NT>(img + I::C0, lane, cin, a0h);
+        layer64s<2, NT>(img + I::C1, lane, a0h, a1h);
+        layer64s<2, NT>(img + I::C2, lane, a1h, a0h);
+        f4 co[NT];
+        out16s<NT>(img + I::CO, lane, a0h, co);
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (g == 0) *reinterpret_cast<f4*>(&sc->q[t * 16 + c][0]) = co[t];
+        wave_lds_fence();
+        {
+            const f4 v = *reinterpret_cast<const f4*>(&sc->q[lane][0]);
+            const float cr = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[0])));
+            const float cg = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[1])));
+            const float cb = (float)(half_t)(1.0f / (1.0f + expf(-(float)(half_t)v[2])));
+            wave_lds_fence();                                            // every lane has read its logits
+            *reinterpret_cast<f4*>(&sc->q[lane][0]) = f4{sig, cr, cg, cb};
+            fs->dl[lane][0] = d0; fs->dl[lane][1] = d1;
+            if (EDIT) fs->eo[lane] = eo;
+        }
+        wave_lds_fence();
+        // ---- composite_rays of the group's rays (raymarching.cu:948-1035; k_frame_composite of round 1-3, same statements)
+        bool keep = false;
+        if (valid) {
+            float ws = a0.x, d = a0.y, r = a0.z, gc = a0.w, b = a1.x, t = a1.y, wse = a1.z, de = a1.w;
+            uint32_t step = 0;
+            while (step < n_step) {
+                const float e0 = fs->dl[lane + step][0];
+                if (e0 == 0) break;
+                const f4 v = *reinterpret_cast<const f4*>(&sc->q[lane + step][0]);
+                const float alpha = 1.0f - __expf(-v[0] * e0);
+                const float T = 1 - ws;
+                const float wgt = alpha * T;
+                ws += wgt;
+                if (EDIT) { if (fs->eo[lane + step]) { wse += wgt; de = fmaf(wgt, t, de); } }
+                t += fs->dl[lane + step][1];
+                d = fmaf(wgt, t, d);
+                r = fmaf(wgt, v[1], r); gc = fmaf(wgt, v[2], gc); b = fmaf(wgt, v[3], b);
+                if (T < fa.T_thresh) break;
+                step++;
+            }
+            keep = step == n_step;
+            reinterpret_cast<float4*>(ap)[0] = make_float4(ws, d, r, gc);
+            reinterpret_cast<float4*>(ap)[1] = make_float4(b, keep ? t : a1.y, wse, de);      // rays_t moves only for rays that go on
+        }
+        const unsigned long long km = __ballot(keep);
+        if (keep) seg[kept + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = (int32_t)idx;
+        kept += (uint32_t)__builtin_popcountll(km);
+        wave_lds_fence();                                                // scratch is rewritten by the next group
+    }
+    if (lane == 0) { fa.seg_counts_next[unit] = kept; wave_kept[w] = kept; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) tot += wave_kept[i];
+        fa.blk_counts_next[blockIdx.x] = tot;
+    }
+}
+
 // FFMLP forward for the common shape (64 wide, ReLU, linear output, 32 / 48 / 64 inputs, 1 or 2 hidden GEMMs) with the
 // weights staged in LDS once per workgroup, like k_nerf_head_fwd: the generic k_mlp_fwd re-reads every weight fragment
 // from global memory for every 32-row group (41 us per 100 k rows for the LAENeRF nets against ~10 us here).
@@ -1654,15 +1854,31 @@ static int head_args_ok(const void* ws, const void* wc, uint64_t rows, const cha
     return LAE_OK;
 }
 
-// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], live rows = *n_rows_dev
-int lae::nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
-                                 uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
-                                 float* rgbs, hipStream_t stream) {
-    if (M_launch == 0) return LAE_OK;
-    if (M_cap % 16 != 0) return LAE_EINVAL;
-    if (const int rc = head_args_ok(sigma_weights, color_weights, M_cap, "nerf_head_forward_frame")) return rc;
-    return launch_head_fwd5<true>((const half_t*)enc, dirs, (const half_t*)sigma_weights, (const half_t*)color_weights, M_cap / 16,
-                                  lae::cdiv(std::min(M_launch, M_cap), 16), density_scale, nullptr, sigmas, rgbs, 1, n_rows_dev, M_cap, stream);
+// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], loop state in device memory
+uint32_t lae::frame_head_max_blocks() { return (uint32_t)lae::num_cus() * head_blocks_per_cu(); }
+
+template <bool EDIT, int WAVES>
+static int launch_frame_head(const half_t* enc, const float* dirs, const half_t* Ws, const half_t* Wc, uint32_t lm_rows, uint32_t blocks,
+                             float density_scale, const lae::FrameHeadArgs& fa, hipStream_t s) {
+    const size_t lds_bytes = (size_t)Head5Img::END * 2 + (size_t)WAVES * (sizeof(Head4Scratch) + sizeof(FrameHeadScratch));
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_head<EDIT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess) return LAE_ELAUNCH;
+        attr_set = true;
+    }
+    k_frame_head<EDIT, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(enc, dirs, Ws, Wc, density_scale, lm_rows, fa);
+    return LAE_OK;
+}
+
+int lae::nerf_head_composite_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                                   uint32_t M_cap, float density_scale, const FrameHeadArgs& fa, bool edit, uint32_t n_blocks,
+                                   hipStream_t stream) {
+    if (M_cap % 64 != 0 || n_blocks == 0) return LAE_EINVAL;
+    if (const int rc = head_args_ok(sigma_weights, color_weights, M_cap, "render_frame(head)")) return rc;
+    const half_t *e = (const half_t*)enc, *ws = (const half_t*)sigma_weights, *wc = (const half_t*)color_weights;
+    return edit ? launch_frame_head<true, FRAME_HEAD_WAVES>(e, dirs, ws, wc, M_cap, n_blocks, density_scale, fa, stream)
+                : launch_frame_head<false, FRAME_HEAD_WAVES>(e, dirs, ws, wc, M_cap, n_blocks, density_scale, fa, stream);
 }
 
 extern "C" {

@@ -28,9 +28,36 @@ int grid_forward_frame(const float* inputs, const void* embeddings, const int32_
                        uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                        int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
                        const int32_t* offsets_host);
-int nerf_head_forward_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
-                            uint32_t M_cap, uint32_t M_launch, const uint32_t* n_rows_dev, float density_scale, float* sigmas,
-                            float* rgbs, hipStream_t stream);
+// Loop state of the frame loop, double-buffered in device memory (raymarching.hip k_frame_emit advances it).
+// Sample rows are RAY-MAJOR IN 64-ROW GROUPS: a group holds rpg = 64 / n_step whole rays (integer division), ray n's row j is
+// (n / rpg) * 64 + (n % rpg) * n_step + j; the 64 - rpg * n_step rows at a group's end (n_step = 3, 5, 6, 7 only) are padding.
+// A wave of the head kernel owns a group, so the compositing of a ray never crosses waves.
+struct FrameCtrl { uint32_t n_alive, n_step, n_rows, step, iter, done, total_rows, pad; };
+static_assert(sizeof(FrameCtrl) == 32, "FrameCtrl layout");
+__host__ __device__ __forceinline__ uint32_t frame_rays_per_group(uint32_t n_step) { return 64u / n_step; }
+// per-ray accumulators of composite_rays (raymarching.cu:948-1035 / :1037-1142) as ONE 32-byte record: two 16-byte
+// loads / stores per ray and iteration instead of six to eight scattered 4-byte ones
+struct __attribute__((aligned(16))) RayAcc { float ws, depth, r, g, b, t, wse, de; };
+static_assert(sizeof(RayAcc) == 32, "RayAcc layout");
+struct FrameHeadArgs {
+    const FrameCtrl* cur;            // this iteration's state
+    const int32_t* alive;            // compact list of ray indices
+    const float* deltas;             // [rows, 2]
+    const uint8_t* edit_occ;         // [rows] (distill render) or NULL
+    RayAcc* acc;                     // [N]
+    int32_t* seg_next;               // survivors of wave u (unit), in order, at [u * R, u * R + seg_counts_next[u])
+    uint32_t* seg_counts_next;       // per wave (unit)
+    uint32_t* blk_counts_next;       // per workgroup: the sum of its FRAME_HEAD_WAVES unit counts
+    uint32_t R;
+    float T_thresh;
+};
+// head + compositing of one iteration in one launch of n_blocks workgroups x FRAME_HEAD_WAVES waves; every wave is a
+// unit of work (a contiguous run of 64-row groups) and writes one survivor segment (stride fa.R) + its count
+constexpr int FRAME_HEAD_WAVES = 8;
+int nerf_head_composite_frame(const void* enc, const float* dirs, const void* sigma_weights, const void* color_weights,
+                              uint32_t M_cap, float density_scale, const FrameHeadArgs& fa, bool edit, uint32_t n_blocks,
+                              hipStream_t stream);
+uint32_t frame_head_max_blocks();
 
 // every launch is followed by this: the reference never checked its launches
 // (SURVEY 8b "Errors"); we do, and surface the error through the return code.

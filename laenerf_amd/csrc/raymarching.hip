@@ -994,25 +994,23 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void k_compact_scatter(const int32_t
 //     positions and deltas are recomputed from the recorded times with the reference's arithmetic, no probing.
 // The lookahead also advances its own copy of rays_t with the compositing kernel's arithmetic (t += deltas[1] per
 // sample), so every iteration starts from bit-identical times to the host loop's.
-struct FrameCtrl { uint32_t n_alive, n_step, n_rows, step, iter, done, total_rows, pad; };
-static_assert(sizeof(FrameCtrl) == 32, "FrameCtrl layout");
-struct FrameMirror { volatile uint64_t tag; volatile uint32_t n_alive, done, total_rows, iters; };   // pinned host memory
+using lae::FrameCtrl;                          // lae_common.h (shared with the head kernel, ffmlp.hip)
+using lae::RayAcc;
+struct FrameMirror { volatile uint64_t tag; volatile uint32_t n_alive, done, total_rows, iters, hung; };   // pinned host memory; hung: a k_frame_wait gave up
 constexpr int FRAME_BLOCK = 256;
-constexpr uint32_t FRAME_SEG_MAX = 512;        // compositing workgroups = survivor segments
+constexpr uint32_t FRAME_SEG_MAX = 4096;       // survivor segments = waves of the head + compositing kernel (k_frame_head, ffmlp.hip)
+constexpr uint32_t FRAME_SEG_SLACK = 200;      // a segment's stride exceeds bound_alive / segments by < 66 + 63 + 64 (see the stride below)
 constexpr uint32_t FRAME_LA = 8;               // recorded samples per ray (>= max_n_step)
 
 __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const float* __restrict__ nears,
-                             float* __restrict__ rays_t, float* __restrict__ tc, float* __restrict__ weights_sum,
-                             float* __restrict__ depth, float* __restrict__ image, float* __restrict__ weights_edit,
-                             float* __restrict__ depth_edit, uint32_t* __restrict__ q_counts) {
+                             RayAcc* __restrict__ acc, float* __restrict__ tc, uint32_t* __restrict__ q_counts) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n == 0) { ctrl[0] = FrameCtrl{}; q_counts[0] = 0u; q_counts[1] = 0u; }   // state "before iteration 0": step = 0, nothing issued, no straggler queued
     if (n >= N) return;
-    rays_t[n] = nears[n];
-    tc[n] = nears[n];
-    weights_sum[n] = 0.0f; depth[n] = 0.0f;
-    image[3 * (size_t)n] = 0.0f; image[3 * (size_t)n + 1] = 0.0f; image[3 * (size_t)n + 2] = 0.0f;
-    if (weights_edit) { weights_edit[n] = 0.0f; depth_edit[n] = 0.0f; }
+    const float t0 = nears[n];
+    tc[n] = t0;
+    reinterpret_cast<float4*>(acc + n)[0] = make_float4(0.f, 0.f, 0.f, 0.f);      // weights_sum, depth, image
+    reinterpret_cast<float4*>(acc + n)[1] = make_float4(0.f, t0, 0.f, 0.f);       // image.b, rays_t, weights_edit_sum, depth_edit
 }
 
 // Wave-cooperative continuation of ONE ray (state broadcast from lane L): the candidate scheme of k_march_train_wave --
@@ -1098,6 +1096,81 @@ __device__ __forceinline__ float perturbed_start(const MarchCfg& cfg, float t, c
 // iteration p -- first advance tc[ray] (this loop's copy of rays_t) over the n_step samples that iteration consumes, with
 // the compositing kernel's arithmetic (t += deltas[1]), then walk on from there (march_rays restarts from rays_t,
 // raymarching.cu:736).  Records la_t[ray][0..cnt) = sample times, la_e = edit flags, la_cnt[ray] = cnt <= max_n_step.
+// ---- survivors of the previous iteration: nu segments (one per wave of k_frame_head, in list order) of stride R with their
+// counts, and the per-workgroup sums of those counts (FRAME_HEAD_WAVES consecutive segments = one workgroup).  Both per-ray
+// kernels of an iteration (emit, lookahead) walk these lists directly: wave wv of a launch takes entries
+// [(wv % cpb) * 64, +64) of workgroup-level list wv / cpb, cpb = W * R / 64, finds its lane's segment from the workgroup's W
+// counts, and gets n_alive and its offset in the compact order from the <= 512 workgroup sums (the per-wave counts of every
+// workgroup, 2048 words read by each of ~14 k waves, made the emit kernel 18 us instead of 13).
+struct FrameSegs { const uint32_t* unit_counts; const uint32_t* blk_counts; const int32_t* seg; uint32_t nu, R; };
+struct FrameSlot { uint32_t n_alive, n, index; bool has; };
+__device__ __forceinline__ FrameSlot frame_locate(const FrameSegs& sg, uint32_t N, uint32_t wv, int lane) {
+    constexpr uint32_t W = lae::FRAME_HEAD_WAVES;
+    FrameSlot f;
+    if (sg.nu == 0) {                                      // first iteration: every ray, identity order
+        f.n_alive = N; f.n = wv * 64u + (uint32_t)lane; f.index = f.n; f.has = f.n < N;
+        return f;
+    }
+    const uint32_t nb = sg.nu / W, cpb = W * sg.R / 64u;
+    const uint32_t bb = wv / cpb, l = (wv % cpb) * 64u + (uint32_t)lane;
+    const uint32_t bbc = bb < nb ? bb : 0u;
+    uint32_t below = 0, total = 0;
+    for (uint32_t j = (uint32_t)lane; j < nb; j += 64u) {
+        const uint32_t c = sg.blk_counts[j];
+        total += c; below += j < bb ? c : 0u;
+    }
+    uint32_t uc[W];                                        // requested beside the sums above: one round trip, not two
+#pragma unroll
+    for (uint32_t j = 0; j < W; j++) uc[j] = sg.unit_counts[bbc * W + j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { total += __shfl_xor(total, d, 64); below += __shfl_xor(below, d, 64); }
+    uint32_t pre = 0, unit = bbc * W, off = l;
+    bool found = false;
+#pragma unroll
+    for (uint32_t j = 0; j < W; j++) {
+        if (!found && l < pre + uc[j]) { found = true; unit = bbc * W + j; off = l - pre; }
+        pre += uc[j];
+    }
+    f.n_alive = total; f.n = below + l; f.index = 0;
+    f.has = bb < nb && found;                              // pre == the workgroup's survivors
+    if (f.has) f.index = (uint32_t)sg.seg[(size_t)unit * sg.R + off];
+    return f;
+}
+// Cross-stream handshake of the frame loop WITHOUT events: hipEventRecord + hipStreamWaitEvent cost 10-12 us per dependency
+// on this stack, a 64-bit word in device memory written by the producer (its own kernel, or a one-thread kernel behind it)
+// and a one-wave kernel polling it on the consumer's stream 1.7-2.8 us (tools/ubench/stream_hop.hip, profiles/r4_stream_hop.txt).
+// Values grow monotonically over the life of the process ((frame number << 32) | iteration + 1), so nothing is ever reset.
+__global__ void k_frame_signal(unsigned long long* __restrict__ flag, unsigned long long value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_frame_wait(const unsigned long long* __restrict__ flag, unsigned long long value, volatile uint32_t* __restrict__ hung) {
+    // bounded (~ seconds): a producer that never comes (a failed launch on the other stream) must not hang the device
+    for (uint32_t spin = 0; spin < (1u << 23); spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (threadIdx.x == 0) *hung = 1u;
+}
+// the next loop state from the previous one and the number of survivors (renderer.py:352,363,377); evaluated with the same
+// arguments by the emit kernel (which publishes it) and by the lookahead kernel (which only needs n_step and done)
+__device__ __forceinline__ FrameCtrl frame_next_ctrl(const FrameCtrl& pv, uint32_t n_alive, uint32_t row_budget, uint32_t max_steps,
+                                                     uint32_t max_n_step) {
+    FrameCtrl c;
+    c.step = pv.step + pv.n_step;
+    c.total_rows = pv.total_rows + pv.n_alive * pv.n_step;
+    c.done = (pv.done || n_alive == 0 || c.step >= max_steps) ? 1u : 0u;
+    c.n_alive = c.done ? 0u : n_alive;
+    c.n_step = c.done ? 0u : max(min(row_budget / n_alive, max_n_step), 1u);
+    const uint32_t rpg = lae::frame_rays_per_group(max(c.n_step, 1u));          // rows in 64-row groups of whole rays (lae_common.h)
+    const uint32_t n_groups = (c.n_alive + rpg - 1u) / rpg;
+    c.n_rows = c.n_alive ? (n_groups - 1u) * 64u + (c.n_alive - (n_groups - 1u) * rpg) * c.n_step : 0u;
+    c.iter = pv.iter + (c.done ? 0u : 1u);
+    c.pad = 0;
+    return c;
+}
+// a ray's lookahead record, double-buffered: iteration i's emit AND lookahead read buffer i & 1, the lookahead writes the other
+struct LookRec { float* t; uint8_t* e; uint32_t* cnt; float* tend; float* tc; };      // [N * FRAME_LA], [N * FRAME_LA], [N], [N], [N]
+
 // in-kernel stamps of the lookahead for tools/frame_look_stamps.py (compiled in only with -DLAE_FRAME_STAMPS): per wave of ONE
 // launch (phase == g_look_phase): wall clock at start / state loaded / lane rounds done / end, lane rounds, coop rays, coop passes
 #ifdef LAE_FRAME_STAMPS
@@ -1116,46 +1189,54 @@ constexpr uint32_t FRAME_FINISH_BLOCKS = 1024; // x 4 waves: more than one wave 
 constexpr int FRAME_COOP_MAX = 8;              // unfinished lanes per wave up to which they are finished cooperatively
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
-    int phase, const FrameCtrl* __restrict__ ctrl, uint32_t N, uint32_t max_n_step, const int32_t* __restrict__ alive,
-    float* __restrict__ tc, float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt,
-    float* __restrict__ la_tend,
+    int phase, const FrameCtrl* __restrict__ prev, FrameSegs sg, uint32_t N, uint32_t row_budget, uint32_t max_steps,
+    uint32_t max_n_step, LookRec in, LookRec out,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
     uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds) {
-    const uint32_t n = blockIdx.x * FRAME_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LOOK_NOTE(0, wall_clock64());
-    // Two dependent round trips before the walk instead of four (beside the encoder a wave's state loads were 5.4 of its
-    // 7.9 us, stamps of round 4): alive[n] is requested together with the loop state -- the list has N slots whatever
-    // n_alive turns out to be -- and everything the ray's index addresses (count, ray, far, t, record) together, before
-    // the count decides whether the ray goes on.
-    uint32_t index = (phase >= 0 && n < N) ? (uint32_t)alive[n] : n;
-    const uint32_t n_alive = phase < 0 ? N : ctrl->n_alive, n_consumed = phase < 0 ? 0u : ctrl->n_step;
-    bool has_ray = n < n_alive;
+    // Iteration `phase` consumes n_step samples of every ray that survived iteration phase - 1.  Neither the rays nor n_step
+    // come from this iteration's emit kernel: the rays are read off the previous head kernel's survivor segments, n_step
+    // follows from their number (frame_next_ctrl, the emit kernel's own formula), and the records are double-buffered -- so
+    // this launch needs nothing the emit kernel of its iteration writes and may run beside it.
+    FrameSlot f;
+    uint32_t n_consumed = 0;
+    if (phase < 0) { f.n_alive = N; f.n = wv * 64u + (uint32_t)lane; f.index = f.n; f.has = f.n < N; }
+    else {
+        f = frame_locate(sg, N, wv, lane);
+        const FrameCtrl c = frame_next_ctrl(*prev, f.n_alive, row_budget, max_steps, max_n_step);
+        if (c.done) return;
+        n_consumed = c.n_step;
+    }
+    const uint32_t n = f.n;
+    uint32_t index = f.index;
+    bool has_ray = f.has;
     if (__ballot(has_ray) == 0ull) return;
-    if (!has_ray) index = 0;                               // slots past n_alive hold stale entries
+    if (!has_ray) index = 0;
     uint32_t st_rounds = 0;
     [[maybe_unused]] uint32_t st_coop = 0, st_passes = 0;
     Ray r{};
     float t = 0.f, far = 0.f, tend0 = 0.f;
     uint32_t cnt0 = 0;
-    float* out_t = la_t + (size_t)index * FRAME_LA;
-    uint8_t* out_e = EDIT ? la_e + (size_t)index * FRAME_LA : nullptr;
-    // the ray's record travels as two 16-byte loads (and, if part of it is kept, two stores): a load per consumed sample
-    // and a load + store per kept one, each waited for in turn inside its loop, were a dozen dependent round trips
-    // through a memory system the encoder kernel next door keeps saturated -- the kernel's 110-150 us
+    float* out_t = out.t + (size_t)index * FRAME_LA;
+    uint8_t* out_e = EDIT ? out.e + (size_t)index * FRAME_LA : nullptr;
+    // everything the ray's index addresses is requested together, before the count decides whether the ray goes on; the
+    // record travels as two 16-byte loads (a load per consumed sample and a load + store per kept one, each waited for in
+    // turn, were a dozen dependent round trips through a memory system the encoder kernel next door keeps saturated)
     static_assert(FRAME_LA == 8, "the record is handled as 2 x float4 / one 64-bit word");
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     unsigned long long rece = 0ull;
     if (has_ray) {
         r = load_ray(rays_o, rays_d, index);
         far = fars[index];
-        t = tc[index];
+        t = in.tc[index];
         if (phase >= 0) {
-            cnt0 = la_cnt[index];
-            ra = reinterpret_cast<const float4*>(out_t)[0]; rb = reinterpret_cast<const float4*>(out_t)[1];
-            if (EDIT) rece = *reinterpret_cast<const unsigned long long*>(out_e);
-            tend0 = la_tend[index];
+            cnt0 = in.cnt[index];
+            ra = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[0]; rb = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[1];
+            if (EDIT) rece = *reinterpret_cast<const unsigned long long*>(in.e + (size_t)index * FRAME_LA);
+            tend0 = in.tend[index];
         }
     }
     if (phase >= 0 && cnt0 < n_consumed) has_ray = false;  // the ray ends in this iteration
@@ -1175,7 +1256,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
                     last = tn;
                 }
             }
-            tc[index] = t;
+            out.tc[index] = t;
             // The samples recorded beyond the consumed ones are exactly what a walk restarted at t would find, provided the
             // compositing kernel's running t equals the walker's own t after the last consumed sample (it does unless the
             // float subtraction / addition pair above rounded: then everything is walked again from t, like the reference).
@@ -1294,13 +1375,13 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             const uint32_t index_l = (uint32_t)__builtin_amdgcn_readlane((int)index, L);
             float t_end;
             const uint32_t got = frame_lookahead_coop<EDIT>(rl, cfg, grid, edit_grid, bcast(t, L), bcast(far, L), max_n_step - step_l,
-                                                            la_t + (size_t)index_l * FRAME_LA + step_l,
-                                                            EDIT ? la_e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane, t_end);
+                                                            out.t + (size_t)index_l * FRAME_LA + step_l,
+                                                            EDIT ? out.e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane, t_end);
             if (lane == L) { step += got; t = t_end; }
         }
         break;
     }
-    if (has_ray) { la_cnt[index] = step; la_tend[index] = t; }
+    if (has_ray) { out.cnt[index] = step; out.tend[index] = t; }
     LOOK_NOTE(3, wall_clock64());
     LOOK_NOTE(4, (unsigned long long)st_rounds | ((unsigned long long)st_coop << 16) | ((unsigned long long)__builtin_popcountll(__ballot(has_ray)) << 32));
 }
@@ -1310,8 +1391,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
     uint32_t max_n_step, const uint32_t* __restrict__ q_count, uint32_t* __restrict__ q_count_next, const LookTask* __restrict__ q_tasks,
-    float* __restrict__ la_t, uint8_t* __restrict__ la_e, uint32_t* __restrict__ la_cnt, float* __restrict__ la_tend,
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
+    LookRec out, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *q_count_next = 0u;
     const uint32_t n_tasks = *q_count;
@@ -1324,54 +1404,31 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
         const Ray r = load_ray(rays_o, rays_d, index);
         float t_end;
         const uint32_t got = frame_lookahead_coop<EDIT>(r, cfg, grid, edit_grid, t, fars[index], max_n_step - step,
-                                                        la_t + (size_t)index * FRAME_LA + step,
-                                                        EDIT ? la_e + (size_t)index * FRAME_LA + step : nullptr, lane, t_end);
-        if (lane == 0) { la_cnt[index] = step + got; la_tend[index] = t_end; }
+                                                        out.t + (size_t)index * FRAME_LA + step,
+                                                        EDIT ? out.e + (size_t)index * FRAME_LA + step : nullptr, lane, t_end);
+        if (lane == 0) { out.cnt[index] = step + got; out.tend[index] = t_end; }
     }
 }
 
-// march_rays (raymarching.cu:700-805 / :811-926) as a replay of the recorded sample times; see the section comment
+// march_rays (raymarching.cu:700-805 / :811-926) as a replay of the recorded sample times; see the section comment.
+// The survivors of the previous iteration arrive as segments (frame_locate); this kernel lists them in order (alive[]),
+// publishes the loop state and writes the sample rows.  It also tells the lookahead stream when to start (k_frame_wait there
+// polls `go`): at its beginning (go_early: the lookahead of this iteration needs nothing this kernel writes -- only that the
+// previous head kernel is complete, which this kernel running proves) or when its last-dispatched workgroup is done (the
+// lookahead then does not compete with this kernel, which is on the caller's critical path, for the memory system).
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
-    const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, const uint32_t* __restrict__ seg_counts,
-    const int32_t* __restrict__ seg, uint32_t nb_prev, uint32_t R_prev, uint32_t N, uint32_t row_budget, uint32_t max_steps,
-    uint32_t max_n_step, int32_t* __restrict__ alive, const float* __restrict__ tc, const float* __restrict__ la_t,
-    const uint8_t* __restrict__ la_e, const uint32_t* __restrict__ la_cnt, const float* __restrict__ rays_o,
+    const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, FrameSegs sg, uint32_t N, uint32_t row_budget, uint32_t max_steps,
+    uint32_t max_n_step, int32_t* __restrict__ alive, LookRec in, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, MarchCfg cfg, float* __restrict__ xyzs, float* __restrict__ dirs,
     float* __restrict__ deltas, uint8_t* __restrict__ edit_occ, const float* __restrict__ noises,
-    FrameMirror* __restrict__ mirror, uint64_t frame_id) {
-    __shared__ uint32_t red[2][FRAME_BLOCK / 64];
-    uint32_t n_alive, off_b, cnt_b, b, local;
-    if (nb_prev == 0) {                                    // first iteration: every ray, identity order
-        n_alive = N; b = 0; off_b = 0; cnt_b = N; local = blockIdx.x * FRAME_BLOCK + threadIdx.x;
-    } else {
-        const uint32_t cpb = R_prev / FRAME_BLOCK;         // chunks per segment
-        b = blockIdx.x / cpb; local = (blockIdx.x % cpb) * FRAME_BLOCK + threadIdx.x;
-        uint32_t below = 0, total = 0;
-        for (uint32_t j = threadIdx.x; j < nb_prev; j += FRAME_BLOCK) {
-            const uint32_t c = seg_counts[j];
-            total += c; below += j < b ? c : 0u;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { total += __shfl_xor(total, d, 64); below += __shfl_xor(below, d, 64); }
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = total; red[1][threadIdx.x >> 6] = below; }
-        __syncthreads();
-        total = 0; below = 0;
-#pragma unroll
-        for (int w = 0; w < FRAME_BLOCK / 64; w++) { total += red[0][w]; below += red[1][w]; }
-        n_alive = total; off_b = below; cnt_b = seg_counts[b];
-    }
-    // loop state (renderer.py:352,363,377)
-    const FrameCtrl pv = *prev;
-    FrameCtrl c;
-    c.step = pv.step + pv.n_step;
-    c.total_rows = pv.total_rows + pv.n_rows;
-    c.done = (pv.done || n_alive == 0 || c.step >= max_steps) ? 1u : 0u;
-    c.n_alive = c.done ? 0u : n_alive;
-    c.n_step = c.done ? 0u : max(min(row_budget / n_alive, max_n_step), 1u);
-    c.n_rows = c.n_alive * c.n_step;
-    c.iter = pv.iter + (c.done ? 0u : 1u);
-    c.pad = 0;
+    FrameMirror* __restrict__ mirror, uint64_t frame_id, unsigned long long* __restrict__ go, unsigned long long go_value, int go_early) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (go && go_early && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const FrameSlot f = frame_locate(sg, N, wv, lane);
+    const FrameCtrl c = frame_next_ctrl(*prev, f.n_alive, row_budget, max_steps, max_n_step);
+    const uint32_t rpg = lae::frame_rays_per_group(max(c.n_step, 1u));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *cur = c;
         mirror->total_rows = c.total_rows; mirror->iters = c.iter; mirror->n_alive = c.n_alive; mirror->done = c.done;   // done last
@@ -1380,23 +1437,25 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
         for (uint32_t row = c.n_rows; row < ((c.n_rows + 15u) & ~15u); row++) {     // pad rows of the last 16-row MLP tile
             xyzs[3 * (size_t)row] = 0.f; xyzs[3 * (size_t)row + 1] = 0.f; xyzs[3 * (size_t)row + 2] = 0.f;
             dirs[3 * (size_t)row] = 0.f; dirs[3 * (size_t)row + 1] = 0.f; dirs[3 * (size_t)row + 2] = 0.f;
+            deltas[2 * (size_t)row] = 0.f; deltas[2 * (size_t)row + 1] = 0.f;
         }
     }
-    if (c.done || local >= cnt_b) return;
-    const uint32_t n = off_b + local, n_step = c.n_step;
-    const int32_t index = nb_prev ? seg[(size_t)b * R_prev + local] : (int32_t)n;
-    alive[n] = index;
-    const Ray r = load_ray(rays_o, rays_d, (uint32_t)index);
-    const uint32_t have = min(la_cnt[index], n_step);
-    float last_t = tc[index];
-    if (nb_prev == 0) last_t = perturbed_start(cfg, last_t, noises, n);
+    if (!c.done && f.has) {
+    const uint32_t n = f.n, n_step = c.n_step;
+    const uint32_t index = f.index;
+    alive[n] = (int32_t)index;
+    const Ray r = load_ray(rays_o, rays_d, index);
+    const uint32_t have = min(in.cnt[index], n_step);
+    float last_t = in.tc[index];
+    if (sg.nu == 0) last_t = perturbed_start(cfg, last_t, noises, n);
     // the record as two 16-byte loads (+ one 8-byte load of the edit flags), not a dependent load per sample
-    const float4 ra = reinterpret_cast<const float4*>(la_t + (size_t)index * FRAME_LA)[0];
-    const float4 rb = reinterpret_cast<const float4*>(la_t + (size_t)index * FRAME_LA)[1];
+    const float4 ra = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[0];
+    const float4 rb = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[1];
     const float st[FRAME_LA] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
     unsigned long long ste = 0ull;
-    if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(la_e + (size_t)index * FRAME_LA);
-    size_t row = (size_t)n * n_step;
+    if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(in.e + (size_t)index * FRAME_LA);
+    const uint32_t grp = n / rpg, slot = n - grp * rpg;
+    size_t row = (size_t)grp * 64u + (size_t)slot * n_step;
 #pragma unroll
     for (uint32_t j = 0; j < FRAME_LA; j++, row++) {
         if (j >= n_step) break;                            // uniform
@@ -1415,77 +1474,42 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
             if (EDIT) edit_occ[row] = 0;
         }
     }
-}
-
-// composite_rays (raymarching.cu:948-1035 / :1037-1142) + survivors of workgroup b's range [b*R, (b+1)*R) of the alive
-// list into segment b (stable), count into seg_counts[b]
-template <bool EDIT>
-__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_composite(
-    const FrameCtrl* __restrict__ cur, const int32_t* __restrict__ alive, int32_t* __restrict__ seg_next,
-    uint32_t* __restrict__ seg_counts_next, uint32_t R, float* __restrict__ rays_t, const float* __restrict__ sigmas,
-    const float* __restrict__ rgbs, const float* __restrict__ deltas, float* __restrict__ weights_sum,
-    float* __restrict__ weights_edit_sum, float* __restrict__ depth, float* __restrict__ depth_edit,
-    const uint8_t* __restrict__ edit_occ, float* __restrict__ image, float T_thresh) {
-    __shared__ uint32_t lds[FRAME_BLOCK / 64 + 1];
-    const uint32_t n_alive = cur->n_alive, n_step = cur->n_step;
-    const uint32_t lo = blockIdx.x * R, hi = min(lo + R, n_alive);
-    uint32_t running = 0;
-    for (uint32_t base = lo; base < hi; base += FRAME_BLOCK) {
-        const uint32_t n = base + threadIdx.x;
-        uint32_t keep = 0;
-        int32_t index = -1;
-        if (n < hi) {
-            index = alive[n];
-            const float* s = sigmas + (size_t)n * n_step;
-            const float* c = rgbs + 3 * (size_t)n * n_step;
-            const float* dl = deltas + 2 * (size_t)n * n_step;
-            const uint8_t* eo = EDIT ? edit_occ + (size_t)n * n_step : nullptr;
-            float t = rays_t[index];
-            float ws = weights_sum[index], d = depth[index];
-            float wse = 0, de = 0;
-            if (EDIT) { wse = weights_edit_sum[index]; de = depth_edit[index]; }
-            float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
-            uint32_t step = 0;
-            while (step < n_step) {
-                const float d0 = dl[2 * step];
-                if (d0 == 0) break;
-                const float alpha = 1.0f - __expf(-s[step] * d0);
-                const float T = 1 - ws;
-                const float w = alpha * T;
-                ws += w;
-                if (EDIT) { if (eo[step]) { wse += w; de = fmaf(w, t, de); } }
-                t += dl[2 * step + 1];
-                d = fmaf(w, t, d);
-                r = fmaf(w, c[3 * step], r); g = fmaf(w, c[3 * step + 1], g); b = fmaf(w, c[3 * step + 2], b);
-                if (T < T_thresh) break;
-                step++;
-            }
-            if (step == n_step) { keep = 1; rays_t[index] = t; }
-            weights_sum[index] = ws; depth[index] = d;
-            if (EDIT) { weights_edit_sum[index] = wse; depth_edit[index] = de; }
-            image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    if (slot == rpg - 1u) {                                // the group's padding rows (n_step = 3, 5, 6, 7: at most 4)
+        for (size_t pr = (size_t)grp * 64u + (size_t)rpg * n_step; pr < (size_t)grp * 64u + 64u; pr++) {
+            xyzs[3 * pr] = 0.f; xyzs[3 * pr + 1] = 0.f; xyzs[3 * pr + 2] = 0.f;
+            dirs[3 * pr] = 0.f; dirs[3 * pr + 1] = 0.f; dirs[3 * pr + 2] = 0.f;
+            deltas[2 * pr] = 0.f; deltas[2 * pr + 1] = 0.f;
+            if (EDIT) edit_occ[pr] = 0;
         }
-        uint32_t total;
-        const uint32_t ex = lae::block_excl_scan<FRAME_BLOCK / 64>(keep, &total, lds);
-        if (keep) seg_next[(size_t)lo + running + ex] = index;
-        running += total;
     }
-    if (threadIdx.x == 0) seg_counts_next[blockIdx.x] = running;
+    }
+    if (go && !go_early) {
+        // the workgroup holding the LAST ray of the list was dispatched last of those with work: when it is done the kernel
+        // is (all but) done and the lookahead may start.  Nothing alive / loop over: workgroup 0 says so.
+        const int last = __syncthreads_or((f.has && f.n + 1u == f.n_alive) || ((c.done || f.n_alive == 0u) && blockIdx.x == 0));
+        if (last && threadIdx.x == 0) { __threadfence(); __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    }
 }
 
-// renderer.py:381-383: background blend and depth normalisation
+// renderer.py:381-383: the accumulators go out to the caller's arrays with the background blend and the depth normalisation
 __global__ void k_frame_finish(uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
-                               const float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
+                               const RayAcc* __restrict__ acc, float* __restrict__ weights_sum, float* __restrict__ depth,
+                               float* __restrict__ image, float* __restrict__ weights_edit, float* __restrict__ depth_edit,
                                const float* __restrict__ bg_rays, float bg_r, float bg_g, float bg_b, int blend_bg, int scale_depth) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    const float4 a0 = reinterpret_cast<const float4*>(acc + n)[0], a1 = reinterpret_cast<const float4*>(acc + n)[1];
+    float r = a0.z, g = a0.w, b = a1.x, d = a0.y;
     if (blend_bg) {
-        const float om = 1 - weights_sum[n];
+        const float om = 1 - a0.x;
         const float b0 = bg_rays ? bg_rays[3 * (size_t)n] : bg_r, b1 = bg_rays ? bg_rays[3 * (size_t)n + 1] : bg_g,
                     b2 = bg_rays ? bg_rays[3 * (size_t)n + 2] : bg_b;
-        image[3 * (size_t)n] += om * b0; image[3 * (size_t)n + 1] += om * b1; image[3 * (size_t)n + 2] += om * b2;
+        r += om * b0; g += om * b1; b += om * b2;
     }
-    if (scale_depth) depth[n] = fmaxf(depth[n] - nears[n], 0.0f) / (fars[n] - nears[n]);
+    if (scale_depth) d = fmaxf(d - nears[n], 0.0f) / (fars[n] - nears[n]);
+    weights_sum[n] = a0.x; depth[n] = d;
+    image[3 * (size_t)n] = r; image[3 * (size_t)n + 1] = g; image[3 * (size_t)n + 2] = b;
+    if (weights_edit) { weights_edit[n] = a1.z; depth_edit[n] = a1.w; }
 }
 
 }  // namespace
@@ -1754,17 +1778,21 @@ int lae_compact_rays_alive(const int32_t* rays_alive, uint32_t n_alive, int32_t*
 
 // ---- whole-frame inference (MI355X-native; replaces the host loop of NeRFRenderer.run_cuda, renderer.py:335-387,
 // and of run_cuda_distill, :394-480, when edit_grid != NULL)
-static inline uint64_t frame_budget(uint32_t N, uint64_t row_budget) { return row_budget < N ? N : std::min<uint64_t>(row_budget, 0xfffffff0ull); }
-static inline uint64_t frame_cap(uint64_t budget) { return (budget + 15) / 16 * 16 + 16; }
+static inline uint64_t frame_budget(uint32_t N, uint64_t row_budget) { return row_budget < N ? N : std::min<uint64_t>(row_budget, 0xe0000000ull); }
+// rows of an iteration in the grouped layout (lae_common.h FrameCtrl): at most 64 / 60 of the budget (n_step = 7: 63 of
+// 64 rows of a group hold samples; n_step = 5, 6: 60) plus one partial group
+static inline uint64_t frame_padded_rows(uint64_t rows) { return (rows + rows / 15 + 64 + 63) / 64 * 64; }
+static inline uint64_t frame_cap(uint64_t budget) { return frame_padded_rows(budget) + 64; }
 static inline uint64_t al256(uint64_t b) { return (b + 255) / 256 * 256; }
-static inline uint64_t frame_seg_elems(uint32_t N) { return (uint64_t)N + (uint64_t)FRAME_SEG_MAX * FRAME_BLOCK; }
+static inline uint64_t frame_seg_elems(uint32_t N) { return (uint64_t)N + (uint64_t)FRAME_SEG_MAX * FRAME_SEG_SLACK; }
 uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_budget) {
     const uint64_t cap = frame_cap(frame_budget(N, row_budget));
-    return 256 /*ctrl x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*segment counts x2*/ + al256(4ull * N) /*alive*/ +
-           2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + 4 * al256(4ull * N) /*rays_t, tc, nears, fars*/ +
-           al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 2 * al256(4ull * N) /*lookahead times, edit flags, counts, end t*/ +
+    return 256 /*ctrl x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*segment counts x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*workgroup sums x2*/ +
+           al256(4ull * N) /*alive*/ + 2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + al256(32ull * N) /*accumulators*/ +
+           2 * al256(4ull * N) /*nears, fars*/ +
+           2 * (al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 3 * al256(4ull * N)) /*lookahead records x2: times, edit flags, count, end t, tc*/ +
            2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
-           al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ + al256(4 * cap) /*sigmas*/ + al256(12 * cap) /*rgbs*/ +
+           al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ +
            256 /*straggler task counters x2*/ + al256(12ull * N) /*straggler tasks*/;
 }
 
@@ -1773,8 +1801,7 @@ struct FrameHost {                                        // process-wide helper
     FrameMirror* mirror_h = nullptr;
     FrameMirror* mirror_d = nullptr;
     hipStream_t side = nullptr;                           // lookahead marcher runs here, beside the encoder / MLP kernels
-    static constexpr int NEV = 16;
-    hipEvent_t ev_emit[NEV] = {}, ev_look[NEV] = {};
+    unsigned long long* flags = nullptr;                  // device: [0] "lookahead may start" (emit kernel), [1] "lookahead done" (side stream); values only grow
     uint64_t frame_counter = 0;
     hipStream_t last_stream = nullptr;                    // stream of the previous frame (its tail may still be queued)
     bool have_last = false;
@@ -1788,20 +1815,13 @@ struct FrameHost {                                        // process-wide helper
         mirror_h = reinterpret_cast<FrameMirror*>(hp); mirror_d = reinterpret_cast<FrameMirror*>(dp);
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess) return false;
-        // The events only order this device's two streams (the host learns the loop state from the mirror, which the emit kernel
-        // publishes with its own system-scope fence): no system-scope fence at the record -- 13.75 -> 13.30 ms per 800x800
-        // frame.  LAE_FRAME_EVENT_FLAGS=0 restores the default flags, 2 = device-scope release (13.7 ms) for A/B.
-        unsigned ev_flags = hipEventDisableTiming | hipEventDisableSystemFence;
-        if (const char* e = getenv("LAE_FRAME_EVENT_FLAGS")) {
-            const int m = atoi(e);
-            if (m == 0) ev_flags = hipEventDisableTiming;
-            if (m == 2) ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
-        }
-        for (int i = 0; i < NEV; i++) {
-            if (hipEventCreateWithFlags(&ev_emit[i], ev_flags) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&ev_look[i], ev_flags) != hipSuccess) return false;
-        }
+        int prio = hi;
+        if (const char* e = getenv("LAE_FRAME_SIDE_PRIO")) { const int m = atoi(e); prio = m > 0 ? lo : m == 0 ? (lo + hi) / 2 : hi; }   // 1 lowest / 0 normal / -1 highest (default; measured: no difference)
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return false;
+        // The two streams hand each other work through two 64-bit words in device memory, not through events (k_frame_wait /
+        // k_frame_signal above): an event record + wait is 10-12 us per dependency here, 2-3 of them per iteration.
+        if (hipMalloc(reinterpret_cast<void**>(&flags), 256) != hipSuccess) return false;
+        if (hipMemset(flags, 0, 256) != hipSuccess) return false;
         ok = true;
         return true;
     }
@@ -1855,23 +1875,25 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     auto take = [&](uint64_t bytes) { uint8_t* p = w; w += al256(bytes); return p; };
     FrameCtrl* ctrl = reinterpret_cast<FrameCtrl*>(take(256));
     uint32_t* seg_counts[2] = {reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX)), reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX))};
+    uint32_t* blk_counts[2] = {reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX)), reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX))};
     int32_t* alive = reinterpret_cast<int32_t*>(take(4ull * N));
     int32_t* seg[2] = {reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N))), reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N)))};
-    float* rays_t = reinterpret_cast<float*>(take(4ull * N));
-    float* tc = reinterpret_cast<float*>(take(4ull * N));
+    RayAcc* acc = reinterpret_cast<RayAcc*>(take(32ull * N));
     float* nears = reinterpret_cast<float*>(take(4ull * N));
     float* fars = reinterpret_cast<float*>(take(4ull * N));
-    float* la_t = reinterpret_cast<float*>(take(4ull * FRAME_LA * N));
-    uint8_t* la_e = take((uint64_t)FRAME_LA * N);
-    uint32_t* la_cnt = reinterpret_cast<uint32_t*>(take(4ull * N));
-    float* la_tend = reinterpret_cast<float*>(take(4ull * N));
+    LookRec rec[2];
+    for (int k = 0; k < 2; k++) {
+        rec[k].t = reinterpret_cast<float*>(take(4ull * FRAME_LA * N));
+        rec[k].e = take((uint64_t)FRAME_LA * N);
+        rec[k].cnt = reinterpret_cast<uint32_t*>(take(4ull * N));
+        rec[k].tend = reinterpret_cast<float*>(take(4ull * N));
+        rec[k].tc = reinterpret_cast<float*>(take(4ull * N));
+    }
     float* xyzs = reinterpret_cast<float*>(take(12 * cap));
     float* dirs = reinterpret_cast<float*>(take(12 * cap));
     float* deltas = reinterpret_cast<float*>(take(8 * cap));
     uint8_t* edit_occ = take(cap);
     void* feats = take((uint64_t)L * cap * 4);
-    float* sigmas = reinterpret_cast<float*>(take(4 * cap));
-    float* rgbs = reinterpret_cast<float*>(take(12 * cap));
     uint32_t* q_counts = reinterpret_cast<uint32_t*>(take(256));            // [2], used alternately by consecutive lookaheads
     LookTask* q_tasks = reinterpret_cast<LookTask*>(take(12ull * N));
     static_assert(sizeof(LookTask) == 12, "LookTask layout");
@@ -1884,38 +1906,59 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
 
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
     const float in_shift = bound, in_scale = 1.0f / (2.0f * bound);        // grid.py:149 (torch multiplies by the fp32 reciprocal)
-    auto lookahead = [&](int phase, const FrameCtrl* c, uint32_t n_bound, hipStream_t q) {
-        const uint32_t blocks = lae::cdiv(n_bound, FRAME_BLOCK);
+    // lookahead of iteration `phase` (-1: before the loop): rays = the survivor lists `sg` of iteration phase - 1, records
+    // read from `in`, written to `out`; `waves` sizes the launch (one wave per 64 list entries), n_bound the finishing kernel
+    auto lookahead = [&](int phase, const FrameCtrl* pv, const FrameSegs& sg, const LookRec& in, const LookRec& out, uint32_t waves,
+                         uint32_t n_bound, hipStream_t q) {
+        const uint32_t blocks = lae::cdiv(waves, FRAME_BLOCK / 64);
         uint32_t* qc = q_counts + (look_no & 1u);
         uint32_t* qc_next = q_counts + ((look_no + 1u) & 1u);
         look_no++;
         LookTask* qt = finish_queue ? q_tasks : nullptr;
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
-            k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, la_e, la_cnt, la_tend, rays_o, rays_d, fars,
+            k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
                                                                  cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max, max_rounds);
-            if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, la_e, la_cnt, la_tend, rays_o,
-                                                                                        rays_d, fars, cfg, grid, edit_grid);
+            if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid);
         } else {
-            k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, c, N, max_n_step, alive, tc, la_t, nullptr, la_cnt, la_tend, rays_o, rays_d,
-                                                                  fars, cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds);
-            if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, la_t, nullptr, la_cnt, la_tend, rays_o,
-                                                                                         rays_d, fars, cfg, grid, nullptr);
+            k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
+                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds);
+            if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr);
         }
     };
     k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
-    k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, rays_t, tc, weights_sum, depth, image,
-                                                    edit_grid ? weights_edit : nullptr, edit_grid ? depth_edit : nullptr, q_counts);
-    lookahead(-1, nullptr, N, s);
+    k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, acc, rec[0].tc, q_counts);
+    const FrameSegs no_segs{nullptr, nullptr, nullptr, 0u, 0u};
+    lookahead(-1, nullptr, no_segs, rec[0], rec[0], lae::cdiv(N, 64), N, s);
+    // Two chains per iteration i (records double-buffered: emit(i) and lookahead(i) read buffer i & 1 and the survivor
+    // segments of head(i-1), lookahead(i) writes buffer (i+1) & 1):
+    //   caller's stream:  wait(look = i)  -> emit(i) [go = i+1, at its start or its end] -> encoder(i) -> head + compositing(i)
+    //   side stream:      wait(go = i+1)  -> lookahead(i) -> its finishing kernel -> signal(look = i+1)
+    // go at the START of the emit kernel: lookahead(i) needs nothing emit(i) writes, only that head(i-1) is complete, which the
+    // emit kernel running proves.  (LAE_FRAME_LOOK_EARLY=0: go when the emit kernel's last workgroup is done, so that the
+    // lookahead's loads do not compete with the emit kernel on the caller's critical path -- measured 11.83 / 69.8 / 12.47 ms
+    // against 11.40 / 69.1 / 11.73 ms for the 800x800 frame / the 1080p frame / one rank's shard of it: the later start costs
+    // the lookahead chain more than the quieter emit kernel gains.)
+    static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
+    unsigned long long* flag_go = g_frame.flags;
+    unsigned long long* flag_look = g_frame.flags + 1;
+    const unsigned long long fbase = (unsigned long long)frame_id << 32;
+    volatile uint32_t* hung_d = &mirror_d->hung;
+    mirror_h->hung = 0;
     uint32_t bound_alive = N, seen_iter = 0;
     bool done = false;
     int rc = LAE_OK;
     const uint32_t LAG = 4;
-    uint32_t it = 0, nb_prev = 0, R_prev = 0;
-    bool look_pending = false;                            // a lookahead on the side stream the caller's stream has not waited for
+    uint32_t it = 0, nu_prev = 0, R_prev = 0;             // survivor segments (= waves of the previous k_frame_head) and their stride
     auto join_side = [&]() {                               // every exit path: the caller's stream owns the workspace again
-        if (look_pending) (void)hipStreamWaitEvent(s, g_frame.ev_look[(it + FrameHost::NEV - 1) % FrameHost::NEV], 0);
-        look_pending = false;
+        if (overlap && it > 0) k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | it, hung_d);
+    };
+    auto abort_frame = [&]() {                             // a launch failed: release whoever polls for work that will never come
+        if (overlap) {
+            k_frame_signal<<<1, 1, 0, s>>>(flag_go, fbase | 0xffffffffull);
+            k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | 0xffffffffull);
+            (void)hipStreamSynchronize(ls);
+        }
     };
     auto poll = [&]() {
         if (mirror_h->tag != frame_id) return;
@@ -1933,9 +1976,9 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
             const auto t0 = std::chrono::steady_clock::now();
             while (it >= seen_iter + LAG && !done) {
                 poll();
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    lae::set_last_error_str("render_frame: device made no progress for 20 s");
-                    join_side();
+                if (mirror_h->hung || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    lae::set_last_error_str("render_frame: device made no progress");
+                    abort_frame();
                     return LAE_ELAUNCH;
                 }
             }
@@ -1943,54 +1986,52 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         }
         const FrameCtrl* prev = ctrl + (it & 1u);
         FrameCtrl* cur = ctrl + ((it + 1u) & 1u);
-        const uint32_t emit_blocks = nb_prev ? nb_prev * (R_prev / FRAME_BLOCK) : lae::cdiv(N, FRAME_BLOCK);
+        const uint32_t p = it & 1u;                        // segments / counts written by this iteration's head: [p]; read: [p ^ 1]; records read: [p]
+        const FrameSegs sg{seg_counts[p ^ 1u], blk_counts[p ^ 1u], seg[p ^ 1u], nu_prev, R_prev};
+        const uint32_t list_waves = nu_prev ? nu_prev * (R_prev / 64u) : lae::cdiv(N, 64);
         const uint32_t rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)budget, (uint64_t)max_n_step * bound_alive);
-        const uint32_t rows_launch = (rows_bound + 15u) & ~15u;
-        const uint32_t p = it & 1u;                        // segments written by this iteration's compositing: [p]; read: [p ^ 1]
-        const int e = (int)(it % FrameHost::NEV);
-        join_side();                                       // samples of this iteration come from the previous lookahead
+        const uint32_t rows_launch = (uint32_t)std::min<uint64_t>(frame_padded_rows(rows_bound), cap);
+        // side chain: lookahead for the NEXT iteration's samples
+        if (overlap) k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 1u), hung_d);
+        lookahead((int)it, prev, sg, rec[p], rec[p ^ 1u], list_waves, bound_alive, ls);
+        if (overlap) k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | (it + 1u));
+        // caller's chain: the samples of this iteration come from the previous lookahead
+        join_side();
+        const uint32_t emit_blocks = lae::cdiv(list_waves, FRAME_BLOCK / 64);
         if (edit_grid)
-            k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, seg_counts[p ^ 1u], seg[p ^ 1u], nb_prev, R_prev, N, budget,
-                                                                max_steps, max_n_step, alive, tc, la_t, la_e, la_cnt, rays_o, rays_d, cfg,
-                                                                xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id);
+            k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+                                                                xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
+                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
         else
-            k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, seg_counts[p ^ 1u], seg[p ^ 1u], nb_prev, R_prev, N, budget,
-                                                                 max_steps, max_n_step, alive, tc, la_t, nullptr, la_cnt, rays_o, rays_d, cfg,
-                                                                 xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id);
-        // lookahead for the NEXT iteration: beside the network kernels below
-        if (overlap) {
-            if (hipEventRecord(g_frame.ev_emit[e], s) != hipSuccess || hipStreamWaitEvent(ls, g_frame.ev_emit[e], 0) != hipSuccess) {
-                lae::set_last_error_str("render_frame: event record / wait failed");
-                return LAE_ELAUNCH;
-            }
-        }
-        lookahead((int)it, cur, bound_alive, ls);
-        if (overlap) {
-            if (hipEventRecord(g_frame.ev_look[e], ls) != hipSuccess) { lae::set_last_error_str("render_frame: event record failed"); return LAE_ELAUNCH; }
-            look_pending = true;
-        }
+            k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+                                                                 xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
+                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
                                      gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
-        if (rc == LAE_OK)
-            rc = lae::nerf_head_forward_frame(feats, dirs, sigma_weights, color_weights, (uint32_t)cap, rows_launch, &cur->n_rows,
-                                              density_scale, sigmas, rgbs, s);
-        if (rc) { it++; join_side(); return rc; }
-        // compositing: nb workgroups, each owning R consecutive entries of the alive list (nb * R >= bound_alive >= n_alive)
-        const uint32_t nb = std::max(1u, std::min(lae::cdiv(bound_alive, FRAME_BLOCK), FRAME_SEG_MAX));
-        const uint32_t R = std::max(lae::cdiv(lae::cdiv(bound_alive, nb), FRAME_BLOCK), 1u) * FRAME_BLOCK;
-        if (edit_grid)
-            k_frame_composite<true><<<nb, FRAME_BLOCK, 0, s>>>(cur, alive, seg[p], seg_counts[p], R, rays_t, sigmas, rgbs, deltas, weights_sum,
-                                                             weights_edit, depth, depth_edit, edit_occ, image, T_thresh);
-        else
-            k_frame_composite<false><<<nb, FRAME_BLOCK, 0, s>>>(cur, alive, seg[p], seg_counts[p], R, rays_t, sigmas, rgbs, deltas, weights_sum,
-                                                              nullptr, depth, nullptr, nullptr, image, T_thresh);
-        nb_prev = nb; R_prev = R;
-        rc = lae::check_launch("render_frame");
-        if (rc) { it++; join_side(); return rc; }
+        // head + compositing: one wave per run of 64-row groups; the survivors of wave u go, in order, to segment u of
+        // stride R (> the rays a wave can own: bound_alive / units + 64 / units + 64) with their count
+        if (rc == LAE_OK) {
+            lae::FrameHeadArgs fa;
+            fa.cur = cur; fa.alive = alive; fa.deltas = deltas; fa.edit_occ = edit_grid ? edit_occ : nullptr; fa.acc = acc;
+            fa.seg_next = seg[p]; fa.seg_counts_next = seg_counts[p]; fa.blk_counts_next = blk_counts[p]; fa.T_thresh = T_thresh;
+            const uint32_t head_blocks = std::max(1u, std::min(lae::cdiv(rows_launch, 64u * lae::FRAME_HEAD_WAVES), lae::frame_head_max_blocks()));
+            const uint32_t units = head_blocks * lae::FRAME_HEAD_WAVES;
+            fa.R = ((bound_alive / units + 66u + 63u) / 64u) * 64u;
+            if (units > FRAME_SEG_MAX || (uint64_t)units * fa.R > frame_seg_elems(N)) {
+                lae::set_last_error_str("render_frame: survivor segments do not fit their buffers");
+                rc = LAE_EINVAL;
+            } else {
+                rc = lae::nerf_head_composite_frame(feats, dirs, sigma_weights, color_weights, (uint32_t)cap, density_scale, fa,
+                                                    edit_grid != nullptr, head_blocks, s);
+                nu_prev = units; R_prev = fa.R;
+            }
+        }
+        if (rc == LAE_OK) rc = lae::check_launch("render_frame");
+        if (rc) { abort_frame(); return rc; }
     }
     join_side();
-    k_frame_finish<<<lae::cdiv(N, 256), 256, 0, s>>>(N, nears, fars, weights_sum, depth, image, bg_rays, bg_r, bg_g, bg_b, blend_bg,
-                                                     scale_depth);
+    k_frame_finish<<<lae::cdiv(N, 256), 256, 0, s>>>(N, nears, fars, acc, weights_sum, depth, image, edit_grid ? weights_edit : nullptr,
+                                                     edit_grid ? depth_edit : nullptr, bg_rays, bg_r, bg_g, bg_b, blend_bg, scale_depth);
     rc = lae::check_launch("render_frame(finish)");
     if (rc) return rc;
     if (stats_out) {

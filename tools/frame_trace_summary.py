@@ -17,7 +17,7 @@ rows.sort(key=lambda x: x[1])
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     for k in ("k_frame_lookahead_finish", "k_frame_lookahead", "k_frame_emit", "k_frame_composite", "k_frame_init", "k_frame_finish",
-              "k_frame_grid", "k_frame_head", "k_grid_fwd_lean", "k_grid_fwd", "k_nerf_head_fwd5", "k_nerf_head_fwd", "k_near_far"):
+              "k_frame_grid", "k_frame_head", "k_frame_wait", "k_frame_signal", "k_grid_fwd_lean", "k_grid_fwd", "k_nerf_head_fwd5", "k_nerf_head_fwd", "k_near_far"):
         if k in n:
             return k
     return n[:40]
@@ -39,11 +39,16 @@ if not inits or not fins:
 lo, hi = inits[-1], fins[-1]
 last = rows[lo:hi + 1]
 print(f"\nlast frame: {(last[-1][2] - last[0][1]) / 1e6:.3f} ms from k_frame_init start to k_frame_finish end")
-main = [r for r in last if "lookahead" not in r[0] and "k_frame_init" not in r[0] and "k_frame_finish" not in r[0] and "k_near_far" not in r[0]]
-look = [r for r in last if "lookahead" in r[0]]
+# streams by hardware queue: the caller's stream is the one the emit kernel runs on, the lookahead stream the other
+q_main = next((r[4] for r in last if "k_frame_emit" in r[0]), None)
+q_side = next((r[4] for r in last if "k_frame_lookahead" in r[0] and r[4] != q_main), None)
+main = [r for r in last if r[4] == q_main and "lookahead" not in r[0] and "k_frame_init" not in r[0] and "k_frame_finish" not in r[0] and "k_near_far" not in r[0]]
+look = [r for r in last if "lookahead" in r[0] or (q_side is not None and r[4] == q_side)]
 if not main:
     sys.exit(0)
-first = short(main[0][0])
+first = "k_frame_emit"
+while main and short(main[0][0]) != first:      # a wait kernel may precede the first emit
+    main.pop(0)
 its, cur = [], []
 for r in main:
     if short(r[0]) == first and cur:
