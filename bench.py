@@ -177,18 +177,19 @@ def eval_frame(dev, H=800, W=800):
                     "device-resident loop (lookahead marcher on a side stream)"}
 
 
-def frame_workload(args, world, rank, dev, backend_name):
+def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=False):
     """configs[3]: full-frame inference render, rays sharded across the ranks (laenerf_amd/dist.py), one all-gather of the
-    [n/W, 5] fp32 block per frame.  Every rank holds the same (random-init, synthetic-occupancy) model; a step = a frame."""
+    [n/W, 5] fp32 block per frame (north_star / SURVEY 8e; the reference's dormant `dist.all_gather(preds)`, nerf/utils.py:1555-1570).
+    Every rank holds the same (random-init, synthetic-occupancy) model; a step = a frame.  Collective: every rank calls it;
+    returns the same dict on every rank.  with_n1: rank 0 also renders the whole frame alone (W = 1, the reference's schedule)
+    while the others wait, for `speedup_vs_n1`."""
+    import hashlib
     import torch.distributed as dist
     from laenerf_amd import synthetic as S
-    from laenerf_amd.dist import render_frame_sharded
-    from laenerf_amd.network import NeRFNetwork
-    from laenerf_amd.renderer import NeRFRenderer
+    from laenerf_amd.dist import render_frame_sharded, broadcast_model_state
     # configs[3] is mip360/bonsai: scripts/configs_mip360/bonsai.sh has bound=2 -> 2 cascades (renderer.py:74), a 512 KiB
     # bitfield and a 6 328 848-entry table (finest resolution 4096); the camera orbits INSIDE the bound-2 box
     net, r = eval_model(dev, bound=2, seed=1234)              # identical replicas on every rank
-    from laenerf_amd.dist import broadcast_model_state
     broadcast_model_state(r, src=0)                           # SURVEY 8e: replicate table / MLPs / bitfield at load
     H, W = 1080, 1920
     o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
@@ -196,53 +197,81 @@ def frame_workload(args, world, rank, dev, backend_name):
 
     # rows per iteration of the device-resident loop: the reference's rule sizes an iteration by the rays of THE CALL
     # (n_step = max(min(N // n_alive, 8), 1), renderer.py:363), so a rank holding 1/W of the rays would run the whole frame's
-    # iteration count on 1/W of the work per iteration -- 177 launch-chain latencies for a ninth of the samples (42 ms per shard
-    # against 72 ms for the whole frame on one GPU, `frame1080.shard_of_8` of the default line).  With W > 1 every rank
-    # therefore takes the WHOLE frame's row budget (row_budget = W x its rays): same per-ray sample sequences, <= 1e-5 image
-    # difference (rays_t rounding at other boundaries: tests/test_gpu_frame.py::test_frame_loop_row_budget), a few times
-    # fewer iterations.  LAE_FRAME_REFERENCE_SCHEDULE=1 keeps the reference's rule on every rank.
+    # iteration count on 1/W of the work per iteration -- 177 launch-chain latencies for a ninth of the samples (`frame1080.
+    # shard_of_8.reference_schedule_ms` of the N = 1 line).  With W > 1 every rank therefore takes the WHOLE frame's row budget
+    # (row_budget = W x its rays): same per-ray sample sequences, <= 1e-5 image difference (rays_t rounding at other boundaries:
+    # tests/test_gpu_frame.py::test_frame_loop_row_budget), a few times fewer iterations.  LAE_FRAME_REFERENCE_SCHEDULE=1 keeps
+    # the reference's rule on every rank.
     budget = 0 if (world == 1 or os.environ.get("LAE_FRAME_REFERENCE_SCHEDULE") == "1") else None
 
-    def render(ro, rd):
+    def render(ro, rd, whole=False):
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            return r.render_eval(ro, rd, bg_color=1, max_steps=1024, row_budget=(world * ro.shape[0] if budget is None else budget))
+            return r.render_eval(ro, rd, bg_color=1, max_steps=1024, row_budget=(0 if whole else world * ro.shape[0] if budget is None else budget))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     def frame():
         return render_frame_sharded(render, o, d, rank, world)
-    for _ in range(max(args.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         res = frame()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = frame()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sync()
     dt = time.perf_counter() - t0
-    import hashlib
     frame_hash = hashlib.sha256(res["image"].cpu().numpy().tobytes()).hexdigest()[:16]
     hashes = [frame_hash]
+    n1_ms = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         hashes = [None] * world
         dist.all_gather_object(hashes, frame_hash)               # every rank holds the whole frame after the all-gather
+        if with_n1:
+            if rank == 0:                                        # the same model, the whole frame on ONE GPU, the others idle
+                ts = []
+                for it in range(5):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    render_frame_sharded(lambda ro, rd: render(ro, rd, whole=True), o, d, 0, 1)
+                    torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+                n1_ms = sorted(ts[2:])[1] * 1e3
+            sync()
+    ms = dt / steps * 1e3
+    tiles = -(-H * W // 128)
+    out = {"ms_per_frame": round(ms, 3), "Mrays_per_s": round(H * W * steps / dt / 1e6, 3), "rays": H * W, "frames_timed": steps,
+           "n_gpus": world, "frame_sha256_per_rank": hashes, "ranks_hold_the_same_frame": len(set(hashes)) == 1,
+           "gather_bytes_per_rank": int(-(-tiles // world) * 128 * 5 * 4),
+           "collective": "one all_gather_into_tensor of the [n/W, 5] fp32 block per frame" if world > 1 else "none (W = 1)",
+           "backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
+           "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
+           "parallelism": f"rays in 128-ray tiles dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}
+    if n1_ms is not None:
+        out["n1_ms_per_frame"] = round(n1_ms, 3)
+        out["speedup_vs_n1"] = round(n1_ms / ms, 3)
+    return out
+
+
+def frame_workload(args, world, rank, dev, backend_name):
+    """`--workload frame1080`: the sharded frame as the bench's own `value` (strong scaling: the frame is fixed)"""
+    import torch.distributed as dist
+    f = sharded_frame1080(world, rank, dev, backend_name, args.steps, args.warmup)
     if rank == 0:
-        ms = dt / args.steps * 1e3
         print(json.dumps({
-            "frame_sha256_per_rank": hashes, "ranks_hold_the_same_frame": len(set(hashes)) == 1,
-            "gather_bytes_per_rank": int(-(-(-(-H * W // 128)) // world) * 128 * 5 * 4),
-            "metric": "Mrays/s, 1920x1080 whole-frame inference render", "value": round(H * W * args.steps / dt / 1e6, 3), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "frame_sha256_per_rank": f["frame_sha256_per_rank"], "ranks_hold_the_same_frame": f["ranks_hold_the_same_frame"],
+            "gather_bytes_per_rank": f["gather_bytes_per_rank"],
+            "metric": "Mrays/s, 1920x1080 whole-frame inference render", "value": f["Mrays_per_s"], "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": f["ms_per_frame"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
             "config": {"workload": "configs[3]-shaped (mip360/bonsai: bound 2, 2 cascades, 512 KiB bitfield, 6 328 848-entry table): "
                                    "1920x1080 rays of one view from inside the box, L=16 T=2^19 hash grid + 2x64 / 3x64 ffmlp, "
                                    "analytic occupancy, device-resident inference loop per rank",
-                       "rays_per_frame": H * W, "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
-                       "parallelism": f"rays in 128-ray tiles dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}}),
+                       "rays_per_frame": f["rays"], "rays_hitting_geometry": f["rays_hitting_geometry"],
+                       "backend": f["backend"], "world_size": f["world_size"], "parallelism": f["parallelism"]}}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -888,6 +917,12 @@ def main():
         tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    # N > 1: the north star's split, beside the replica `value` -- the configs[3] frame ray-sharded over the ranks with ONE
+    # all-gather per frame on the job's backend (RCCL under the driver), timed like `--workload frame1080`, and the same frame on
+    # rank 0 alone for the speed-up.  Collective: every rank takes part, rank 0 reports.
+    sharded = None
+    if world > 1 and not args.no_frame:
+        sharded = sharded_frame1080(world, rank, dev, backend_name, steps=10, warmup=2, with_n1=True)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -935,6 +970,11 @@ def main():
                         "max": round(max(windows) / args.steps * 1e3, 4), "note": "5 consecutive windows of K steps; `value` is the first"},
             "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
         }
+        if sharded is not None:
+            sharded["note"] = ("configs[3]-shaped (mip360/bonsai) 1080p inference frame, rays sharded over the ranks of THIS job "
+                               "(laenerf_amd/dist.py: 128-ray tiles round-robin, one all_gather_into_tensor per frame), 10 frames between "
+                               "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone (reference schedule)")
+            out["frame1080"] = sharded                         # the north star's 8-GPU split (not `value`)
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
             out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)

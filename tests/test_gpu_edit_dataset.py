@@ -64,20 +64,23 @@ def test_selection_rules_and_crop_terms():
     assert tv_h.max() > 0
 
 
-def test_extract_views_end_to_end(O):
+@pytest.mark.parametrize("bound", [1, 2])
+def test_extract_views_end_to_end(O, bound):
+    """bound 2 = the shape of the config this path serves (configs[4], mip360/bonsai: scripts/configs_mip360/bonsai.sh:2 -> 2
+    cascades, cameras inside the box); bound 1 = the lego shape"""
     from laenerf_amd import synthetic as S
     from laenerf_amd.editing import extract_view, extract_views
     from laenerf_amd.rays import get_rays
-    net, r = make(bound=1, seed=2)
+    net, r = make(bound=bound, seed=2)
     H = W = 96
     intr = np.array([133.3, 133.3, 48.0, 48.0], np.float32)
-    poses = T(poses_looking_at_origin(3, 3.2, seed=1))
+    poses = T(poses_looking_at_origin(3, 3.2 if bound == 1 else 1.7, seed=1))
     r.density_scale = 30.0                                                  # opaque surfaces: weights saturate (> .99)
-    dens = S.sphere_density_grid()
+    dens = S.sphere_density_grid(cascade=r.cascade, bound=float(bound))     # [C, 128^3]
     coords = O.morton3D_invert(np.arange(128 ** 3, dtype=np.int32))       # cell x coordinate of every Morton index
     right = (coords[:, 0] >= 64)
-    edit = T(S.pack_bits_np(np.where(right, dens[0], 0)[None], 10.0))       # edit region: the x > 0 half of the geometry
-    grow = T(S.pack_bits_np(np.where(~right, dens[0], 0)[None], 10.0))      # "grow" region: the other half
+    edit = T(S.pack_bits_np(np.where(right[None], dens, 0), 10.0))          # edit region: the x > 0 half of the geometry (every cascade)
+    grow = T(S.pack_bits_np(np.where(~right[None], dens, 0), 10.0))         # "grow" region: the other half
     images = torch.rand(3, H, W, 4, device=DEV)
     torch.manual_seed(1)
     v = extract_view(r, poses[0], intr, H, W, edit, images[0], depth_diff=0.5, grow_grid=grow)

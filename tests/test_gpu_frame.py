@@ -10,6 +10,11 @@ from gpu_util import DEV, N, T
 
 pytestmark = pytest.mark.gpu
 
+# HIP frame loop against the ORACLE's loop (fp16 MLPs on both sides; what differs is the fp32 accumulate of the MFMA against the
+# oracle FFMLP's and __expf against expf): bounds = ~2x the deviation observed on the MI355X box (printed by the tests), all well
+# inside north_star's 1e-4 RGB -- rounds 1-3 asserted 3e-3 here
+ORACLE_LOOP_TOL = {"weights_sum": 2e-6, "image": 1.5e-5, "depth": 2.5e-6}      # observed 8.9e-7 / 7.0e-6 / 1.1e-6
+
 
 def make(bound=1, log2_T=14, seed=0, table_amp=0.5):
     from laenerf_amd import synthetic as S
@@ -153,11 +158,13 @@ def test_frame_loop_vs_oracle_loop(O):
         step += n_step; rows += m; iters += 1
     image = image + (1 - wsum)[:, None]
     assert got["stats"]["iterations"] == iters and got["stats"]["rows"] == rows      # schedule and row counts: exact
-    assert np.abs(N(got["weights_sum"]) - wsum).max() < 3e-3                          # fp16 MLP / fast exp tolerance
-    assert np.abs(N(got["image"]) - image).max() < 3e-3
     hit = wsum > 0
     dref = np.clip(depth - nears, 0, None)[hit] / (fars - nears)[hit]
-    assert np.abs(N(got["depth"])[hit] - dref).max() < 3e-3
+    dev = {"weights_sum": float(np.abs(N(got["weights_sum"]) - wsum).max()), "image": float(np.abs(N(got["image"]) - image).max()),
+           "depth": float(np.abs(N(got["depth"])[hit] - dref).max())}
+    print("frame loop vs oracle loop, max abs deviation:", {k: float("%.3g" % v) for k, v in dev.items()})
+    for k, v in dev.items():
+        assert v < ORACLE_LOOP_TOL[k], dev
 
 
 @pytest.mark.parametrize("tag", ["b1", "b2"])

@@ -23,6 +23,11 @@ from gpu_util import DEV, N, T
 
 pytestmark = pytest.mark.gpu
 
+# HIP frame loop against the ORACLE's loop (fp16 MLPs on both sides; what differs is the fp32 accumulate of the MFMA against the
+# oracle FFMLP's and __expf against expf): bounds = ~2x the deviation observed on the MI355X box (printed by the tests), all well
+# inside north_star's 1e-4 RGB -- rounds 1-3 asserted 3e-3 here
+ORACLE_LOOP_TOL = {"weights_sum": 2e-6, "image": 2.5e-5, "depth": 1.5e-6}      # observed 9.5e-7 / 1.2e-5 / 5.7e-7
+
 H, W = 1080, 1920
 
 
@@ -122,11 +127,13 @@ def test_frame1080_subset_against_the_oracle_loop(bonsai, O):
     image = image + (1 - wsum)[:, None]
     assert got["stats"]["iterations"] == iters and got["stats"]["rows"] == rows
     assert (wsum > 0).mean() > 0.2
-    assert np.abs(N(got["weights_sum"]) - wsum).max() < 3e-3
-    assert np.abs(N(got["image"]) - image).max() < 3e-3
     hit = wsum > 0
     dref = np.clip(depth - nears, 0, None)[hit] / (fars - nears)[hit]
-    assert np.abs(N(got["depth"])[hit] - dref).max() < 3e-3
+    dev = {"weights_sum": float(np.abs(N(got["weights_sum"]) - wsum).max()), "image": float(np.abs(N(got["image"]) - image).max()),
+           "depth": float(np.abs(N(got["depth"])[hit] - dref).max())}
+    print("frame loop vs oracle loop, max abs deviation:", {k: float("%.3g" % v) for k, v in dev.items()})
+    for k, v in dev.items():
+        assert v < ORACLE_LOOP_TOL[k], dev
 
 
 def test_frame1080_two_ranks_in_fresh_processes_hold_the_same_frame():
@@ -146,3 +153,26 @@ def test_frame1080_two_ranks_in_fresh_processes_hold_the_same_frame():
     assert len(j["frame_sha256_per_rank"]) == 2 and j["ranks_hold_the_same_frame"] is True
     assert j["gather_bytes_per_rank"] == 8100 * 128 * 5 * 4
     assert j["config"]["rays_per_frame"] == H * W and j["config"]["rays_hitting_geometry"] > 0.2
+
+
+def test_default_workload_two_ranks_carries_the_sharded_frame_object():
+    """`bench.py --gpus 2` WITHOUT --workload, as the driver launches its scaling runs: beside the replica `value` the line must
+    carry the north star's split -- the configs[3] frame ray-sharded over the job's ranks with one all-gather per frame, timed,
+    with the speed-up against the same frame on rank 0 alone, the backend and the world size (the reference's
+    dormant gather: nerf/utils.py:1555-1570).  Same gloo / one-device rehearsal as above."""
+    env = dict(os.environ, LAE_BENCH_DIST_BACKEND="gloo", LAE_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() + 1081) % 2000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "Mrays/s" and j["value"] > 0
+    f = j["frame1080"]
+    assert f["n_gpus"] == 2 and f["world_size"] == 2 and f["backend"] == "gloo"
+    assert f["ranks_hold_the_same_frame"] is True and len(f["frame_sha256_per_rank"]) == 2
+    assert f["gather_bytes_per_rank"] == 8100 * 128 * 5 * 4 and f["rays"] == H * W
+    assert f["ms_per_frame"] > 0 and f["n1_ms_per_frame"] > 0 and f["speedup_vs_n1"] == pytest.approx(f["n1_ms_per_frame"] / f["ms_per_frame"], rel=1e-2)
+    assert "eval_frame" not in j                                    # one-GPU extras stay out of the multi-rank line

@@ -11,6 +11,13 @@ from gpu_util import DEV, N
 
 pytestmark = pytest.mark.gpu
 
+# palette network against torch's half-precision linear chain on the same parameters (test_laenerf_forward_train_and_gradients):
+# gradients relative to the largest reference entry (table: relative L2), outputs absolute.  Rounds 1-3 compared with an fp32 chain
+# at 1e-2 / 8 % / 10 %.
+STYLE_TOL = {"pred": 1e-3, "w_hat": 1e-4, "o_hat": 5e-4, "loss": 1e-5, "g_wn": 1e-3, "g_on": 1e-3, "g_pal": 2e-3, "g_table": 1e-3}
+# observed (n = 4096 / 1000): pred 5.0e-4 / 3.5e-4 (one fp16 ulp at 0.5-1), w_hat 3.5e-5, o_hat 2.4e-4, loss 2.6e-6, g_wn 2.5e-4 / 6e-5,
+# g_on 1.1e-4 / 4.4e-4, g_pal 7.6e-4 / 2.9e-4, g_table 3.4e-4 / 4.6e-4
+
 
 def torch_recompose(w_logits, o_raw, palette, active):
     """style_encoder.py:148-158 in fp32"""
@@ -87,15 +94,21 @@ def make_model(P=8, dir_encoding="sphere_harmonics"):
     return m, params
 
 
-def reference_forward(m, x, d):
-    """fp32 restatement of style_encoder.py:135-158 on the same parameters"""
-    feat = m.encoder(x, bound=m.bound).float()
-    wl = chain(feat, m.weight_net.weights.float(), [(64, 32), (64, 64), (16, 64)])
+def reference_forward(m, x, d, half=False):
+    """restatement of style_encoder.py:135-158 on the same parameters.  half=False: fp32 `nn.Linear`-shaped chain (the shape
+    anchor of rounds 1-3).  half=True: the SAME PRECISION PATH as the kernels -- what torch's own nn.Linear chain does under fp16
+    autocast (the reference's default nets, nerf/network.py:95-124: half operands, fp32 accumulate, every layer's output and every
+    layer's gradient rounded to half), so that outputs and gradients can be pinned at rounding level instead of at 8-10 %
+    (VERDICT r3 weak 1 iii; the e2e pins went the same way in round 3)."""
+    feat = m.encoder(x, bound=m.bound)
+    feat = feat.half() if half else feat.float()
+    cast = (lambda w: w.half()) if half else (lambda w: w.float())
+    wl = chain(feat, cast(m.weight_net.weights), [(64, 32), (64, 64), (16, 64)])
     cols = [feat]
     if m.dir_encoding is not None:
-        cols.append(m.dir_encoding(d).float())
+        cols.append(m.dir_encoding(d).to(feat.dtype))
     cols.append(feat.new_zeros(feat.shape[0], m.offset_in_dim - sum(c.shape[1] for c in cols)))
-    ol = chain(torch.cat(cols, -1), m.offset_net.weights.float(), [(64, m.offset_in_dim), (64, 64), (16, 64)])
+    ol = chain(torch.cat(cols, -1), cast(m.offset_net.weights), [(64, m.offset_in_dim), (64, 64), (16, 64)])
     return torch_recompose(wl, ol, m.color_palette.float(), m.active_palets)
 
 
@@ -120,16 +133,24 @@ def test_laenerf_forward_train_and_gradients(n):
     got = {k: (v.grad / 128.0).clone() for k, v in (("table", m.encoder.embeddings), ("wn", m.weight_net.weights),
                                                      ("on", m.offset_net.weights), ("pal", m.color_palette))}
     m.zero_grad()
+    # (a) shape anchor: the fp32 chain (loose: it differs from the kernels by the fp16 rounding of every activation)
     rp, rw, ro = reference_forward(m, x, d)
     assert np.abs(N(pred) - N(rp)).max() < 1e-2 and np.abs(N(w_hat) - N(rw)).max() < 1e-2 and np.abs(N(o_hat) - N(ro)).max() < 1e-2
-    rloss = loss_of(rp, rw, ro)
-    assert loss.item() == pytest.approx(rloss.item(), rel=2e-2)
-    rloss.backward()
+    # (b) the same precision path (torch half linears: fp32 accumulate, half outputs and half gradients per layer, same loss scale)
+    with torch.autocast("cuda", dtype=torch.float16):
+        hp, hw, ho = reference_forward(m, x, d, half=True)
+        hloss = loss_of(hp, hw, ho)
+    dev = {"pred": float(np.abs(N(pred) - N(hp)).max()), "w_hat": float(np.abs(N(w_hat) - N(hw)).max()), "o_hat": float(np.abs(N(o_hat) - N(ho)).max()),
+           "loss": abs(loss.item() - hloss.item()) / abs(hloss.item())}
+    (hloss * 128.0).backward()
     for k, p in (("wn", m.weight_net.weights), ("on", m.offset_net.weights), ("pal", m.color_palette)):
-        ref = N(p.grad)
-        assert np.abs(N(got[k]) - ref).max() < 0.08 * np.abs(ref).max() + 1e-6, k
-    gt, rt = N(got["table"]), N(m.encoder.embeddings.grad)
-    assert np.linalg.norm(gt - rt) < 0.1 * np.linalg.norm(rt)
+        ref = N(p.grad) / 128.0
+        dev["g_" + k] = float(np.abs(N(got[k]) - ref).max() / np.abs(ref).max())
+    gt, rt = N(got["table"]), N(m.encoder.embeddings.grad) / 128.0
+    dev["g_table"] = float(np.linalg.norm(gt - rt) / np.linalg.norm(rt))
+    print("style net vs torch half chain:", {k: float("%.3g" % v) for k, v in dev.items()})
+    for k, v in dev.items():
+        assert v < STYLE_TOL[k], dev
 
 
 def test_laenerf_inference_active_palettes_and_no_dirs():
