@@ -336,6 +336,8 @@ def grid_update(dev):
     net = NeRFNetwork(bound=1).to(dev)
     net.encoder.embeddings.data.uniform_(-0.5, 0.5)
     r = NeRFRenderer(net, bound=1, density_thresh=10).to(dev)
+    from laenerf_amd.optim import FusedAdam
+    FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)   # as in training: the fp16 shadow table exists (no per-call cast)
     ts = []
     for it in range(24):
         torch.cuda.synchronize(); t0 = time.perf_counter()

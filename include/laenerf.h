@@ -498,6 +498,20 @@ LAE_API int lae_grow_region(uint8_t* grid, const float* density_grid, uint32_t C
  *   noise [n,3] in [0,1) or NULL (no jitter). */
 LAE_API int lae_density_grid_positions(const int32_t* coords, uint32_t n, uint32_t H, float bound_c, const float* noise,
                                float* xyzs, int32_t* indices, void* stream);
+/* partial sweep of update_extra_state on the device (renderer.py:600-612: n random cells + n draws from the occupied cells of
+ * density_grid[cas] > 0, found there with nonzero() and a host-sized randint).  Writes 2n points: xyzs [2n,3], indices [2n] (Morton;
+ * -1 for the occupied half when no cell is occupied: lae_density_grid_update skips them, the reference keeps the n random points
+ * only).  noise [2n,3] in [0,1) or NULL.  Two ways to supply the draws:
+ *   rnd == NULL: coords_rand [n,3] int32 in [0,H) and u [n] uniform in [0,1) -- draw j takes occupied cell number
+ *     min(floor(u[j] * K), K - 1) in index order, K = their count (tests pin this against the reference's statements);
+ *   rnd != NULL: [2, n+1] uniforms in [0,1); both halves are then drawn as SORTED i.i.d. samples (order statistics from partial sums
+ *     of exponentials, no sort), cells through Morton codes (H must be a power of two) -- same distribution, points in Morton
+ *     order (the encoder and the scatter run 1.7x / 2.5x faster on ordered points).  coords_rand / u are ignored.
+ * scratch: lae_density_grid_partial_scratch_bytes(cells, n) bytes of device memory; cells = H^3.  No host read: K stays on the device. */
+LAE_API uint64_t lae_density_grid_partial_scratch_bytes(uint32_t cells, uint32_t n);
+LAE_API int lae_density_grid_partial_positions(const float* grid_c, uint32_t cells, const int32_t* coords_rand, const float* u, const float* rnd,
+                                       uint32_t n, uint32_t H, float bound_c, const float* noise, float* xyzs, int32_t* indices,
+                                       void* scratch, void* stream);
 /* update: tmp[indices] = sigmas * density_scale (maximum where indices repeat), then on sampled cells with grid >= 0:
  *   grid = max(grid * decay, tmp)  (renderer.py:596, 627, 633-634).  grid [cells] fp32 is one cascade; tmp [cells] uint32
  *   scratch must be zero on entry and is zero again on return. */

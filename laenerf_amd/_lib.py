@@ -67,6 +67,8 @@ SIGNATURES = {
     "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, i32, vp],
     "lae_nerf_density_forward": [vp, vp, u32, f32, vp, vp, i32, vp],
     "lae_density_grid_positions": [vp, u32, u32, f32, vp, vp, vp, vp],
+    "lae_density_grid_partial_scratch_bytes": [u32, u32],
+    "lae_density_grid_partial_positions": [vp, u32, vp, vp, vp, u32, u32, f32, vp, vp, vp, vp, vp],
     "lae_density_grid_update": [vp, vp, u32, f32, f32, u32, vp, vp, vp],
     "lae_mark_untrained_grid": [vp, u32, f32, f32, f32, f32, u32, u32, f32, f32, i32, vp, vp],
     "lae_nerf_head_backward": [vp, vp, vp, vp, vp, vp, vp, vp, u32, f32, vp, vp, vp, vp, i32, i32, vp, vp, u32, u32, vp, vp, vp],
@@ -95,6 +97,7 @@ SIGNATURES = {
 _RESTYPES = {
     "lae_march_rays_train_scratch_bytes": u64,
     "lae_compact_scratch_bytes": u64,
+    "lae_density_grid_partial_scratch_bytes": u64,
     "lae_palette_backward_scratch_bytes": u64,
     "lae_style_loss_scratch_bytes": u64,
     "lae_render_frame_workspace_bytes": u64,

@@ -129,6 +129,20 @@ class _RayMarching:
                                                      stream()), "density_grid_positions")
 
     @staticmethod
+    def density_grid_partial_positions(grid_c, coords_rand, u, rnd, n, H, bound_c, noise, xyzs, indices):
+        """MI355X-native: the point selection of update_extra_state's partial sweep without a host read (include/laenerf.h);
+        rnd [2, n+1]: sorted draws made on the device, else coords_rand [n,3] + u [n]"""
+        ts = (grid_c, coords_rand, u, rnd, noise, xyzs, indices)
+        need_cuda(*ts); need_contig(*ts); _need_f32(grid_c, u, rnd, noise, xyzs)
+        assert indices.dtype == torch.int32 and (coords_rand is None or coords_rand.dtype == torch.int32)
+        assert grid_c.numel() == H ** 3 and xyzs.numel() == 6 * n and indices.numel() == 2 * n and (noise is None or noise.numel() == 6 * n)
+        assert (rnd is not None and rnd.numel() == 2 * (n + 1)) or (coords_rand.numel() == 3 * n and u.numel() == n)
+        lib = _lib.load()
+        ws = _workspace(grid_c.device, lib.lae_density_grid_partial_scratch_bytes(grid_c.numel(), n))
+        check(lib.lae_density_grid_partial_positions(ptr(grid_c), grid_c.numel(), ptr(coords_rand), ptr(u), ptr(rnd), n, H, float(bound_c),
+                                                     ptr(noise), ptr(xyzs), ptr(indices), ptr(ws), stream()), "density_grid_partial_positions")
+
+    @staticmethod
     def density_grid_update(sigmas, indices, n, density_scale, decay, cells, grid, tmp):
         need_cuda(sigmas, indices, grid, tmp); need_contig(sigmas, indices, grid, tmp); _need_f32(sigmas, grid)
         assert indices.dtype == torch.int32 and tmp.dtype == torch.int32

@@ -14,7 +14,7 @@ from ..backend import raymarching_backend as _backend
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "march_rays_distill", "composite_rays", "composite_rays_distill",
-           "compact_rays_alive", "render_frame", "composite_rays_train_blend", "composite_rays_train_blend_mse", "density_grid_positions", "density_grid_update", "mark_untrained_grid"]
+           "compact_rays_alive", "render_frame", "composite_rays_train_blend", "composite_rays_train_blend_mse", "density_grid_positions", "density_grid_partial_positions", "density_grid_update", "mark_untrained_grid"]
 
 
 def _gpu(t):
@@ -466,6 +466,21 @@ def density_grid_positions(n, H, bound_c, noise=None, coords=None):
     indices = torch.empty(n, dtype=torch.int32, device=dev)
     _backend.density_grid_positions(None if coords is None else _gpu(coords).int().contiguous(), n, H, bound_c,
                                     None if noise is None else _gpu(noise).float().contiguous(), xyzs, indices)
+    return xyzs, indices
+
+
+def density_grid_partial_positions(grid_c, coords_rand, u, H, bound_c, noise=None, rnd=None, n=None):
+    """MI355X-native: the 2n query points of update_extra_state's PARTIAL sweep (nerf/renderer.py:600-621) without the host read
+    of `nonzero`: coords_rand [n,3] random cells, u [n] uniform in [0,1) choosing among the occupied cells of grid_c [H^3] (> 0,
+    in index order), noise [2n,3] jitter -- or rnd [2, n+1] uniforms from which both halves are drawn sorted on the device (H a
+    power of two).  Returns xyzs [2n,3], indices [2n] int32 (Morton; -1 where no cell is occupied)."""
+    n = coords_rand.shape[0] if rnd is None else (rnd.numel() // 2 - 1 if n is None else n)
+    xyzs = torch.empty(2 * n, 3, dtype=torch.float32, device=grid_c.device)
+    indices = torch.empty(2 * n, dtype=torch.int32, device=grid_c.device)
+    _backend.density_grid_partial_positions(grid_c.contiguous(), None if rnd is not None else _gpu(coords_rand).int().contiguous(),
+                                            None if rnd is not None else _gpu(u).float().contiguous(),
+                                            None if rnd is None else _gpu(rnd).float().contiguous(), n, H, bound_c,
+                                            None if noise is None else _gpu(noise).float().contiguous(), xyzs, indices)
     return xyzs, indices
 
 

@@ -137,8 +137,28 @@ class NeRFRenderer(nn.Module):
                 bound_c = min(2 ** cas, self.bound)
                 if self.iter_density < 16:
                     n = H ** 3
-                    xyzs, indices = raymarching.density_grid_positions(n, H, bound_c, noise=rand(n))
-                else:
+                    if rng is None and H & (H - 1) == 0:
+                        # every cell once, jitter i.i.d.: the order is free -- Morton order (point j = cell with Morton index j)
+                        # instead of the reference's meshgrid order keeps neighbouring points in neighbouring cells
+                        xyzs, indices = raymarching.density_grid_positions(
+                            n, H, bound_c, noise=rand(n), coords=raymarching.morton3D_invert(torch.arange(n, device=dev, dtype=torch.int32)))
+                    else:
+                        xyzs, indices = raymarching.density_grid_positions(n, H, bound_c, noise=rand(n))
+                elif rng is None:
+                    # partial sweep, selection on the device: the occupied cells are counted, listed and drawn from without
+                    # `nonzero`'s host read (round 3: 0.78 ms for half the points of the 0.82 ms full sweep).  The order of the
+                    # points does not matter to the result (scatter-max + EMA), so both halves are drawn SORTED inside the call
+                    # (order statistics, no sort; csrc/densitygrid.hip): two torch launches (the uniforms) instead of ~30.
+                    n = H ** 3 // 4
+                    if H & (H - 1) == 0:
+                        xyzs, indices = raymarching.density_grid_partial_positions(self.density_grid[cas], None, None, H, bound_c,
+                                                                                   noise=torch.rand(2 * n, 3, device=dev),
+                                                                                   rnd=torch.rand(2, n + 1, device=dev), n=n)
+                    else:
+                        xyzs, indices = raymarching.density_grid_partial_positions(
+                            self.density_grid[cas], torch.randint(0, H, (n, 3), device=dev, dtype=torch.int32), torch.rand(n, device=dev), H, bound_c,
+                            noise=torch.rand(2 * n, 3, device=dev))
+                else:                                            # recorded draws (tests): the reference's statements, one by one
                     n = H ** 3 // 4
                     coords = randint(H, (n, 3)).int()
                     occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
@@ -155,11 +175,19 @@ class NeRFRenderer(nn.Module):
                                                 self.density_scale, decay)
         finally:
             self.model.train(was_training)
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        # mean_density and the mean_count refresh (renderer.py:638, 644-647) need one host read each in the reference; here both
+        # scalars travel in ONE device-to-host copy (the second read cost a second wait for an idle device)
+        total_step = min(16, self.local_step)
+        mean_t = torch.mean(self.density_grid.clamp(min=0)).double()
+        cnt_t = self.step_counter[:total_step, 0].sum().double() if total_step > 0 else mean_t.new_zeros(())
+        mean_v, cnt_v = torch.stack([mean_t, cnt_t]).tolist()
+        self.mean_density = mean_v                                             # the fp32 mean, exactly what `.item()` returned
         self.iter_density += 1
         density_thresh = min(self.mean_density, self.density_thresh)
         self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-        self.update_mean_count()
+        if total_step > 0:
+            self.mean_count = int(int(cnt_v) / total_step)
+        self.local_step = 0
 
     def update_mean_count(self):
         """the mean_count refresh of update_extra_state (renderer.py:644-647); one D2H read every 16 steps"""

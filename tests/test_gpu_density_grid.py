@@ -28,6 +28,78 @@ def test_positions_bit_exact(O, H, bound_c):
     assert np.array_equal(N(xyz), rx)
 
 
+@pytest.mark.parametrize("H,bound_c,frac", [(32, 1.0, 0.1), (128, 2.0, 0.03), (16, 1.0, 0.0), (16, 1.0, 1.0)])
+def test_partial_sweep_selection_on_the_device_equals_the_reference_statements(O, H, bound_c, frac):
+    """update_extra_state's partial sweep (nerf/renderer.py:600-621): `occ = nonzero(grid > 0); occ = occ[randint(len(occ), n)];
+    coords = cat([rand_coords, morton3D_invert(occ)])` -- the reference's statements on torch tensors (with one host read) against
+    the device-side selection (lae_density_grid_partial_positions: count / scan / compact / draw, no host read), fed with the SAME
+    draws (u = (rank + 0.5) / K picks occupied cell number `rank`): positions and Morton indices bit for bit, with no cell occupied
+    (the reference then keeps the n random points: the device marks the other half -1, which the update skips) and with all."""
+    from laenerf_amd import raymarching as rm
+    rng = np.random.default_rng(H + int(100 * frac))
+    cells, n = H ** 3, max(H ** 3 // 4, 64)
+    grid = np.where(rng.random(cells) < frac, rng.random(cells, dtype=np.float32) + 0.01, -rng.random(cells, dtype=np.float32)).astype(np.float32)
+    if frac > 0:
+        grid[rng.integers(0, cells)] = 0.0                                 # zero is not occupied (strict >)
+    g = T(grid)
+    coords_r = rng.integers(0, H, (n, 3)).astype(np.int32)
+    noise = rng.random((2 * n, 3), dtype=np.float32)
+    occ = torch.nonzero(g > 0).squeeze(-1)
+    K = int(occ.numel())
+    ranks = rng.integers(0, max(K, 1), n)
+    u = ((ranks + 0.5) / max(K, 1)).astype(np.float32)
+    xyz, idx = rm.density_grid_partial_positions(g, T(coords_r), T(u), H, bound_c, noise=T(noise))
+    assert xyz.shape == (2 * n, 3) and idx.shape == (2 * n,)
+    if K == 0:
+        rx, ri = rm.density_grid_positions(n, H, bound_c, noise=T(noise[:n]), coords=T(coords_r))
+        assert torch.equal(xyz[:n], rx) and torch.equal(idx[:n], ri) and bool((idx[n:] == -1).all())
+    else:
+        coords = torch.cat([T(coords_r), rm.morton3D_invert(occ[T(ranks.astype(np.int64))].int())], dim=0)
+        rx, ri = rm.density_grid_positions(2 * n, H, bound_c, noise=T(noise), coords=coords)
+        assert torch.equal(idx, ri) and torch.equal(xyz, rx)
+        assert bool((g[idx[n:].long()] > 0).all())                         # every drawn cell is occupied
+    # u at the ends of [0, 1): first and last occupied cell, never out of range
+    if K > 0:
+        ue = np.zeros(n, np.float32); ue[1::2] = np.nextafter(np.float32(1.0), np.float32(0.0))
+        _, idx2 = rm.density_grid_partial_positions(g, T(coords_r), T(ue), H, bound_c)
+        assert int(idx2[n]) == int(occ[0]) and int(idx2[n + 1]) == int(occ[-1])
+
+
+def test_partial_sweep_sorted_draws_made_on_the_device():
+    """rnd path of lae_density_grid_partial_positions: both halves drawn as SORTED i.i.d. uniforms from partial sums of exponentials
+    (no sort, no host read).  Against a float64 numpy evaluation of the same order statistics fed through the explicit (coords, u)
+    path: the same cells up to the summation order of the partial sums (a draw within rounding of a cell boundary may land next
+    door: < 0.1 % of the points, never further than one code / rank); cells in Morton order, occupied draws occupied, and the
+    sample is uniform (Kolmogorov distance)."""
+    from laenerf_amd import raymarching as rm
+    H, bound_c = 128, 2.0
+    cells, n = H ** 3, H ** 3 // 4
+    rng = np.random.default_rng(5)
+    grid = np.where(rng.random(cells) < 0.07, 1.0, -1.0).astype(np.float32)
+    g = T(grid)
+    occ = np.nonzero(grid > 0)[0]
+    K = occ.size
+    rnd = rng.random((2, n + 1)).astype(np.float32)
+    noise = rng.random((2 * n, 3), dtype=np.float32)
+    xyz, idx = rm.density_grid_partial_positions(g, None, None, H, bound_c, noise=T(noise), rnd=T(rnd))
+    idx = N(idx)
+    c = np.cumsum(-np.log1p(-rnd.astype(np.float64)), axis=1)
+    u = np.minimum((c[:, :n] / c[:, n:]).astype(np.float32), np.float32(0.99999994))
+    codes = np.minimum((u[0].astype(np.float64) * cells).astype(np.int64), cells - 1)
+    ranks = np.minimum((u[1] * np.float32(K)).astype(np.int64), K - 1)
+    d0, d1 = np.abs(idx[:n].astype(np.int64) - codes), np.abs(np.searchsorted(occ, idx[n:]) - ranks)
+    assert (d0 > 0).mean() < 1e-3 and d0.max() <= 1 and (d1 > 0).mean() < 1e-3 and d1.max() <= 1
+    assert (np.diff(idx[:n]) >= 0).all() and (np.diff(idx[n:]) >= 0).all()            # Morton order within each half
+    assert (grid[idx[n:]] > 0).all()
+    ks = np.abs((np.arange(n) + 0.5) / n - (idx[:n] + 0.5) / cells).max()               # empirical vs uniform CDF
+    assert ks < 4.0 / np.sqrt(n), ks
+    # positions of the points whose cells agree: the explicit path's arithmetic, bit for bit
+    same = np.nonzero((d0 == 0))[0][:50000]
+    coords = rm.morton3D_invert(T(codes[same].astype(np.int32)))
+    rx, ri = rm.density_grid_positions(same.size, H, bound_c, noise=T(noise[same]), coords=coords)
+    assert np.array_equal(N(xyz)[same], N(rx)) and np.array_equal(idx[same], N(ri))
+
+
 def test_update_is_exact_max_rule_and_leaves_scratch_clean(O):
     from laenerf_amd import raymarching as rm
     rng = np.random.default_rng(3)
