@@ -537,55 +537,66 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
 
 def cpu_baseline_cfg1(n_threads, budget_s=8.0):
     """the cfg1 train step -- `run()` path (renderer.py:128-256), 1024 rays x 512 uniform steps, L=4 hash grid,
-    nn.Linear-shaped nets (network.py:95-124) -- on the host cores: the oracle's operators + numpy, forward + backward,
-    whole steps repeated until the budget is spent."""
+    nn.Linear-shaped nets (network.py:95-124) -- on the host cores: the oracle's operators (OpenMP) for the hash grid and the
+    SH encoder, torch CPU tensors with torch.set_num_threads(all cores) for everything else (the GEMMs, exp / sigmoid, cumprod,
+    the reverse cumulative sums of the backward) -- round 3 ran those in numpy, which torch.set_num_threads does not reach
+    (VERDICT r3 weak 8).  Forward + backward, whole steps repeated until the budget is spent."""
     from oracle import oracle as O
     from laenerf_amd import synthetic as S
     offsets, pls = O.grid_offsets(num_levels=4, desired_resolution=2048)
     rng = np.random.default_rng(0)
     table = rng.uniform(-1e-4, 1e-4, (int(offsets[-1]), 2)).astype(np.float32)
-    W = [rng.uniform(-0.3, 0.3, sh).astype(np.float32) for sh in ((64, 8), (16, 64), (64, 31), (64, 64), (3, 64))]
+    Wn = [rng.uniform(-0.3, 0.3, sh).astype(np.float32) for sh in ((64, 8), (16, 64), (64, 31), (64, 64), (3, 64))]
     o, d = S.lego_like_rays(1024, H=64, W=64, focal=1111.1 * 64 / 800, seed=3)
     N, T = 1024, 512
+    torch.set_num_threads(n_threads)
+    W = [torch.from_numpy(w) for w in Wn]
+    ot, dt_ = torch.from_numpy(o), torch.from_numpy(d)
+    lin = torch.linspace(0, 1, T)
 
     def step():
         nears, fars = O.near_far_from_aabb(o, d, [-1, -1, -1, 1, 1, 1], 0.2)
-        z = nears[:, None] + (fars - nears)[:, None] * np.linspace(0, 1, T, dtype=np.float32)[None]
-        xyz = np.clip(o[:, None] + d[:, None] * z[..., None], -1, 1).astype(np.float32).reshape(-1, 3)
-        x01 = ((xyz + 1) / 2).astype(np.float32)
+        nears, fars = torch.from_numpy(nears), torch.from_numpy(fars)
+        z = nears[:, None] + (fars - nears)[:, None] * lin[None]
+        xyz = torch.clamp(ot[:, None] + dt_[:, None] * z[..., None], -1, 1).reshape(-1, 3)
+        x01 = ((xyz + 1) / 2).contiguous().numpy()
         enc, _ = O.grid_encode_forward(x01, table, offsets, pls, 16, out_blc=True)
-        h1 = np.maximum(enc @ W[0].T, 0); h = h1 @ W[1].T
-        sigma = np.exp(h[:, 0]).reshape(N, T)
-        deltas = np.concatenate([z[:, 1:] - z[:, :-1], ((fars - nears) / T)[:, None]], 1)
-        alphas = 1 - np.exp(-deltas * sigma)
-        trans = np.cumprod(np.concatenate([np.ones((N, 1), np.float32), 1 - alphas + 1e-15], 1), 1)[:, :-1]
+        enc = torch.from_numpy(enc)
+        h1 = torch.relu(enc @ W[0].T); h = h1 @ W[1].T
+        sigma = torch.exp(h[:, 0]).reshape(N, T)
+        deltas = torch.cat([z[:, 1:] - z[:, :-1], ((fars - nears) / T)[:, None]], 1)
+        alphas = 1 - torch.exp(-deltas * sigma)
+        trans = torch.cumprod(torch.cat([torch.ones(N, 1), 1 - alphas + 1e-15], 1), 1)[:, :-1]
         w = alphas * trans
         sh, _ = O.sh_encode_forward(np.repeat(d, T, axis=0), 4)
-        cin = np.concatenate([sh, h[:, 1:]], 1)
-        c1 = np.maximum(cin @ W[2].T, 0); c2 = np.maximum(c1 @ W[3].T, 0); c3 = c2 @ W[4].T
-        rgb = (1 / (1 + np.exp(-c3))).reshape(N, T, 3)
+        cin = torch.cat([torch.from_numpy(sh), h[:, 1:]], 1)
+        c1 = torch.relu(cin @ W[2].T); c2 = torch.relu(c1 @ W[3].T); c3 = c2 @ W[4].T
+        rgb = torch.sigmoid(c3).reshape(N, T, 3)
         image = (w[..., None] * rgb).sum(1) + (1 - w.sum(1))[:, None]
         # backward (MSE against 0.5): image -> rgb, w -> sigma (reverse cumulative sums) -> nets -> table
-        gimg = (2 * (image - 0.5) / image.size).astype(np.float32)
+        gimg = 2 * (image - 0.5) / image.numel()
         grgb = (w[..., None] * gimg[:, None]).reshape(-1, 3)
         gw = ((rgb - 1.0) * gimg[:, None]).sum(-1)
-        sfx = np.cumsum((gw * w)[:, ::-1], 1)[:, ::-1] - gw * w
-        gsigma = (deltas * (gw * trans * (1 - alphas) - sfx)).astype(np.float32).reshape(-1)
-        gc3 = grgb * (rgb.reshape(-1, 3) * (1 - rgb.reshape(-1, 3)))
+        gww = gw * w
+        sfx = torch.flip(torch.cumsum(torch.flip(gww, [1]), 1), [1]) - gww
+        gsigma = (deltas * (gw * trans * (1 - alphas) - sfx)).reshape(-1)
+        r2 = rgb.reshape(-1, 3)
+        gc3 = grgb * (r2 * (1 - r2))
         gc2 = (gc3 @ W[4]) * (c2 > 0); gc1 = (gc2 @ W[3]) * (c1 > 0); gcin = gc1 @ W[2]
-        gh = np.concatenate([(gsigma * sigma.reshape(-1))[:, None], gcin[:, 16:]], 1).astype(np.float32)
+        gh = torch.cat([(gsigma * sigma.reshape(-1))[:, None], gcin[:, 16:]], 1)
         genc = ((gh @ W[1]) * (h1 > 0)) @ W[0]
-        O.grid_encode_backward(genc.astype(np.float32), x01, table.shape, offsets, pls, 16, grad_blc=True)
+        gW = [((gh @ W[1]) * (h1 > 0)).T @ enc, h1.T @ gh, gc1.T @ cin, gc2.T @ c1, gc3.T @ c2]     # weight gradients of the five GEMMs
+        assert len(gW) == 5
+        O.grid_encode_backward(genc.contiguous().numpy(), x01, table.shape, offsets, pls, 16, grad_blc=True)
         return N
-    torch.set_num_threads(n_threads)
-    step()                                                    # warm-up (page-in, BLAS threads)
+    step()                                                    # warm-up (page-in, thread pools)
     t0 = time.perf_counter(); n = 0; k = 0
     while time.perf_counter() - t0 < budget_s or k < 2:
         n += step(); k += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt / 1e6, 6), "unit": "Mrays/s", "ms_per_step": round(dt / k * 1e3, 1), "steps": k,
+    return {"value": round(n / dt / 1e6, 6), "unit": "Mrays/s", "ms_per_step": round(dt / k * 1e3, 1), "steps": k, "cores": n_threads,
             "sample": f"{k} cfg1 train steps (run() path: 1024 rays x 512 steps = 524288 points, L=4 grid, nn.Linear-shaped nets), forward + "
-                      f"backward, oracle operators + numpy BLAS ({n_threads} host threads available), {dt:.1f} s"}
+                      f"backward incl. weight gradients, oracle operators (OpenMP) for the hash grid / SH + torch CPU ops on {n_threads} threads, {dt:.1f} s"}
 
 
 def main():

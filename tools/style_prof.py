@@ -1,4 +1,4 @@
-"""profile target: LAENeRF palette-network steps, eager (rocprofv3 --kernel-trace --stats -- python tools/style_prof.py)"""
+"""profile target: LAENeRF palette-network steps (the step of bench.py style_step), eager (rocprofv3 --kernel-trace --stats -- python tools/style_prof.py)"""
 import sys, os, time, torch
 sys.path.insert(0, os.getcwd())
 from types import SimpleNamespace
@@ -18,10 +18,10 @@ target = torch.rand(P, 3, device=dev)
 for it in range(12):
     if it == 2:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-    with torch.autocast("cuda", dtype=torch.float16):
-        pred, w, o = m.forward_train(x, d)
-        loss = torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params) + m.palet_loss(params)
-    opt.scale(loss).backward()
+    with torch.autocast("cuda", dtype=torch.float16):      # the step bench.py's style_step captures (fused point losses)
+        loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt)
+        loss = loss + opt.scale(m.palet_loss(params))
+    opt.backward(loss)
     opt.step()
 torch.cuda.synchronize()
 print("eager ms/step", (time.perf_counter() - t0) / 10 * 1e3)
