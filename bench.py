@@ -371,9 +371,8 @@ def style_step(dev, P=100000, steps=30):
 
     def body():
         with torch.autocast("cuda", dtype=torch.float16):
-            # recomposition + MSE + weight + offset losses as one node (palette.hip); the palette-only term stays in torch
-            loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt)
-            loss = loss + opt.scale(m.palet_loss(params))
+            # recomposition + MSE + weight + offset + palette losses as one node (palette.hip)
+            loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True)
         opt.backward(loss)
         opt.step()
     side = torch.cuda.Stream()

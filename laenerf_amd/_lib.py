@@ -76,8 +76,8 @@ SIGNATURES = {
     "lae_palette_backward_scratch_bytes": [u32],
     "lae_palette_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp],
     "lae_style_loss_scratch_bytes": [u32],
-    "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp],
-    "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, vp],
+    "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp, u32, f32, f32, vp],
+    "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, i32, f32, f32, vp],
     "lae_grow_region": [vp, vp, u32, u32, f32, vp, u32, vp, u32, u32, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],

@@ -606,22 +606,27 @@ class _Style:
 
 
     @staticmethod
-    def style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin):
-        ts = (pred, target, w_hat, o_hat, scale, fin)
+    def style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin, reg_palette=None, reg_w=(0.0, 0.0)):
+        """reg_palette [P,3] fp32 + reg_w = (palette_loss_valid, palette_loss_distinct): `palet_loss` joins the criterion (include/laenerf.h)"""
+        ts = (pred, target, w_hat, o_hat, scale, fin, reg_palette)
         need_cuda(*ts); need_contig(*ts)
+        assert fin.numel() >= 12
         lib = _lib.load()
         ws = _workspace(pred.device, lib.lae_style_loss_scratch_bytes(M))
         check(lib.lae_style_loss_forward(ptr(pred), ptr(target), ptr(w_hat), ptr(o_hat), M, n_active, float(lw[0]), float(lw[1]), float(lw[2]),
-                                         ptr(scale), ptr(fin), ptr(ws), stream()), "style_loss_forward")
+                                         ptr(scale), ptr(fin), ptr(ws), ptr(reg_palette), 0 if reg_palette is None else reg_palette.shape[0],
+                                         float(reg_w[0]), float(reg_w[1]), stream()), "style_loss_forward")
 
     @staticmethod
-    def style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, upstream, lw, g_w_logits, g_o_raw, g_palette):
+    def style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, upstream, lw, g_w_logits, g_o_raw, g_palette,
+                            reg_w=None):
         ts = (w_logits, o_raw, palette, target, fin, upstream, g_w_logits, g_o_raw, g_palette)
         need_cuda(*ts); need_contig(*ts)
         lib = _lib.load()
         ws = _workspace(w_logits.device, max(lib.lae_palette_backward_scratch_bytes(M), lib.lae_style_loss_scratch_bytes(M)))
         check(lib.lae_style_loss_backward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(target), ptr(fin), ptr(upstream),
                                           float(lw[0]), float(lw[1]), float(lw[2]), ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws),
+                                          int(reg_w is not None), float(reg_w[0]) if reg_w else 0.0, float(reg_w[1]) if reg_w else 0.0,
                                           stream()), "style_loss_backward")
 
 

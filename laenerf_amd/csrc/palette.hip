@@ -18,25 +18,24 @@ typedef _Float16 half_t;
 constexpr int PAL_MAX = 16;          // FFMLP output width
 constexpr int PAL_BLOCK = 256;
 
-struct Palette { float c[PAL_MAX][3]; };   // active rows, compacted, rounded to fp16 values (palette.half())
+// Every per-base array below is indexed by the base number k with COMPILE-TIME indices (loops fully unrolled, inactive bases
+// predicated off by the wave-uniform mask).  Rounds 1-3 compacted the active bases into arrays indexed by a running count: a
+// run-time register index, so the arrays lived in scratch memory (196 / 400 bytes per lane) and the forward / backward kernels
+// took 23 / 39 us for 100 k points (profiles/r4_style_kernel_stats.csv).  Same operations in the same order: same bits.
+struct Palette { float c[PAL_MAX][3]; };   // row k = base k rounded to fp16 values (palette.half()), zeros for inactive bases
 
-// palette [P,3] fp32 in device memory (uniform address -> scalar loads); rows of inactive bases are skipped
+__device__ __forceinline__ bool base_active(uint32_t k, uint32_t P, uint32_t mask) { return k < P && ((mask >> k) & 1u); }
+__device__ __forceinline__ uint32_t compact_col(uint32_t k, uint32_t mask) { return (uint32_t)__popc(mask & ((1u << k) - 1u)); }   // column of base k among the active ones
+
+// palette [P,3] fp32 in device memory (uniform address -> scalar loads)
 __device__ __forceinline__ Palette load_palette(const float* __restrict__ palette, uint32_t P, uint32_t mask) {
     Palette pal;
 #pragma unroll
-    for (int k = 0; k < PAL_MAX; k++) { pal.c[k][0] = 0.f; pal.c[k][1] = 0.f; pal.c[k][2] = 0.f; }
-    uint32_t j = 0;
+    for (int k = 0; k < PAL_MAX; k++) {
+        const bool act = base_active(k, P, mask);
 #pragma unroll
-    for (int k = 0; k < PAL_MAX; k++)
-        if ((uint32_t)k < P && ((mask >> k) & 1u)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float v = (float)(half_t)palette[k * 3 + c];
-#pragma unroll
-                for (int q = 0; q < PAL_MAX; q++) if ((uint32_t)q == j) pal.c[q][c] = v;      // static register indexing
-            }
-            j++;
-        }
+        for (int c = 0; c < 3; c++) pal.c[k][c] = act ? (float)(half_t)palette[k * 3 + c] : 0.0f;
+    }
     return pal;
 }
 
@@ -50,25 +49,30 @@ __device__ __forceinline__ Row16 load_row16(const half_t* __restrict__ p) {
     return r;
 }
 
-// softmax over the active columns of one row (fp32, max-subtracted like torch), compacted: w[0..n_active)
-__device__ __forceinline__ void softmax_active(const Row16& r, uint32_t P, uint32_t mask, float (&w)[PAL_MAX], uint32_t& n_active) {
+// softmax over the active columns of one row (fp32, max-subtracted like torch); w[k] = 0 for inactive bases
+__device__ __forceinline__ void softmax_active(const Row16& r, uint32_t P, uint32_t mask, float (&w)[PAL_MAX]) {
     float mx = -3.0e38f;
-    n_active = 0;
 #pragma unroll
-    for (int k = 0; k < PAL_MAX; k++)
-        if ((uint32_t)k < P && ((mask >> k) & 1u)) { w[n_active] = (float)r.v[k]; mx = fmaxf(mx, w[n_active]); n_active++; }
+    for (int k = 0; k < PAL_MAX; k++) if (base_active(k, P, mask)) mx = fmaxf(mx, (float)r.v[k]);
     float sum = 0.0f;
-    for (uint32_t j = 0; j < n_active; j++) { w[j] = expf(w[j] - mx); sum += w[j]; }
+#pragma unroll
+    for (int k = 0; k < PAL_MAX; k++) {
+        w[k] = 0.0f;
+        if (base_active(k, P, mask)) { w[k] = expf((float)r.v[k] - mx); sum += w[k]; }
+    }
     const float inv = 1.0f / sum;
-    for (uint32_t j = 0; j < n_active; j++) w[j] *= inv;
+#pragma unroll
+    for (int k = 0; k < PAL_MAX; k++) if (base_active(k, P, mask)) w[k] *= inv;
 }
 
-__device__ __forceinline__ void recompose(const float (&w)[PAL_MAX], uint32_t n_active, const Palette& pal, const half_t (&o)[3],
+__device__ __forceinline__ void recompose(const float (&w)[PAL_MAX], uint32_t P, uint32_t mask, const Palette& pal, const half_t (&o)[3],
                                           half_t (&pre)[3]) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float acc = 0.0f;
-        for (uint32_t j = 0; j < n_active; j++) acc = fmaf((float)(half_t)w[j], pal.c[j][c], acc);   // half operands, fp32 accumulate
+#pragma unroll
+        for (int k = 0; k < PAL_MAX; k++)
+            if (base_active(k, P, mask)) acc = fmaf((float)(half_t)w[k], pal.c[k][c], acc);            // half operands, fp32 accumulate
         pre[c] = (half_t)((float)(half_t)acc + (float)o[c]);                                            // half matmul result + half offset
     }
 }
@@ -82,13 +86,14 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_fwd(const half_t* __restr
     const Palette pal = load_palette(palette, P, mask);
     const Row16 wl = load_row16(w_logits + (size_t)i * 16), ol = load_row16(o_raw + (size_t)i * 16);
     float w[PAL_MAX];
-    uint32_t na;
-    softmax_active(wl, P, mask, w, na);
+    softmax_active(wl, P, mask, w);
+    const uint32_t na = (uint32_t)__popc(mask & ((P >= 32 ? 0u : (1u << P)) - 1u));
     half_t o[3], pre[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) o[c] = (half_t)tanhf((float)ol.v[c]);
-    recompose(w, na, pal, o, pre);
-    for (uint32_t j = 0; j < na; j++) w_hat[(size_t)i * na + j] = w[j];
+    recompose(w, P, mask, pal, o, pre);
+#pragma unroll
+    for (int k = 0; k < PAL_MAX; k++) if (base_active(k, P, mask)) w_hat[(size_t)i * na + compact_col(k, mask)] = w[k];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         o_hat[(size_t)i * 3 + c] = o[c];
@@ -103,7 +108,7 @@ struct StyleLossW { float w_uniform, w_non_uniform, c_offset; };
 struct LossSrc { const float* target; const float* fin; const float* upstream; StyleLossW lw; };
 constexpr int SL_COLS = 3 + PAL_MAX;             // partial sums per workgroup: squared error, o^2, 1 - max w, column sums
 constexpr int FIN_LOSS_SCALED = 0, FIN_LOSS = 1, FIN_MSE = 2, FIN_UNIFORM = 3, FIN_NON_UNIFORM = 4, FIN_OFFSET = 5, FIN_JMAX = 6,
-              FIN_SCALE = 7;
+              FIN_SCALE = 7, FIN_REG = 8;      // fin: 12 floats
 
 // g_pred / g_o: fp16 [M,3] or NULL; g_w: fp32 [M, n_active] or NULL (LOSS: derived from the fused criterion instead).
 // Writes g_wl, g_ol [M,16] fp16 (zeros in padded / inactive columns) and this workgroup's palette-gradient partial into
@@ -123,19 +128,22 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
     if (i < M) {
         const Row16 wl = load_row16(w_logits + (size_t)i * 16), ol = load_row16(o_raw + (size_t)i * 16);
         float w[PAL_MAX];
-        uint32_t na;
-        softmax_active(wl, P, mask, w, na);
+        softmax_active(wl, P, mask, w);
         half_t o[3], pre[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) o[c] = (half_t)tanhf((float)ol.v[c]);
-        recompose(w, na, pal, o, pre);
+        recompose(w, P, mask, pal, o, pre);
         float gpc[3], got[3];
         float gmul = 0.0f;                                   // LOSS: upstream d(loss) x loss scale
-        uint32_t jmax_col = 0, jmax_row = 0;
+        uint32_t jmax_col = 0;
+        float wmax = -1.0f;
+        int kmax_row = -1;
         if constexpr (LOSS) {
             gmul = ls.upstream[0] * ls.fin[FIN_SCALE];
             jmax_col = (uint32_t)ls.fin[FIN_JMAX];
-            for (uint32_t j = 1; j < na; j++) if (w[j] > w[jmax_row]) jmax_row = j;                     // first maximum, like torch.max
+#pragma unroll
+            for (int k = 0; k < PAL_MAX; k++)                                                           // first maximum, like torch.max
+                if (base_active(k, P, mask) && (kmax_row < 0 || w[k] > wmax)) { wmax = w[k]; kmax_row = k; }
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -150,22 +158,26 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
                 got[c] = gpc[c] + (g_o ? (float)g_o[(size_t)i * 3 + c] : 0.0f);
             }
         }
+        const uint32_t na = (uint32_t)__popc(mask & ((P >= 32 ? 0u : (1u << P)) - 1u));
         float gw[PAL_MAX], dot = 0.0f;
-        for (uint32_t j = 0; j < na; j++) {
-            float gin;
-            if constexpr (LOSS) gin = gmul * ((j == jmax_col ? ls.lw.w_uniform : 0.0f) - (j == jmax_row ? ls.lw.w_non_uniform : 0.0f));
-            else gin = g_w ? g_w[(size_t)i * na + j] : 0.0f;
-            gw[j] = gin + gpc[0] * pal.c[j][0] + gpc[1] * pal.c[j][1] + gpc[2] * pal.c[j][2];
-            dot = fmaf(w[j], gw[j], dot);
-            gp_pal[j][0] = w[j] * gpc[0]; gp_pal[j][1] = w[j] * gpc[1]; gp_pal[j][2] = w[j] * gpc[2];
+#pragma unroll
+        for (int k = 0; k < PAL_MAX; k++) {
+            gw[k] = 0.0f;
+            if (base_active(k, P, mask)) {
+                float gin;
+                if constexpr (LOSS) gin = gmul * ((compact_col(k, mask) == jmax_col ? ls.lw.w_uniform : 0.0f) - (k == kmax_row ? ls.lw.w_non_uniform : 0.0f));
+                else gin = g_w ? g_w[(size_t)i * na + compact_col(k, mask)] : 0.0f;
+                gw[k] = gin + gpc[0] * pal.c[k][0] + gpc[1] * pal.c[k][1] + gpc[2] * pal.c[k][2];
+                dot = fmaf(w[k], gw[k], dot);
+                gp_pal[k][0] = w[k] * gpc[0]; gp_pal[k][1] = w[k] * gpc[1]; gp_pal[k][2] = w[k] * gpc[2];
+            }
         }
         Row16 out_w, out_o;
 #pragma unroll
         for (int k = 0; k < 16; k++) { out_w.v[k] = (half_t)0.0f; out_o.v[k] = (half_t)0.0f; }
-        uint32_t j = 0;
 #pragma unroll
         for (int k = 0; k < PAL_MAX; k++)
-            if ((uint32_t)k < P && ((mask >> k) & 1u)) { out_w.v[k] = (half_t)(w[j] * (gw[j] - dot)); j++; }   // softmax backward
+            if (base_active(k, P, mask)) out_w.v[k] = (half_t)(w[k] * (gw[k] - dot));                      // softmax backward
 #pragma unroll
         for (int c = 0; c < 3; c++) { const float t = (float)o[c]; out_o.v[c] = (half_t)(got[c] * (1.0f - t * t)); }   // tanh backward
         *reinterpret_cast<uint4*>(g_wl + (size_t)i * 16) = *reinterpret_cast<const uint4*>(&out_w.v[0]);
@@ -173,20 +185,22 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
         *reinterpret_cast<uint4*>(g_ol + (size_t)i * 16) = *reinterpret_cast<const uint4*>(&out_o.v[0]);
         *reinterpret_cast<uint4*>(g_ol + (size_t)i * 16 + 8) = *reinterpret_cast<const uint4*>(&out_o.v[8]);
     }
-    // palette gradient: wave reduce (active rows only; the count is uniform) -> LDS -> one partial row per workgroup
+    // palette gradient: wave reduce of the active bases (uniform mask) -> LDS (compact rows) -> one partial row per workgroup
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t na_u = (uint32_t)__popc(mask & ((P >= 32 ? 0u : (1u << P)) - 1u));
+    if (threadIdx.x < PAL_BLOCK / 64 * PAL_MAX * 3) (&red[0][0])[threadIdx.x] = 0.0f;
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PAL_MAX; k++) {
-        if ((uint32_t)k < na_u) {
+        if (base_active(k, P, mask)) {
+            const uint32_t j = compact_col(k, mask);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float v = gp_pal[k][c];
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                if (lane == 0) red[wv][k * 3 + c] = v;
+                if (lane == 0) red[wv][j * 3 + c] = v;
             }
-        } else if (lane == 0) { red[wv][k * 3] = 0.f; red[wv][k * 3 + 1] = 0.f; red[wv][k * 3 + 2] = 0.f; }
+        }
     }
     __syncthreads();
     if (threadIdx.x < PAL_MAX * 3) {
@@ -197,21 +211,82 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_palette_bwd(const half_t* __restr
     }
 }
 
+// The palette-only regulariser of train_LAENeRF_step (style_encoder.py:195-202, `palet_loss`): over ALL P bases
+//   valid = sum floor(p) * p ;  dists_ij = |p_i - p_j|^2, m = max dists ;  distinct = mean_ij (1 - dists_ij / m)
+//   reg = w_valid * valid + w_distinct * distinct.
+// In torch: ~20 tiny kernels forward and as many backward on a [P,3] tensor, every step.  Here the value is one thread's work in
+// k_style_loss_final and the gradient one thread's per palette entry in k_palette_grad_reduce.  d(max): torch's full-reduction max
+// spreads the gradient evenly over tied maxima; dists is symmetric, so there are always at least two.
+struct PalReg { const float* palette; uint32_t P; float w_valid, w_distinct; };
+__device__ __forceinline__ float pal_dist(const float* __restrict__ pal, uint32_t i, uint32_t j) {
+    float d = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const float t = pal[i * 3 + c] - pal[j * 3 + c]; d += t * t; }
+    return d;
+}
+// wave-cooperative (all 64 lanes of one wave call these with the same arguments; results are wave-uniform): lane q takes the pairs
+// (i, j) = (q / P, q % P), q + 64, ... -- one thread looping over the P^2 pairs with dependent LDS reads took 13 us
+struct PalStats { float S, m, ties; };
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ PalStats pal_reg_stats(const PalReg& r, int lane) {
+    float S = 0.0f, m = 0.0f, ties = 0.0f;
+    for (uint32_t q = (uint32_t)lane; q < r.P * r.P; q += 64u) { const float d = pal_dist(r.palette, q / r.P, q % r.P); S += d; m = fmaxf(m, d); }
+    S = wave_sum(S);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    for (uint32_t q = (uint32_t)lane; q < r.P * r.P; q += 64u) ties += pal_dist(r.palette, q / r.P, q % r.P) == m ? 1.0f : 0.0f;
+    return PalStats{S, m, wave_sum(ties)};
+}
+__device__ __forceinline__ float pal_reg_value(const PalReg& r, int lane) {
+    const PalStats st = pal_reg_stats(r, lane);
+    float valid = 0.0f;
+    for (uint32_t q = (uint32_t)lane; q < r.P * 3u; q += 64u) valid += floorf(r.palette[q]) * r.palette[q];
+    valid = wave_sum(valid);
+    return r.w_valid * valid + r.w_distinct * (1.0f - st.S / ((float)(r.P * r.P) * st.m));
+}
+__device__ __forceinline__ float pal_reg_grad(const PalReg& r, const PalStats& st, uint32_t k, uint32_t c, int lane) {
+    float dm = 0.0f, dS = 0.0f;
+    for (uint32_t q = (uint32_t)lane; q < r.P * r.P; q += 64u) {
+        const uint32_t i = q / r.P, j = q % r.P;
+        if (pal_dist(r.palette, i, j) == st.m) dm += 2.0f * (r.palette[i * 3 + c] - r.palette[j * 3 + c]) * ((i == k ? 1.0f : 0.0f) - (j == k ? 1.0f : 0.0f));
+    }
+    for (uint32_t j = (uint32_t)lane; j < r.P; j += 64u) dS += 4.0f * (r.palette[k * 3 + c] - r.palette[j * 3 + c]);
+    dm = wave_sum(dm) / st.ties; dS = wave_sum(dS);
+    return r.w_valid * floorf(r.palette[k * 3 + c]) - r.w_distinct * (dS / st.m - st.S / (st.m * st.m) * dm) / (float)(r.P * r.P);
+}
+
 // fixed-order sum of the slabs (one workgroup per (compact row j, channel c): lanes stride over the partials, then a
-// butterfly -- the same order every run); scatter the compact active rows back to the [P,3] parameter gradient
+// butterfly -- the same order every run); scatter the compact active rows back to the [P,3] parameter gradient; reg.palette != NULL:
+// + gmul[0] * gmul[1] * d(reg) / d(palette) on every entry (gmul = upstream, fin: the scaled upstream gradient of the criterion)
 __global__ __launch_bounds__(64) void k_palette_grad_reduce(const float* __restrict__ slab, uint32_t n_blocks, uint32_t P, uint32_t mask,
-                                                            float* __restrict__ g_palette) {
+                                                            float* __restrict__ g_palette, PalReg reg, const float* __restrict__ upstream,
+                                                            const float* __restrict__ fin) {
+    __shared__ float spal[PAL_MAX * 3];                  // the regulariser's loops read the palette ~P^2 times: from LDS, not from memory
+    if (reg.palette && threadIdx.x < reg.P * 3u) spal[threadIdx.x] = reg.palette[threadIdx.x];
+    __syncthreads();
+    if (reg.palette) reg.palette = spal;
     const uint32_t e = blockIdx.x;                       // (compact row j, channel c)
     float t = 0.0f;
     for (uint32_t b = threadIdx.x; b < n_blocks; b += 64) t += slab[(size_t)b * (PAL_MAX * 3) + e];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
-    if (threadIdx.x != 0) return;
     const uint32_t j = e / 3, c = e % 3;
+    const float gmul = reg.palette ? upstream[0] * fin[7] : 0.0f;       // fin[FIN_SCALE]
+    PalStats st{0.f, 1.f, 1.f};
+    if (reg.palette) st = pal_reg_stats(reg, (int)threadIdx.x);
     uint32_t seen = 0;
-    for (uint32_t k = 0; k < P; k++) {
-        if ((mask >> k) & 1u) { if (seen == j) g_palette[k * 3 + c] = t; seen++; }
-        else if (j == 0) g_palette[k * 3 + c] = 0.0f;
+    for (uint32_t k = 0; k < P; k++) {                   // uniform control flow: every lane takes part in the regulariser's sums
+        const bool act = (mask >> k) & 1u;
+        const bool mine = act ? seen == j : j == 0;
+        if (mine) {
+            const float g = reg.palette ? gmul * pal_reg_grad(reg, st, k, c, (int)threadIdx.x) : 0.0f;
+            if (threadIdx.x == 0) g_palette[k * 3 + c] = (act ? t : 0.0f) + g;
+        }
+        seen += act ? 1u : 0u;
     }
 }
 
@@ -256,8 +331,10 @@ __global__ __launch_bounds__(PAL_BLOCK) void k_style_loss_partial(const half_t* 
 
 // one workgroup: fixed-order totals of the partials, the loss terms, the arg-max column of the uniform term
 __global__ __launch_bounds__(1024) void k_style_loss_final(const float* __restrict__ slab, uint32_t n_blocks, uint32_t M, uint32_t na,
-                                                           StyleLossW lw, const float* __restrict__ scale, float* __restrict__ fin) {
+                                                           StyleLossW lw, const float* __restrict__ scale, float* __restrict__ fin, PalReg reg) {
     __shared__ float tot[SL_COLS];
+    __shared__ float spal[PAL_MAX * 3];
+    if (reg.palette && threadIdx.x < reg.P * 3u) spal[threadIdx.x] = reg.palette[threadIdx.x];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int col = wave; col < SL_COLS; col += 16) {         // a wave per column: lanes stride over the partials, then a butterfly
         float t = 0.0f;
@@ -267,13 +344,17 @@ __global__ __launch_bounds__(1024) void k_style_loss_final(const float* __restri
         if (lane == 0) tot[col] = t;
     }
     __syncthreads();
+    if (threadIdx.x >= 64) return;
+    if (reg.palette) reg.palette = spal;                                 // (written before the barrier above)
+    const float regv = reg.palette ? pal_reg_value(reg, (int)threadIdx.x) : 0.0f;      // wave 0, all lanes
     if (threadIdx.x != 0) return;
     uint32_t jmax = 0;
     for (uint32_t j = 1; j < na; j++) if (tot[3 + j] > tot[3 + jmax]) jmax = j;
     const float s = scale ? scale[0] : 1.0f;
     const float mse = tot[0] / (3.0f * (float)M), uni = lw.w_uniform * tot[3 + jmax], non = lw.w_non_uniform * tot[2],
                 off = lw.c_offset * tot[1];
-    const float loss = ((mse + uni) + non) + off;
+    const float loss = (((mse + uni) + non) + off) + regv;
+    fin[FIN_REG] = regv;
     fin[FIN_LOSS_SCALED] = loss * s; fin[FIN_LOSS] = loss; fin[FIN_MSE] = mse; fin[FIN_UNIFORM] = uni; fin[FIN_NON_UNIFORM] = non;
     fin[FIN_OFFSET] = off; fin[FIN_JMAX] = (float)jmax; fin[FIN_SCALE] = s;
 }
@@ -313,7 +394,7 @@ int lae_palette_backward(const void* w_logits, const void* o_raw, const float* p
     k_palette_bwd<false><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M,
                                                   (const half_t*)g_pred, g_w, (const half_t*)g_o, (half_t*)g_w_logits, (half_t*)g_o_raw,
                                                   (float*)scratch, LossSrc{});
-    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
+    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette, PalReg{nullptr, 0, 0.f, 0.f}, nullptr, nullptr);
     return lae::check_launch("palette_backward");
 }
 
@@ -321,20 +402,21 @@ uint64_t lae_style_loss_scratch_bytes(uint32_t M) { return (uint64_t)lae::cdiv(M
 
 int lae_style_loss_forward(const void* pred, const float* target, const float* w_hat, const void* o_hat, uint32_t M, uint32_t n_active,
                            float w_uniform, float w_non_uniform, float c_offset, const float* scale, float* fin, void* scratch,
-                           void* stream) {
+                           const float* reg_palette, uint32_t reg_P, float w_valid, float w_distinct, void* stream) {
     if (!pred || !target || !w_hat || !o_hat || !fin || !scratch) return LAE_ENULL;
-    if (M == 0 || n_active == 0 || n_active > PAL_MAX) return LAE_EINVAL;
+    if (M == 0 || n_active == 0 || n_active > PAL_MAX || (reg_palette && (reg_P == 0 || reg_P > PAL_MAX))) return LAE_EINVAL;
     hipStream_t s = STREAM(stream);
     const uint32_t nb = lae::cdiv(M, PAL_BLOCK);
     k_style_loss_partial<<<nb, PAL_BLOCK, 0, s>>>((const half_t*)pred, target, w_hat, (const half_t*)o_hat, M, n_active, (float*)scratch);
     k_style_loss_final<<<1, 1024, 0, s>>>((const float*)scratch, nb, M, n_active, StyleLossW{w_uniform, w_non_uniform, c_offset},
-                                                  scale, fin);
+                                                  scale, fin, PalReg{reg_palette, reg_P, w_valid, w_distinct});
     return lae::check_launch("style_loss_forward");
 }
 
 int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask, uint32_t M,
                             const float* target, const float* fin, const float* upstream, float w_uniform, float w_non_uniform,
-                            float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch, void* stream) {
+                            float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch, int with_reg, float w_valid,
+                            float w_distinct, void* stream) {
     if (!w_logits || !o_raw || !palette || !target || !fin || !upstream || !g_w_logits || !g_o_raw || !g_palette || !scratch) return LAE_ENULL;
     if (M == 0) return LAE_EINVAL;
     const int rc = check_palette(P, active_mask);
@@ -344,7 +426,8 @@ int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float
     const LossSrc ls{target, fin, upstream, StyleLossW{w_uniform, w_non_uniform, c_offset}};
     k_palette_bwd<true><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M, nullptr, nullptr,
                                                  nullptr, (half_t*)g_w_logits, (half_t*)g_o_raw, (float*)scratch, ls);
-    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette);
+    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette,
+                                                     PalReg{with_reg ? palette : nullptr, P, w_valid, w_distinct}, upstream, fin);
     return lae::check_launch("style_loss_backward");
 }
 

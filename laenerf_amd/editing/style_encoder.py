@@ -63,7 +63,7 @@ class _palette_point_loss(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, w_logits, o_raw, palette, active_mask, target, lw, scale):
+    def forward(ctx, w_logits, o_raw, palette, active_mask, target, lw, scale, reg_w=None):
         M = w_logits.shape[0]
         w_logits, o_raw = w_logits.half().contiguous(), o_raw.half().contiguous()
         palette, target = palette.float().contiguous(), target.float().contiguous()
@@ -74,10 +74,12 @@ class _palette_point_loss(Function):
         w_hat = torch.empty(M, n_active, dtype=torch.float32, device=dev)
         o_hat = torch.empty(M, 3, dtype=torch.half, device=dev)
         _backend.palette_forward(w_logits, o_raw, palette, P, active_mask, M, pred, w_hat, o_hat)
-        fin = torch.empty(8, dtype=torch.float32, device=dev)
-        _backend.style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin)
+        fin = torch.empty(12, dtype=torch.float32, device=dev)
+        # reg_w = (palette_loss_valid, palette_loss_distinct): the palette-only term `palet_loss` rides in the same two launches
+        _backend.style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin,
+                                    reg_palette=palette if reg_w is not None else None, reg_w=reg_w or (0.0, 0.0))
         ctx.save_for_backward(w_logits, o_raw, palette, target, fin)
-        ctx.meta = (P, active_mask, M, lw)
+        ctx.meta = (P, active_mask, M, lw, reg_w)
         ctx.mark_non_differentiable(pred, w_hat, o_hat, fin)
         ctx.set_materialize_grads(False)                 # no zero-filled gradients for the auxiliary outputs
         return fin[0], pred, w_hat, o_hat, fin
@@ -86,14 +88,14 @@ class _palette_point_loss(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, g_loss, *_):
         if g_loss is None:
-            return (None,) * 7
+            return (None,) * 8
         w_logits, o_raw, palette, target, fin = ctx.saved_tensors
-        P, active_mask, M, lw = ctx.meta
+        P, active_mask, M, lw, reg_w = ctx.meta
         g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)
         g_pal = torch.empty_like(palette)
         _backend.style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, g_loss.float().reshape(1).contiguous(), lw,
-                                     g_wl, g_ol, g_pal)
-        return g_wl, g_ol, g_pal, None, None, None, None
+                                     g_wl, g_ol, g_pal, reg_w=reg_w)
+        return g_wl, g_ol, g_pal, None, None, None, None, None
 
 
 def palette_recompose(w_logits, o_raw, palette, active_mask):
@@ -170,11 +172,12 @@ class LAENeRF(nn.Module):
         """style_encoder.py:111-133"""
         return self.forward_train(x, d)[0]
 
-    def forward_train_loss(self, x, d, target, params, scaler=None):
+    def forward_train_loss(self, x, d, target, params, scaler=None, with_palet_loss=False):
         """MI355X-native: forward_train + the point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996) in one node:
-        loss = MSE(pred, target) + weights_loss(w_hat) + offset_loss(o_hat), multiplied by `scaler`'s loss scale (a FusedAdam,
-        a 1-element fp32 cuda tensor, or None).  `palet_loss(params)` (palette only) is left to the caller.
-        -> (loss, pred [M,3], w_hat, o_hat); loss.terms = [scaled loss, loss, mse, uniform, non-uniform, offset, ...]"""
+        loss = MSE(pred, target) + weights_loss(w_hat) + offset_loss(o_hat) [+ palet_loss(params) with with_palet_loss=True: the
+        palette-only term and its gradient then ride in the criterion's own launches instead of ~40 tiny torch kernels per step],
+        multiplied by `scaler`'s loss scale (a FusedAdam, a 1-element fp32 cuda tensor, or None).
+        -> (loss, pred [M,3], w_hat, o_hat); loss.terms = [scaled loss, loss, mse, uniform, non-uniform, offset, jmax, scale, palet, ...]"""
         if self.dir_encoding is not None:
             assert d is not None
         w_logits, o_raw, M = self._logits(x, d)
@@ -184,7 +187,8 @@ class LAENeRF(nn.Module):
         if scaler is not None:
             scale = scaler if torch.is_tensor(scaler) else (scaler._scale_view[:1] if scaler.use_scaler else None)
         lw = (float(params.weight_loss_uniform), float(params.weight_loss_non_uniform), float(params.offset_loss))
-        loss, pred, w_hat, o_hat, fin = _palette_point_loss.apply(w_logits, o_raw, self.color_palette, self._active_mask, target, lw, scale)
+        reg_w = (float(params.palette_loss_valid), float(params.palette_loss_distinct)) if with_palet_loss else None
+        loss, pred, w_hat, o_hat, fin = _palette_point_loss.apply(w_logits, o_raw, self.color_palette, self._active_mask, target, lw, scale, reg_w)
         loss.terms = fin
         return loss, pred, w_hat, o_hat
 

@@ -181,9 +181,12 @@ def test_laenerf_inference_active_palettes_and_no_dirs():
     assert np.abs(N(p2) - N(rp2)).max() < 1e-2
 
 
+@pytest.mark.parametrize("palet", [False, True])
 @pytest.mark.parametrize("n,mask", [(4096, 0xFF), (1008, 0b10110101)])
-def test_fused_point_losses_equal_the_torch_formulation(n, mask):
-    """forward_train_loss == forward_train followed by MSE + weights_loss + offset_loss in torch (value and gradients)"""
+def test_fused_point_losses_equal_the_torch_formulation(n, mask, palet):
+    """forward_train_loss == forward_train followed by MSE + weights_loss + offset_loss [+ palet_loss, the palette-only regulariser
+    of style_encoder.py:195-202, with_palet_loss=True] in torch (value and gradients).  The palette starts with one base outside
+    [0, 1) so that floor(p) * p and its gradient are not identically zero."""
     m, params = make_model()
     m.set_active_palets([(mask >> k) & 1 == 1 for k in range(8)])
     m.train()
@@ -192,15 +195,20 @@ def test_fused_point_losses_equal_the_torch_formulation(n, mask):
     d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
     target = torch.rand(n, 3, device=DEV)
     scale = torch.tensor([256.0], device=DEV)
+    with torch.no_grad():
+        m.color_palette[1] = torch.tensor([1.3, -0.4, 0.7], device=DEV)
     res = []
     for fused in (False, True):
         m.zero_grad()
         with torch.autocast("cuda", dtype=torch.float16):
             if fused:
-                loss, pred, w, o = m.forward_train_loss(x, d, target, params, scale)
+                loss, pred, w, o = m.forward_train_loss(x, d, target, params, scale, with_palet_loss=palet)
+                if palet:
+                    assert loss.terms[8].item() == pytest.approx(m.palet_loss(params).item(), rel=1e-5)
             else:
                 pred, w, o = m.forward_train(x, d)
-                loss = (torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params)) * scale
+                loss = (torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params)
+                        + (m.palet_loss(params) if palet else 0.0)) * scale
         (loss * 0.5).backward()
         res.append((loss.detach().float().clone(), pred.detach().clone(), [p.grad.clone() for p in (m.color_palette, m.weight_net.weights,
                                                                                                      m.offset_net.weights, m.encoder.embeddings)]))
@@ -227,7 +235,7 @@ def test_palette_and_loss_argument_errors():
         palette_recompose(wl.cpu(), wl.cpu(), pal.cpu(), 0xFF)              # CPU tensors: no fallback
     pred = torch.zeros(32, 3, device=DEV, dtype=torch.half)
     w = torch.zeros(32, 8, device=DEV)
-    fin = torch.zeros(8, device=DEV)
+    fin = torch.zeros(12, device=DEV)
     with pytest.raises(RuntimeError):
         B.style_loss_forward(pred, torch.zeros(32, 3, device=DEV), w, pred, 32, 0, (1, 1, 1), None, fin)     # n_active = 0
     # empty batch: forward is a no-op, backward zeroes the palette gradient

@@ -19,8 +19,7 @@ for it in range(12):
     if it == 2:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     with torch.autocast("cuda", dtype=torch.float16):      # the step bench.py's style_step captures (fused point losses)
-        loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt)
-        loss = loss + opt.scale(m.palet_loss(params))
+        loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True)
     opt.backward(loss)
     opt.step()
 torch.cuda.synchronize()
