@@ -64,6 +64,32 @@ def parse():
     return p.parse_args()
 
 
+def host_threads():
+    """threads the CPU baselines run on: the cores this job may actually use -- the cgroup CPU quota when there is one (the GPU
+    pool gives a one-GPU job 16 CPUs' worth of time on a 256-thread host: /sys/fs/cgroup/cpu.max = "1600000 100000"; 256 threads
+    under that quota are throttled, measured 13.96 s per cfg1 step against 1.11 s on 16 threads), else the affinity mask / core
+    count.  LAE_CPU_THREADS overrides."""
+    if os.environ.get("LAE_CPU_THREADS"):
+        return max(1, int(os.environ["LAE_CPU_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(n_rays_hint, n_threads):
     """The oracle (C restatement of the reference kernels, oracle/lae_oracle.c) timed on the host cores on a
     bounded sample of the SAME workload: forward + backward of one train step, without the optimizer."""
@@ -536,10 +562,12 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
 
 def cpu_baseline_cfg1(n_threads, budget_s=8.0):
     """the cfg1 train step -- `run()` path (renderer.py:128-256), 1024 rays x 512 uniform steps, L=4 hash grid,
-    nn.Linear-shaped nets (network.py:95-124) -- on the host cores: the oracle's operators (OpenMP) for the hash grid and the
-    SH encoder, torch CPU tensors with torch.set_num_threads(all cores) for everything else (the GEMMs, exp / sigmoid, cumprod,
-    the reverse cumulative sums of the backward) -- round 3 ran those in numpy, which torch.set_num_threads does not reach
-    (VERDICT r3 weak 8).  Forward + backward, whole steps repeated until the budget is spent."""
+    nn.Linear-shaped nets (network.py:95-124) -- on the host cores: the oracle's (sequential C) operators for the hash grid and the
+    SH encoder dealt over n_threads Python threads in chunks of points (ctypes releases the GIL), torch CPU tensors with
+    torch.set_num_threads(n_threads) for everything else (the GEMMs, exp / sigmoid, cumprod, the reverse cumulative sums of the
+    backward) -- round 3 ran those in numpy, which torch.set_num_threads does not reach.  Forward + backward,
+    whole steps repeated until the budget is spent."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from laenerf_amd import synthetic as S
     offsets, pls = O.grid_offsets(num_levels=4, desired_resolution=2048)
@@ -549,6 +577,11 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
     o, d = S.lego_like_rays(1024, H=64, W=64, focal=1111.1 * 64 / 800, seed=3)
     N, T = 1024, 512
     torch.set_num_threads(n_threads)
+    pool = ThreadPoolExecutor(n_threads)
+
+    def chunks(*arrays):
+        idx = np.array_split(np.arange(arrays[0].shape[0]), n_threads)
+        return [tuple(a[i] for a in arrays) for i in idx if i.size]
     W = [torch.from_numpy(w) for w in Wn]
     ot, dt_ = torch.from_numpy(o), torch.from_numpy(d)
     lin = torch.linspace(0, 1, T)
@@ -559,7 +592,7 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
         z = nears[:, None] + (fars - nears)[:, None] * lin[None]
         xyz = torch.clamp(ot[:, None] + dt_[:, None] * z[..., None], -1, 1).reshape(-1, 3)
         x01 = ((xyz + 1) / 2).contiguous().numpy()
-        enc, _ = O.grid_encode_forward(x01, table, offsets, pls, 16, out_blc=True)
+        enc = np.concatenate(list(pool.map(lambda a: O.grid_encode_forward(a[0], table, offsets, pls, 16, out_blc=True)[0], chunks(x01))))
         enc = torch.from_numpy(enc)
         h1 = torch.relu(enc @ W[0].T); h = h1 @ W[1].T
         sigma = torch.exp(h[:, 0]).reshape(N, T)
@@ -567,7 +600,7 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
         alphas = 1 - torch.exp(-deltas * sigma)
         trans = torch.cumprod(torch.cat([torch.ones(N, 1), 1 - alphas + 1e-15], 1), 1)[:, :-1]
         w = alphas * trans
-        sh, _ = O.sh_encode_forward(np.repeat(d, T, axis=0), 4)
+        sh = np.concatenate(list(pool.map(lambda a: O.sh_encode_forward(a[0], 4)[0], chunks(np.repeat(d, T, axis=0)))))
         cin = torch.cat([torch.from_numpy(sh), h[:, 1:]], 1)
         c1 = torch.relu(cin @ W[2].T); c2 = torch.relu(c1 @ W[3].T); c3 = c2 @ W[4].T
         rgb = torch.sigmoid(c3).reshape(N, T, 3)
@@ -586,7 +619,7 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
         genc = ((gh @ W[1]) * (h1 > 0)) @ W[0]
         gW = [((gh @ W[1]) * (h1 > 0)).T @ enc, h1.T @ gh, gc1.T @ cin, gc2.T @ c1, gc3.T @ c2]     # weight gradients of the five GEMMs
         assert len(gW) == 5
-        O.grid_encode_backward(genc.contiguous().numpy(), x01, table.shape, offsets, pls, 16, grad_blc=True)
+        list(pool.map(lambda a: O.grid_encode_backward(a[0], a[1], table.shape, offsets, pls, 16, grad_blc=True), chunks(genc.contiguous().numpy(), x01)))
         return N
     step()                                                    # warm-up (page-in, thread pools)
     t0 = time.perf_counter(); n = 0; k = 0
@@ -595,7 +628,7 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
     dt = time.perf_counter() - t0
     return {"value": round(n / dt / 1e6, 6), "unit": "Mrays/s", "ms_per_step": round(dt / k * 1e3, 1), "steps": k, "cores": n_threads,
             "sample": f"{k} cfg1 train steps (run() path: 1024 rays x 512 steps = 524288 points, L=4 grid, nn.Linear-shaped nets), forward + "
-                      f"backward incl. weight gradients, oracle operators (OpenMP) for the hash grid / SH + torch CPU ops on {n_threads} threads, {dt:.1f} s"}
+                      f"backward incl. weight gradients, oracle operators for the hash grid / SH in {n_threads} chunks + torch CPU ops on {n_threads} threads, {dt:.1f} s"}
 
 
 def main():
@@ -995,8 +1028,8 @@ def main():
             out["grid_update"] = grid_update(dev)
             out["flower_step"] = flower_step(dev)              # configs[2]-shaped train step (not `value`)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_rays, os.cpu_count() or 1)
-            out["cpu_baseline"]["cfg1_run_path"] = cpu_baseline_cfg1(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rays, host_threads())
+            out["cpu_baseline"]["cfg1_run_path"] = cpu_baseline_cfg1(host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
