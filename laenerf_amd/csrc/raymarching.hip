@@ -12,6 +12,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <mutex>
 #include "lae_common.h"
 
@@ -168,6 +169,7 @@ struct Ray {
 struct MarchCfg {
     float bound, dt_gamma, dt_min, dt_max, rH, Hf, Cf, Hm1;
     uint32_t H3;
+    int bound_exp;       // bound == 2^bound_exp, or INT_MIN when bound is not a power of two (mip_bounds then divides)
 };
 struct Probe {
     float x, y, z, dt, tt;
@@ -181,6 +183,20 @@ __device__ __forceinline__ int cascade_of(float v, float Cf) {
     return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e));
 }
 
+// mip_bound = min(2^level, bound) and its reciprocal (raymarching.cu:370-371: `1 / mip_bound`).  With bound a power of two (every
+// shipped config: 1 or 2) both are powers of two: 2^min(level, bound_exp) and 2^-min(level, bound_exp) -- the same bits as the
+// IEEE division, one v_ldexp_f32 instead of its ten dependent instructions in every visit of every walk.
+__device__ __forceinline__ void mip_bounds(const MarchCfg& c, int level, float& mip_bound, float& mip_rbound) {
+    if (c.bound_exp != INT_MIN) {
+        const int l = level < c.bound_exp ? level : c.bound_exp;
+        mip_bound = scalbnf(1.0f, l);
+        mip_rbound = scalbnf(1.0f, -l);
+    } else {
+        mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+        mip_rbound = 1.0f / mip_bound;
+    }
+}
+
 __device__ __forceinline__ Probe probe_at(const Ray& r, const MarchCfg& c, const uint8_t* __restrict__ grid, float t) {
     Probe p;
     p.x = clampf(fmaf(t, r.dx, r.ox), -c.bound, c.bound);
@@ -191,8 +207,8 @@ __device__ __forceinline__ Probe probe_at(const Ray& r, const MarchCfg& c, const
     const int lp = cascade_of(amax, c.Cf);
     const int ld = cascade_of(p.dt * c.Hf * 0.5f, c.Cf);
     const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
-    const float mip_rbound = 1.0f / mip_bound;
+    float mip_bound, mip_rbound;
+    mip_bounds(c, level, mip_bound, mip_rbound);
     const int nx = (int)clampf((0.5f * fmaf(p.x, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
     const int ny = (int)clampf((0.5f * fmaf(p.y, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
     const int nz = (int)clampf((0.5f * fmaf(p.z, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
@@ -226,8 +242,8 @@ __device__ __forceinline__ VisitGeom visit_geom(const Ray& r, const MarchCfg& c,
     const int lp = cascade_of(amax, c.Cf);
     const int ld = cascade_of(v.dt * c.Hf * 0.5f, c.Cf);
     const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
-    const float mip_rbound = 1.0f / mip_bound;
+    float mip_bound, mip_rbound;
+    mip_bounds(c, level, mip_bound, mip_rbound);
     const int nx = (int)clampf((0.5f * fmaf(x, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
     const int ny = (int)clampf((0.5f * fmaf(y, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
     const int nz = (int)clampf((0.5f * fmaf(z, mip_rbound, 1.0f)) * c.Hf, 0.0f, c.Hm1);
@@ -242,7 +258,26 @@ __device__ __forceinline__ VisitGeom visit_geom(const Ray& r, const MarchCfg& c,
     return v;
 }
 
+// `do t += dt while (t < tt)` (raymarching.cu:396-398).  Constant step (dt_gamma == 0, every shipped config): inside one binade the
+// walk is T_k = t + k q exactly (uniform_step below), so the first T_k >= tt (k >= 1) follows from one multiply and at most one
+// correction either way instead of 5-9 dependent add / compare / branch rounds per empty cell -- the same value bit for bit, or
+// the loop itself whenever the jump could leave the binade, dt sits on a rounding tie, or k is large.
 __device__ __forceinline__ float skip_to(const MarchCfg& c, float t, float tt) {   // :396-398
+    if (c.dt_gamma == 0.0f && t > 0.0f) {                  // (the first condition is launch-uniform)
+        const float dt = clampf(0.0f, c.dt_min, c.dt_max);   // clamp(t * 0, dt_min, dt_max): dt_max when max_steps is so small that dt_min > dt_max
+        int e;
+        (void)frexpf(t, &e);                               // t in [2^(e-1), 2^e)
+        const float top = scalbnf(1.0f, e), half_ulp = scalbnf(1.0f, e - 25);
+        const float q = (t + dt) - t;                      // fl(t + dt) - t: exact, and the same for every T_k of the binade
+        const float span = tt - t;
+        const float k = fmaxf(ceilf(span * __builtin_amdgcn_rcpf(q)), 1.0f);   // within one of the true count (fixed below)
+        if (q > 0.0f && fabsf(dt - q) != half_ulp && k <= 256.0f && (top - t) > (k + 2.0f) * q) {
+            float cand = fmaf(k, q, t);                    // exact: k q and the sum are representable below 2^e
+            if (cand < tt) cand += q;                      // k one short
+            else if (k > 1.0f && cand - q >= tt) cand -= q;   // k one long
+            return cand;
+        }
+    }
     do { t += clampf(t * c.dt_gamma, c.dt_min, c.dt_max); } while (t < tt);
     return t;
 }
@@ -263,6 +298,8 @@ static MarchCfg make_cfg(float bound, float dt_gamma, uint32_t max_steps, uint32
     c.dt_max = 2 * SQRT3 * (float)(1 << (C - 1)) / (float)H;
     c.rH = 1.0f / (float)H; c.Hf = (float)H; c.Cf = (float)C; c.Hm1 = (float)(H - 1);
     c.H3 = H * H * H;
+    int e = 0;
+    c.bound_exp = (bound > 0.0f && frexpf(bound, &e) == 0.5f) ? e - 1 : INT_MIN;
     return c;
 }
 
@@ -311,7 +348,7 @@ __device__ __forceinline__ bool uniform_step(float t_base, float dt, float& q) {
 // 64 candidates starting at t_base: lane i gets T_{base+i}, identical rounding to the serial walk
 __device__ __forceinline__ float candidate_t(const MarchCfg& cfg, float t_base, int lane) {
     float t = t_base, q;
-    if (cfg.dt_gamma == 0.0f && uniform_step(t_base, cfg.dt_min, q)) {
+    if (cfg.dt_gamma == 0.0f && uniform_step(t_base, clampf(0.0f, cfg.dt_min, cfg.dt_max), q)) {   // (not dt_min: the clamp yields dt_max when dt_min > dt_max)
         t = t_base + (float)lane * q;                     // exact, see uniform_step
     } else {
 #pragma unroll 8
