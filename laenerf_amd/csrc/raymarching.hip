@@ -1276,10 +1276,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             tend0 = in.tend[index];
         }
     }
-    if (phase >= 0 && cnt0 < n_consumed) {                 // the ray ends in this iteration: it leaves an EMPTY record, so that a
-        if (has_ray) out.cnt[index] = 0u;                  // lookahead that still lists it (run-ahead mode, below) drops it again
-        has_ray = false;
-    }
+    if (phase >= 0 && cnt0 < n_consumed) has_ray = false;  // the ray ends in this iteration
     if (__ballot(has_ray) == 0ull) return;                 // whole wave idle; otherwise ray-less lanes stay as helpers
     uint32_t step = 0;
     if (has_ray) {
@@ -1827,8 +1824,8 @@ static inline uint64_t al256(uint64_t b) { return (b + 255) / 256 * 256; }
 static inline uint64_t frame_seg_elems(uint32_t N) { return (uint64_t)N + (uint64_t)FRAME_SEG_MAX * FRAME_SEG_SLACK; }
 uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_budget) {
     const uint64_t cap = frame_cap(frame_budget(N, row_budget));
-    return 256 /*ctrl x2*/ + 3 * al256(4ull * FRAME_SEG_MAX) /*segment counts x3*/ + 3 * al256(4ull * FRAME_SEG_MAX) /*workgroup sums x3*/ +
-           al256(4ull * N) /*alive*/ + 3 * al256(4 * frame_seg_elems(N)) /*survivor segments x3*/ + al256(32ull * N) /*accumulators*/ +
+    return 256 /*ctrl x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*segment counts x2*/ + 2 * al256(4ull * FRAME_SEG_MAX) /*workgroup sums x2*/ +
+           al256(4ull * N) /*alive*/ + 2 * al256(4 * frame_seg_elems(N)) /*survivor segments x2*/ + al256(32ull * N) /*accumulators*/ +
            2 * al256(4ull * N) /*nears, fars*/ +
            2 * (al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 3 * al256(4ull * N)) /*lookahead records x2: times, edit flags, count, end t, tc*/ +
            2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
@@ -1914,13 +1911,10 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     uint8_t* w = reinterpret_cast<uint8_t*>(workspace);
     auto take = [&](uint64_t bytes) { uint8_t* p = w; w += al256(bytes); return p; };
     FrameCtrl* ctrl = reinterpret_cast<FrameCtrl*>(take(256));
-    // survivor segments in THREE buffers: head(i) writes [i % 3], emit(i+1) / lookahead(i+1) read it, and a lookahead running one
-    // iteration ahead (below) still reads [(i-1) % 3] while head(i+1) writes [(i+1) % 3]
-    uint32_t* seg_counts[3]; uint32_t* blk_counts[3]; int32_t* seg[3];
-    for (int k = 0; k < 3; k++) seg_counts[k] = reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX));
-    for (int k = 0; k < 3; k++) blk_counts[k] = reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX));
+    uint32_t* seg_counts[2] = {reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX)), reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX))};
+    uint32_t* blk_counts[2] = {reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX)), reinterpret_cast<uint32_t*>(take(4ull * FRAME_SEG_MAX))};
     int32_t* alive = reinterpret_cast<int32_t*>(take(4ull * N));
-    for (int k = 0; k < 3; k++) seg[k] = reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N)));
+    int32_t* seg[2] = {reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N))), reinterpret_cast<int32_t*>(take(4 * frame_seg_elems(N)))};
     RayAcc* acc = reinterpret_cast<RayAcc*>(take(32ull * N));
     float* nears = reinterpret_cast<float*>(take(4ull * N));
     float* fars = reinterpret_cast<float*>(take(4ull * N));
@@ -1983,16 +1977,6 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // against 11.40 / 69.1 / 11.73 ms for the 800x800 frame / the 1080p frame / one rank's shard of it: the later start costs
     // the lookahead chain more than the quieter emit kernel gains.)
     static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
-    // RUN-AHEAD.  When the row budget covers max_n_step samples of every ray (budget >= max_n_step * N: one rank's shard of a frame
-    // rendered with the whole frame's budget) every iteration consumes exactly max_n_step samples of every alive ray, whatever
-    // the number of survivors: lookahead(i+1) then needs nothing head(i) produces.  It starts as soon as emit(i) has read the
-    // records it will overwrite, walks the rays of iteration i (a superset of iteration i+1's: a ray the head kernel terminates
-    // is walked once in vain) and is complete long before emit(i+2) asks for it.  Without it the two chains of an iteration start
-    // together and the iteration lasts as long as the longer one plus the handshake -- on the shard the lookahead (123 + 33 us
-    // against 152 us of emit + encoder + head, profiles/r4_*): 11.4 ms per shard, with run-ahead see DESIGN 4b.
-    // LAE_FRAME_RUNAHEAD=0 switches it off (A/B).
-    static const int runahead_env = [] { const char* e = getenv("LAE_FRAME_RUNAHEAD"); return e ? atoi(e) : 1; }();
-    const bool runahead = overlap && runahead_env != 0 && (uint64_t)budget >= (uint64_t)max_n_step * N;
     unsigned long long* flag_go = g_frame.flags;
     unsigned long long* flag_look = g_frame.flags + 1;
     const unsigned long long fbase = (unsigned long long)frame_id << 32;
@@ -2003,13 +1987,8 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     int rc = LAE_OK;
     const uint32_t LAG = 4;
     uint32_t it = 0, nu_prev = 0, R_prev = 0;             // survivor segments (= waves of the previous k_frame_head) and their stride
-    bool loop_over = false;
-    auto join_side = [&]() {
-        // before emit(it): lookahead(it - 1) = flag value `it` (both modes).  After the loop (loop_over; `it` iterations were
-        // launched): everything the side stream was given, so that the caller's stream owns the workspace again -- the last
-        // lookahead launched is lookahead(it - 1), in run-ahead mode lookahead(it)
-        if (!overlap || it == 0) return;
-        k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | (it + ((loop_over && runahead) ? 1u : 0u)), hung_d);
+    auto join_side = [&]() {                               // every exit path: the caller's stream owns the workspace again
+        if (overlap && it > 0) k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | it, hung_d);
     };
     auto abort_frame = [&]() {                             // a launch failed: release whoever polls for work that will never come
         if (overlap) {
@@ -2044,40 +2023,26 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         }
         const FrameCtrl* prev = ctrl + (it & 1u);
         FrameCtrl* cur = ctrl + ((it + 1u) & 1u);
-        const uint32_t p = it & 1u;                        // records read by this iteration: [p]
-        const uint32_t qw = it % 3u, qr = (it + 2u) % 3u;  // segments written by this iteration's head: [qw]; read (head(it-1)'s): [qr]
-        const FrameSegs sg{seg_counts[qr], blk_counts[qr], seg[qr], nu_prev, R_prev};
+        const uint32_t p = it & 1u;                        // segments / counts written by this iteration's head: [p]; read: [p ^ 1]; records read: [p]
+        const FrameSegs sg{seg_counts[p ^ 1u], blk_counts[p ^ 1u], seg[p ^ 1u], nu_prev, R_prev};
         const uint32_t list_waves = nu_prev ? nu_prev * (R_prev / 64u) : lae::cdiv(N, 64);
         const uint32_t rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)budget, (uint64_t)max_n_step * bound_alive);
         const uint32_t rows_launch = (uint32_t)std::min<uint64_t>(frame_padded_rows(rows_bound), cap);
-        if (runahead) {
-            // side chain: lookahead(it + 1) over the rays of iteration it, once emit(it) is done with the records it overwrites
-            if (it == 0) {                                 // lookahead(0) first (it waits for the init kernels and lookahead(-1))
-                k_frame_signal<<<1, 1, 0, s>>>(flag_go, fbase | 1ull);
-                k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | 1ull, hung_d);
-                lookahead(0, ctrl, no_segs, rec[0], rec[1], lae::cdiv(N, 64), N, ls);
-                k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | 1ull);
-            }
-            k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 2u), hung_d);
-            lookahead((int)it + 1, cur, sg, rec[p ^ 1u], rec[p], list_waves, bound_alive, ls);
-            k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | (it + 2u));
-        } else {
-            // side chain: lookahead for the NEXT iteration's samples
-            if (overlap) k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 1u), hung_d);
-            lookahead((int)it, prev, sg, rec[p], rec[p ^ 1u], list_waves, bound_alive, ls);
-            if (overlap) k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | (it + 1u));
-        }
-        // caller's chain: the samples of this iteration come from lookahead(it - 1)
+        // side chain: lookahead for the NEXT iteration's samples
+        if (overlap) k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 1u), hung_d);
+        lookahead((int)it, prev, sg, rec[p], rec[p ^ 1u], list_waves, bound_alive, ls);
+        if (overlap) k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | (it + 1u));
+        // caller's chain: the samples of this iteration come from the previous lookahead
         join_side();
         const uint32_t emit_blocks = lae::cdiv(list_waves, FRAME_BLOCK / 64);
-        unsigned long long* go = (overlap && !runahead) ? flag_go : nullptr;
         if (edit_grid)
             k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
-                                                                xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id, go, fbase | (it + 1u), go_early);
+                                                                xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
+                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
         else
             k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
-                                                                 xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id, go, fbase | (it + 1u), go_early);
-        if (runahead) k_frame_signal<<<1, 1, 0, s>>>(flag_go, fbase | (it + 2u));      // emit(it) is complete (stream order): lookahead(it + 1) may overwrite its records
+                                                                 xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
+                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
                                      gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
         // head + compositing: one wave per run of 64-row groups; the survivors of wave u go, in order, to segment u of
@@ -2085,7 +2050,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         if (rc == LAE_OK) {
             lae::FrameHeadArgs fa;
             fa.cur = cur; fa.alive = alive; fa.deltas = deltas; fa.edit_occ = edit_grid ? edit_occ : nullptr; fa.acc = acc;
-            fa.seg_next = seg[qw]; fa.seg_counts_next = seg_counts[qw]; fa.blk_counts_next = blk_counts[qw]; fa.T_thresh = T_thresh;
+            fa.seg_next = seg[p]; fa.seg_counts_next = seg_counts[p]; fa.blk_counts_next = blk_counts[p]; fa.T_thresh = T_thresh;
             const uint32_t head_blocks = std::max(1u, std::min(lae::cdiv(rows_launch, 64u * lae::FRAME_HEAD_WAVES), lae::frame_head_max_blocks()));
             const uint32_t units = head_blocks * lae::FRAME_HEAD_WAVES;
             fa.R = ((bound_alive / units + 66u + 63u) / 64u) * 64u;
@@ -2101,7 +2066,6 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         if (rc == LAE_OK) rc = lae::check_launch("render_frame");
         if (rc) { abort_frame(); return rc; }
     }
-    loop_over = true;
     join_side();
     k_frame_finish<<<lae::cdiv(N, 256), 256, 0, s>>>(N, nears, fars, acc, weights_sum, depth, image, edit_grid ? weights_edit : nullptr,
                                                      edit_grid ? depth_edit : nullptr, bg_rays, bg_r, bg_g, bg_b, blend_bg, scale_depth);
