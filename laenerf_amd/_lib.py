@@ -136,10 +136,26 @@ def load():
     if tag != ABI_TAG:
         if os.environ.get("LAE_HIP_LIB"):
             raise RuntimeError(f"laenerf_amd: {SO_PATH} is ABI {tag.decode()}, this package binds {ABI_TAG.decode()}")
-        from . import build as _build
-        _build.build(force=True)
-        fresh = SO_PATH + f".{os.getpid()}.reload"
+        # One rebuild per stale library, not one per rank: under torchrun every rank sees the same stale file, so the rebuild is
+        # serialised by an exclusive file lock and skipped by whoever finds the file already fresh (concurrent
+        # builds wrote the same .o / .so paths).  build() itself replaces the .so atomically (temp file + rename).
+        import fcntl
         import shutil
+        from . import build as _build
+        with open(SO_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                probe = SO_PATH + f".{os.getpid()}.probe"
+                shutil.copyfile(SO_PATH, probe)
+                try:
+                    still_stale = _abi_of(probe)[1] != ABI_TAG
+                finally:
+                    os.remove(probe)
+                if still_stale:
+                    _build.build(force=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+        fresh = SO_PATH + f".{os.getpid()}.reload"
         shutil.copyfile(SO_PATH, fresh)
         try:
             lib, tag = _abi_of(fresh)

@@ -212,7 +212,12 @@ class _RayMarching:
             ptr(rows_end), ptr(target), ptr(scale), ptr(weights_sum), ptr(depth), ptr(image), ptr(depth_out), ptr(image_out),
             ptr(grad_image), ptr(grad_sigmas), ptr(grad_rgbs), ptr(loss_out), ptr(partials), int(bool(defer_loss)), stream()),
             "composite_rays_train_step")
-        if defer_loss:
+        if defer_loss and N > 0:                      # N == 0: the library returned at once, there is nothing to finish
+            if _pending_loss and torch.cuda.is_current_stream_capturing():
+                # an older, eagerly made value would be finished INSIDE the capture: its buffers would be baked into the graph
+                # and freed with the entry; refuse instead
+                raise RuntimeError("composite_rays_train_step(defer_loss=True) inside a stream capture while an eager deferred loss is "
+                                   "pending: call laenerf_amd.backend.flush_pending_loss() before capturing")
             flush_pending_loss()                      # an older value nobody finished (no backward ran): finish it now
             _pending_loss[:] = [(partials, (N + 3) // 4, 3 * N, scale, loss_out)]
 
@@ -512,11 +517,16 @@ class _FFMLP:
         if pend is not None and pend[0].device != grad_h.device:
             _pending_loss.append(pend); pend = None
         lp, ln, le, lsc, lo = pend if pend is not None else (None, 0, 0, None, None)
-        check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
-                                                 ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
-                                                 ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
-                                                 ptr(grad_color_weights), int(bool(accumulate)), int(bool(level_major)),
-                                                 nonfinite_flag, ptr(lp), ln, le, ptr(lsc), ptr(lo), stream()), "nerf_head_backward")
+        try:
+            check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
+                                                     ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
+                                                     ptr(grad_h), ptr(grad_enc), ptr(grad_sigma_weights),
+                                                     ptr(grad_color_weights), int(bool(accumulate)), int(bool(level_major)),
+                                                     nonfinite_flag, ptr(lp), ln, le, ptr(lsc), ptr(lo), stream()), "nerf_head_backward")
+        except RuntimeError:
+            if pend is not None:
+                _pending_loss.append(pend)            # the launch failed: the value is still unfinished, flush_pending_loss() can finish it
+            raise
 
     @staticmethod
     def ffmlp_set_mode(mode):

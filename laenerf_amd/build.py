@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(LIBDIR, f"{src.rsplit('.', 1)[0]}.{os.getpid()}.o")   # per-process object names: concurrent builds do not share files
         objs.append(obj)
         cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -55,8 +55,10 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}")
         if verbose and out:
             print(out.decode())
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    tmp_so = SO + f".{os.getpid()}.tmp"                      # link to a temp name, then rename: a reader never maps a half-written library
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so] + objs
     subprocess.check_call(cmd)
+    os.replace(tmp_so, SO)
     for o in objs:
         os.remove(o)
     return SO

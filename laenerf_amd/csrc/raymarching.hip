@@ -1220,7 +1220,7 @@ __device__ int g_look_phase = 20;
 constexpr uint32_t FRAME_LANE_VISITS = 8;      // visits a lane walks alone before the wave decides how to continue
 constexpr int FRAME_QUEUE_MAX = 16;            // the bound when the stragglers go to the finishing kernel (8 / 16 / 24 / 32 / 48: 12.07 / 11.86 / 11.88 / 11.98 / 12.14 ms per frame)
 constexpr int FRAME_MAX_ROUNDS = 1 << 30;      // lane rounds after which ALL unfinished lanes of a wave go to the finishing kernel: never (2: 800x800 11.9 -> 15.1 ms, 1080p 71 -> 92 ms)
-constexpr int FRAME_SPEC = 4;                  // visits of a walk through empty space laid out (and probed) together
+constexpr int FRAME_SPEC = 8;                  // visits of a walk through empty space laid out (and probed) together
 struct LookTask { uint32_t index, step; float t; };   // a ray the lane phase hands to k_frame_lookahead_finish
 constexpr uint32_t FRAME_FINISH_BLOCKS = 1024; // x 4 waves: more than one wave per SIMD, tasks dealt round-robin
 constexpr int FRAME_COOP_MAX = 8;              // unfinished lanes per wave up to which they are finished cooperatively
