@@ -1050,6 +1050,132 @@ __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const flo
     reinterpret_cast<float4*>(acc + n)[1] = make_float4(0.f, t0, 0.f, 0.f);       // image.b, rays_t, weights_edit_sum, depth_edit
 }
 
+// ---- "nothing ahead" test of the lookahead.  The slowest waves of a lookahead launch are those whose rays have left the
+// surface and cross empty space to `far`: 16-25 rounds of 8 visits (130-200 us) while the median wave lives 11 us -- the
+// launch's span is that tail (profiles/r3b_frame_look_stamps.txt).  A walk that will find nothing may simply stop: the reference's
+// walker would visit every cell up to `far`, emit no sample and leave the ray with fewer than n_step samples, which is all the
+// compositing kernel looks at (raymarching.cu:881, 926).  So once per frame the bitfield is reduced to a 32^3 world-space
+// grid of "a sample positioned here could probe an occupied cell of SOME cascade level" (every occupied 2x2x2 block -- one
+// bitfield byte -- dilated by one cell of its level, which covers any rounding in the reference's index arithmetic), and that
+// to a Chebyshev distance field; a lane whose ray is still unfinished after a round sphere-traces the field from t to `far`
+// and, if every point of the rest of the ray keeps at least one coarse cell between itself and any marked cell, is done.
+// Conservative: a failed test changes nothing (the lane walks on), a passed one only skips visits that emit nothing.
+constexpr uint32_t FRAME_CG = 32;              // coarse cells per axis
+constexpr uint32_t FRAME_CG_CAP = 16;          // distances saturate here
+__global__ void k_frame_coarse_mark(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H, float bound, uint32_t* __restrict__ cmask) {
+    const uint32_t per_level = H * H * H / 8u;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= C * per_level) return;
+    if (grid[b] == 0) return;
+    const uint32_t level = b / per_level, m = (b - level * per_level) << 3;
+    const uint32_t vx = morton_compact(m), vy = morton_compact(m >> 1), vz = morton_compact(m >> 2);   // even: the block's low corner
+    const float bl = fminf(scalbnf(1.0f, (int)level), bound), vs = 2.0f * bl / (float)H, inv_s = (float)FRAME_CG / (2.0f * bound);
+    const bool top = level + 1u == C;             // positions beyond the top level's box clamp into its border cells (probe_at)
+    int c0[3], c1[3];
+    const uint32_t v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float lo = -bl + ((float)v[a] - 1.0f) * vs, hi = -bl + ((float)v[a] + 3.0f) * vs;   // cells v-1 .. v+2
+        if (top && v[a] == 0u) lo = -bound;
+        if (top && v[a] + 2u >= H) hi = bound;
+        c0[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((lo + bound) * inv_s)));
+        c1[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((hi + bound) * inv_s)));
+    }
+    const uint32_t xm = (c1[0] >= 31 ? ~0u : ((2u << c1[0]) - 1u)) & ~((1u << c0[0]) - 1u);
+    for (int z = c0[2]; z <= c1[2]; z++)
+        for (int y = c0[1]; y <= c1[1]; y++) {
+            uint32_t* w = cmask + z * (int)FRAME_CG + y;
+            if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & xm) != xm) atomicOr(w, xm);
+        }
+}
+// Chebyshev distance (in coarse cells, saturating at FRAME_CG_CAP) to the nearest marked cell: rounds of 3x3x3 dilation on the
+// 1024 x-rows of the mask held as 32-bit words; one workgroup.
+__global__ __launch_bounds__(1024) void k_frame_coarse_dist(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ cdist) {
+    static_assert(FRAME_CG == 32, "one 32-bit word per x-row");
+    __shared__ uint32_t rows[2][1024];
+    const uint32_t tid = threadIdx.x, y = tid & 31u, z = tid >> 5;
+    uint32_t cur = cmask[tid];
+    for (uint32_t x = 0; x < 32u; x++) cdist[tid * 32u + x] = ((cur >> x) & 1u) ? 0 : (uint8_t)FRAME_CG_CAP;
+    for (uint32_t r = 1; r < FRAME_CG_CAP; r++) {
+        rows[0][tid] = cur | (cur << 1) | (cur >> 1);
+        __syncthreads();
+        uint32_t a = rows[0][tid];
+        if (y > 0) a |= rows[0][tid - 1];
+        if (y < 31) a |= rows[0][tid + 1];
+        rows[1][tid] = a;
+        __syncthreads();
+        uint32_t d = rows[1][tid];
+        if (z > 0) d |= rows[1][tid - 32];
+        if (z < 31) d |= rows[1][tid + 32];
+        uint32_t fresh = d & ~cur;
+        while (fresh) { const uint32_t x = (uint32_t)__builtin_ctz(fresh); fresh &= fresh - 1u; cdist[tid * 32u + x] = (uint8_t)r; }
+        cur = d;
+        __syncthreads();
+    }
+}
+// Per coarse cell and direction octant (bit o = (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2): is the whole sub-box from this cell to
+// the octant's corner of the volume unmarked?  A ray's coordinates are monotone in t, so from a point in this cell it never
+// leaves that sub-box: ONE byte load answers "nothing ahead" for the common case of a ray that has passed the marked region's
+// extent on some axis (the sphere trace below answers the rest, at 5-10 dependent loads).  One workgroup, after k_frame_coarse_mark.
+__global__ __launch_bounds__(1024) void k_frame_coarse_octants(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ coct) {
+    __shared__ uint32_t a[1024], b[1024];
+    const uint32_t tid = threadIdx.x, y = tid & 31u, z = tid >> 5;
+    const uint32_t w = cmask[tid];
+    uint32_t clear[8];
+#pragma unroll
+    for (uint32_t o = 0; o < 8u; o++) {
+        uint32_t s = w;                                    // bit x: a marked cell at x' >= x (dx >= 0) / x' <= x (dx < 0) of this row
+        if (o & 1u) { s |= s << 1; s |= s << 2; s |= s << 4; s |= s << 8; s |= s << 16; }
+        else { s |= s >> 1; s |= s >> 2; s |= s >> 4; s |= s >> 8; s |= s >> 16; }
+        __syncthreads();
+        a[tid] = s;
+        __syncthreads();
+        uint32_t t = 0;
+        if (o & 2u) { for (uint32_t yy = 0; yy <= y; yy++) t |= a[z * 32u + yy]; }
+        else { for (uint32_t yy = y; yy < 32u; yy++) t |= a[z * 32u + yy]; }
+        b[tid] = t;
+        __syncthreads();
+        uint32_t u = 0;
+        if (o & 4u) { for (uint32_t zz = 0; zz <= z; zz++) u |= b[zz * 32u + y]; }
+        else { for (uint32_t zz = z; zz < 32u; zz++) u |= b[zz * 32u + y]; }
+        clear[o] = ~u;
+    }
+    for (uint32_t x = 0; x < 32u; x++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t o = 0; o < 8u; o++) v |= ((clear[o] >> x) & 1u) << o;
+        coct[tid * 32u + x] = (uint8_t)v;
+    }
+}
+__device__ __forceinline__ uint32_t frame_coarse_cell(const Ray& r, float bound, float t) {
+    const float inv_s = (float)FRAME_CG / (2.0f * bound);
+    const int cx = max(0, min((int)FRAME_CG - 1, (int)floorf((fmaf(t, r.dx, r.ox) + bound) * inv_s)));
+    const int cy = max(0, min((int)FRAME_CG - 1, (int)floorf((fmaf(t, r.dy, r.oy) + bound) * inv_s)));
+    const int cz = max(0, min((int)FRAME_CG - 1, (int)floorf((fmaf(t, r.dz, r.oz) + bound) * inv_s)));
+    return (uint32_t)((cz * (int)FRAME_CG + cy) * (int)FRAME_CG + cx);
+}
+// the octant test alone (coct = cdist + FRAME_CG^3)
+__device__ __forceinline__ bool frame_clear_octant(const Ray& r, float bound, float t, const uint8_t* __restrict__ cdist) {
+    const uint32_t o = (r.dx < 0.0f ? 1u : 0u) | (r.dy < 0.0f ? 2u : 0u) | (r.dz < 0.0f ? 4u : 0u);
+    return (cdist[FRAME_CG * FRAME_CG * FRAME_CG + frame_coarse_cell(r, bound, t)] >> o) & 1u;
+}
+// true: no cell the rest of the ray [t, far) could probe is occupied
+__device__ __forceinline__ bool frame_clear_to_far(const Ray& r, float bound, float t, float far, const uint8_t* __restrict__ cdist) {
+    // a step of (D - 1) coarse cells in the largest direction component stays inside the cube of cells D - 1 rings around the
+    // current one, all of them unmarked; 0.98: rounding of the products below
+    const float per_cell = 0.98f * (2.0f * bound / (float)FRAME_CG) / fmaxf(fabsf(r.dx), fmaxf(fabsf(r.dy), fabsf(r.dz)));
+    const uint32_t o = (r.dx < 0.0f ? 1u : 0u) | (r.dy < 0.0f ? 2u : 0u) | (r.dz < 0.0f ? 4u : 0u);
+    for (int it = 0; it < 24; it++) {
+        if (!(t < far)) return true;
+        const uint32_t cell = frame_coarse_cell(r, bound, t);
+        const uint32_t D = cdist[cell];
+        if ((cdist[FRAME_CG * FRAME_CG * FRAME_CG + cell] >> o) & 1u) return true;
+        if (D < 2u) return false;
+        t = fmaf((float)(D - 1u), per_cell, t);
+    }
+    return false;
+}
+
 // Wave-cooperative continuation of ONE ray (state broadcast from lane L): the candidate scheme of k_march_train_wave --
 // 64 consecutive visit candidates T_k per pass, probed in parallel, visited chain resolved from ballots -- recording up
 // to `remaining` sample times at out_t[0..) (+ edit flags).  Exactly the serial walk's samples (same candidate times,
@@ -1059,13 +1185,17 @@ template <bool EDIT>
 __device__ __forceinline__ uint32_t frame_lookahead_coop(const Ray& r, const MarchCfg& cfg, const uint8_t* __restrict__ grid,
                                                          const uint8_t* __restrict__ edit_grid, float t_base, float far,
                                                          uint32_t remaining, float* __restrict__ out_t, uint8_t* __restrict__ out_e,
-                                                         int lane, float& t_end) {
+                                                         int lane, float& t_end, const uint8_t* __restrict__ cdist = nullptr) {
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t emitted = 0;
     bool pending = false;
     float pending_tt = 0.f;
+    uint32_t idle = 0;                                     // passes since the last sample
     t_end = t_base;                                        // the serial walker's t when it stops (wave-uniform)
     while (t_base < far && emitted < remaining) {
+        // every fourth pass without a sample: is anything ahead at all?  (wave-uniform; k_frame_coarse_mark)
+        if (cdist && (idle & 3u) == 3u && frame_clear_to_far(r, cfg.bound, t_base, far, cdist)) { t_end = far; break; }
+        idle++;
         const float t = candidate_t(cfg, t_base, lane);
         const float t_next = t + step_of(cfg, t);
         const bool valid = t < far;
@@ -1109,6 +1239,7 @@ __device__ __forceinline__ uint32_t frame_lookahead_coop(const Ray& r, const Mar
             if (EDIT) out_e[slot] = (edit_grid[p.index >> 3] >> (p.index & 7u)) & 1u;
         }
         emitted += cnt;
+        if (cnt) idle = 0;
         if (emit && emitted >= remaining) {                // sample budget reached: the walker stands right after its last sample
             t_end = __shfl(t_next, 63 - __builtin_clzll(emit), 64);
             break;
@@ -1230,7 +1361,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     uint32_t max_n_step, LookRec in, LookRec out,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
-    uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds) {
+    uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds,
+    const uint8_t* __restrict__ cdist) {
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LOOK_NOTE(0, wall_clock64());
@@ -1321,10 +1453,13 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             }
         }
     }
+    // the first walk of a frame: two thirds of an 800x800 lego frame's rays cross the volume without touching anything
+    if (cdist && phase < 0 && has_ray && t < far && frame_clear_to_far(r, cfg.bound, t, far, cdist)) t = far;
     LOOK_NOTE(1, wall_clock64());
     for (;;) {
         st_rounds++;
         uint32_t visits = 0;                               // lane phase: the reference's walk
+        const uint32_t step_before = step;
         // A lane crossing empty space pays one DEPENDENT bitfield probe per visit, and a wave with more than FRAME_COOP_MAX
         // such lanes keeps walking (8-13 rounds of 8 visits: the slowest waves once the few-straggler case went to the
         // finishing kernel).  The visits of an empty stretch do not depend on what the probes return as long as they
@@ -1375,7 +1510,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             if (!hit) t = tn;
             visits += (uint32_t)nv;
         }
-        const bool unfinished = has_ray && t < far && step < max_n_step;
+        bool unfinished = has_ray && t < far && step < max_n_step;
+        // nothing ahead (see k_frame_coarse_mark): the walk would reach `far` without another sample.  Asked only after a
+        // round that found no sample: a lane inside a surface or about to enter one would ask in vain.
+        if (cdist && unfinished && step == step_before && frame_clear_octant(r, cfg.bound, t, cdist)) { t = far; unfinished = false; }
         unsigned long long um = __ballot(unfinished);
         if (um == 0ull) break;
         // most of the wave is in transit: lanes are well used.  (A wave whose 64 neighbouring rays all leave a surface
@@ -1413,7 +1551,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
             float t_end;
             const uint32_t got = frame_lookahead_coop<EDIT>(rl, cfg, grid, edit_grid, bcast(t, L), bcast(far, L), max_n_step - step_l,
                                                             out.t + (size_t)index_l * FRAME_LA + step_l,
-                                                            EDIT ? out.e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane, t_end);
+                                                            EDIT ? out.e + (size_t)index_l * FRAME_LA + step_l : nullptr, lane, t_end, cdist);
             if (lane == L) { step += got; t = t_end; }
         }
         break;
@@ -1429,7 +1567,7 @@ template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
     uint32_t max_n_step, const uint32_t* __restrict__ q_count, uint32_t* __restrict__ q_count_next, const LookTask* __restrict__ q_tasks,
     LookRec out, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
-    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid) {
+    const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const uint8_t* __restrict__ cdist) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *q_count_next = 0u;
     const uint32_t n_tasks = *q_count;
     const int lane = threadIdx.x & 63;
@@ -1442,7 +1580,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
         float t_end;
         const uint32_t got = frame_lookahead_coop<EDIT>(r, cfg, grid, edit_grid, t, fars[index], max_n_step - step,
                                                         out.t + (size_t)index * FRAME_LA + step,
-                                                        EDIT ? out.e + (size_t)index * FRAME_LA + step : nullptr, lane, t_end);
+                                                        EDIT ? out.e + (size_t)index * FRAME_LA + step : nullptr, lane, t_end, cdist);
         if (lane == 0) { out.cnt[index] = step + got; out.tend[index] = t_end; }
     }
 }
@@ -1453,13 +1591,17 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
 // polls `go`): at its beginning (go_early: the lookahead of this iteration needs nothing this kernel writes -- only that the
 // previous head kernel is complete, which this kernel running proves) or when its last-dispatched workgroup is done (the
 // lookahead then does not compete with this kernel, which is on the caller's critical path, for the memory system).
+constexpr uint32_t EMIT_IMG_ROWS = 64u * FRAME_LA + 4u * (FRAME_LA + 1u) + 28u;      // rows of 64 rays + the padding of the groups they touch; x 32 B + 1 B (edit flag)
+constexpr uint32_t EMIT_IMG_FLOATS = 8u * EMIT_IMG_ROWS + EMIT_IMG_ROWS / 4u;
+static_assert(EMIT_IMG_ROWS % 4u == 0u, "the edit flags follow the floats");
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, FrameSegs sg, uint32_t N, uint32_t row_budget, uint32_t max_steps,
     uint32_t max_n_step, int32_t* __restrict__ alive, LookRec in, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, MarchCfg cfg, float* __restrict__ xyzs, float* __restrict__ dirs,
     float* __restrict__ deltas, uint8_t* __restrict__ edit_occ, const float* __restrict__ noises,
-    FrameMirror* __restrict__ mirror, uint64_t frame_id, unsigned long long* __restrict__ go, unsigned long long go_value, int go_early) {
+    FrameMirror* __restrict__ mirror, uint64_t frame_id, unsigned long long* __restrict__ go, unsigned long long go_value, int go_early,
+    int use_lds) {
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (go && go_early && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1477,6 +1619,61 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
             deltas[2 * (size_t)row] = 0.f; deltas[2 * (size_t)row + 1] = 0.f;
         }
     }
+    // n_step >= 3: a lane's rows are n_step x 32 bytes apart from its neighbour's, every store instruction of the loop below
+    // scatters 64 x 12 (or 8) bytes over 64 x 32 x n_step bytes (the emit kernel of the late iterations, 8 rows per ray, took 28 us
+    // for the rows the early ones write in 11).  The wave's rays are consecutive in the compact order, so their rows (and the
+    // padding rows between them) are ONE contiguous range: the lanes build it in a wave-private LDS image and the wave
+    // stores it with consecutive lanes on consecutive words.
+    extern __shared__ float emit_lds[];
+    if (use_lds && c.n_step >= 3u && !c.done) {
+        const unsigned long long hm = __ballot(f.has);
+        if (hm) {                                              // valid lanes are a prefix of the wave (frame_locate)
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(hm), n_step = c.n_step;
+            float* img = emit_lds + (size_t)(threadIdx.x >> 6) * EMIT_IMG_FLOATS;
+            float* ix = img; float* id = img + 3 * EMIT_IMG_ROWS; float* il = img + 6 * EMIT_IMG_ROWS;
+            uint8_t* ie = reinterpret_cast<uint8_t*>(img + 8 * EMIT_IMG_ROWS);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.n);
+            const uint32_t g0 = n0 / rpg, row0 = g0 * 64u + (n0 - g0 * rpg) * n_step;
+            const uint32_t nl = n0 + cnt - 1u, gl = nl / rpg, sl = nl - gl * rpg;
+            const uint32_t row1 = sl == rpg - 1u ? gl * 64u + 64u : gl * 64u + (sl + 1u) * n_step;   // the last slot of a group takes its padding rows along
+            const uint32_t nrows = row1 - row0;                // <= 64 n_step + 4 (groups + 1) <= EMIT_IMG_ROWS
+            for (uint32_t e = (uint32_t)lane; e < nrows * 2u; e += 64u) il[e] = 0.f;      // deltas == 0 marks "no sample" (and padding)
+            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) { ix[e] = 0.f; id[e] = 0.f; }
+            if (EDIT) for (uint32_t e = (uint32_t)lane; e < nrows; e += 64u) ie[e] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (f.has) {
+                const uint32_t index = f.index;
+                alive[f.n] = (int32_t)index;
+                const Ray r = load_ray(rays_o, rays_d, index);
+                const uint32_t have = min(in.cnt[index], n_step);
+                float last_t = in.tc[index];
+                if (sg.nu == 0) last_t = perturbed_start(cfg, last_t, noises, f.n);
+                const float4 ra = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[0];
+                const float4 rb = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[1];
+                const float st[FRAME_LA] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                unsigned long long ste = 0ull;
+                if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(in.e + (size_t)index * FRAME_LA);
+                const uint32_t grp = f.n / rpg, slot = f.n - grp * rpg;
+                uint32_t lr = grp * 64u + slot * n_step - row0;
+#pragma unroll
+                for (uint32_t j = 0; j < FRAME_LA; j++, lr++) {
+                    if (j >= have) break;
+                    const float t = st[j], dt = step_of(cfg, t), tn = t + dt;
+                    ix[3 * lr] = clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound);
+                    ix[3 * lr + 1] = clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound);
+                    ix[3 * lr + 2] = clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound);
+                    id[3 * lr] = r.dx; id[3 * lr + 1] = r.dy; id[3 * lr + 2] = r.dz;
+                    il[2 * lr] = dt; il[2 * lr + 1] = tn - last_t; last_t = tn;
+                    if (EDIT) ie[lr] = (uint8_t)(ste >> (8u * j));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                    // wave-private image: one wave's LDS accesses execute in order, nothing to wait for
+            float* ox = xyzs + 3 * (size_t)row0; float* od = dirs + 3 * (size_t)row0; float* ol = deltas + 2 * (size_t)row0;
+            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) { ox[e] = ix[e]; od[e] = id[e]; }
+            for (uint32_t e = (uint32_t)lane; e < nrows * 2u; e += 64u) ol[e] = il[e];
+            if (EDIT) for (uint32_t e = (uint32_t)lane; e < nrows; e += 64u) edit_occ[row0 + e] = ie[e];
+        }
+    } else
     if (!c.done && f.has) {
     const uint32_t n = f.n, n_step = c.n_step;
     const uint32_t index = f.index;
@@ -1830,7 +2027,8 @@ uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_b
            2 * (al256(4ull * FRAME_LA * N) + al256((uint64_t)FRAME_LA * N) + 3 * al256(4ull * N)) /*lookahead records x2: times, edit flags, count, end t, tc*/ +
            2 * al256(12 * cap) /*xyzs, dirs*/ + al256(8 * cap) /*deltas*/ + al256(cap) /*edit_occ*/ +
            al256((uint64_t)L * cap * 4) /*features [L,cap,2] fp16*/ +
-           256 /*straggler task counters x2*/ + al256(12ull * N) /*straggler tasks*/;
+           256 /*straggler task counters x2*/ + al256(12ull * N) /*straggler tasks*/ +
+           al256(4ull * FRAME_CG * FRAME_CG) + al256(2ull * FRAME_CG * FRAME_CG * FRAME_CG) /*coarse mask, distance field + octant flags*/;
 }
 
 namespace {
@@ -1934,6 +2132,10 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     uint32_t* q_counts = reinterpret_cast<uint32_t*>(take(256));            // [2], used alternately by consecutive lookaheads
     LookTask* q_tasks = reinterpret_cast<LookTask*>(take(12ull * N));
     static_assert(sizeof(LookTask) == 12, "LookTask layout");
+    uint32_t* cmask = reinterpret_cast<uint32_t*>(take(4ull * FRAME_CG * FRAME_CG));
+    uint8_t* cdist_buf = take(2ull * FRAME_CG * FRAME_CG * FRAME_CG);   // distances, then octant flags
+    static const bool coarse_on = [] { const char* e = getenv("LAE_FRAME_COARSE"); return !e || atoi(e) != 0; }();   // 0: no "nothing ahead" test (A/B)
+    const uint8_t* cdist = coarse_on && H >= 2 && (H & (H - 1u)) == 0u ? cdist_buf : nullptr;   // Morton bytes are 2x2x2 blocks when H is a power of two
     static const bool finish_queue = [] { const char* e = getenv("LAE_FRAME_FINISH_QUEUE"); return !e || atoi(e) != 0; }();   // 0: stragglers finished inside the lane kernel (A/B)
     static const int spec_visits = [] { const char* e = getenv("LAE_FRAME_SPEC"); return e ? atoi(e) : 1; }();   // 0: every visit waits for its own probe (A/B)
     static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
@@ -1955,16 +2157,22 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max, max_rounds);
-            if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid);
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max, max_rounds, cdist);
+            if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid, cdist);
         } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds);
-            if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr);
+                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds, cdist);
+            if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr, cdist);
         }
     };
     k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
     k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, acc, rec[0].tc, q_counts);
+    if (cdist) {                                          // the bitfield is the caller's and may have changed since the last frame
+        if (hipMemsetAsync(cmask, 0, 4ull * FRAME_CG * FRAME_CG, s) != hipSuccess) return LAE_ELAUNCH;
+        k_frame_coarse_mark<<<lae::cdiv(C * (H * H * H / 8u), 256), 256, 0, s>>>(grid, C, H, bound, cmask);
+        k_frame_coarse_dist<<<1, 1024, 0, s>>>(cmask, cdist_buf);
+        k_frame_coarse_octants<<<1, 1024, 0, s>>>(cmask, cdist_buf + FRAME_CG * FRAME_CG * FRAME_CG);
+    }
     const FrameSegs no_segs{nullptr, nullptr, nullptr, 0u, 0u};
     lookahead(-1, nullptr, no_segs, rec[0], rec[0], lae::cdiv(N, 64), N, s);
     // Two chains per iteration i (records double-buffered: emit(i) and lookahead(i) read buffer i & 1 and the survivor
@@ -1976,6 +2184,9 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // lookahead's loads do not compete with the emit kernel on the caller's critical path -- measured 11.83 / 69.8 / 12.47 ms
     // against 11.40 / 69.1 / 11.73 ms for the 800x800 frame / the 1080p frame / one rank's shard of it: the later start costs
     // the lookahead chain more than the quieter emit kernel gains.)
+    // rows of n_step >= 3 iterations through a wave-private LDS image (k_frame_emit); the host knows a lagging bound of n_alive,
+    // so whether an iteration can have n_step >= 3 at all (budget / bound_alive >= 3) decides if the launch asks for the LDS
+    static const int emit_lds_on = [] { const char* e = getenv("LAE_FRAME_EMIT_LDS"); return e ? (atoi(e) != 0) : 1; }();
     static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
     unsigned long long* flag_go = g_frame.flags;
     unsigned long long* flag_look = g_frame.flags + 1;
@@ -2035,14 +2246,16 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         // caller's chain: the samples of this iteration come from the previous lookahead
         join_side();
         const uint32_t emit_blocks = lae::cdiv(list_waves, FRAME_BLOCK / 64);
+        const int emit_lds = emit_lds_on && max_n_step >= 3u && (uint64_t)budget >= 3ull * bound_alive ? 1 : 0;
+        const uint32_t emit_lds_bytes = emit_lds ? (FRAME_BLOCK / 64) * EMIT_IMG_FLOATS * 4u : 0u;
         if (edit_grid)
-            k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+            k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                 xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
-                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
+                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds);
         else
-            k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+            k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                  xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
-                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
+                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds);
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
                                      gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
         // head + compositing: one wave per run of 64-row groups; the survivors of wave u go, in order, to segment u of
