@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
 // previous head kernel is complete, which this kernel running proves) or when its last-dispatched workgroup is done (the
 // lookahead then does not compete with this kernel, which is on the caller's critical path, for the memory system).
 constexpr uint32_t EMIT_IMG_ROWS = 64u * FRAME_LA + 4u * (FRAME_LA + 1u) + 28u;      // rows of 64 rays + the padding of the groups they touch; x 32 B + 1 B (edit flag)
-constexpr uint32_t EMIT_IMG_FLOATS = 8u * EMIT_IMG_ROWS + EMIT_IMG_ROWS / 4u;
+constexpr uint32_t EMIT_IMG_FLOATS = 5u * EMIT_IMG_ROWS + 256u + EMIT_IMG_ROWS / 4u;   // xyz + delta rows, 64 x (direction, samples held), edit flags
 static_assert(EMIT_IMG_ROWS % 4u == 0u, "the edit flags follow the floats");
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
@@ -1625,22 +1625,18 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     // padding rows between them) are ONE contiguous range: the lanes build it in a wave-private LDS image and the wave
     // stores it with consecutive lanes on consecutive words.
     extern __shared__ float emit_lds[];
-    if (use_lds && c.n_step >= 3u && !c.done) {
+    if (use_lds && c.n_step >= (uint32_t)use_lds && !c.done) {
         const unsigned long long hm = __ballot(f.has);
         if (hm) {                                              // valid lanes are a prefix of the wave (frame_locate)
             const uint32_t cnt = (uint32_t)__builtin_popcountll(hm), n_step = c.n_step;
             float* img = emit_lds + (size_t)(threadIdx.x >> 6) * EMIT_IMG_FLOATS;
-            float* ix = img; float* id = img + 3 * EMIT_IMG_ROWS; float* il = img + 6 * EMIT_IMG_ROWS;
-            uint8_t* ie = reinterpret_cast<uint8_t*>(img + 8 * EMIT_IMG_ROWS);
+            float* ix = img; float* il = img + 3 * EMIT_IMG_ROWS; float* idr = img + 5 * EMIT_IMG_ROWS;   // xyz rows, delta rows, per RAY: direction + samples held
+            uint8_t* ie = reinterpret_cast<uint8_t*>(img + 5 * EMIT_IMG_ROWS + 256);
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.n);
             const uint32_t g0 = n0 / rpg, row0 = g0 * 64u + (n0 - g0 * rpg) * n_step;
             const uint32_t nl = n0 + cnt - 1u, gl = nl / rpg, sl = nl - gl * rpg;
             const uint32_t row1 = sl == rpg - 1u ? gl * 64u + 64u : gl * 64u + (sl + 1u) * n_step;   // the last slot of a group takes its padding rows along
             const uint32_t nrows = row1 - row0;                // <= 64 n_step + 4 (groups + 1) <= EMIT_IMG_ROWS
-            for (uint32_t e = (uint32_t)lane; e < nrows * 2u; e += 64u) il[e] = 0.f;      // deltas == 0 marks "no sample" (and padding)
-            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) { ix[e] = 0.f; id[e] = 0.f; }
-            if (EDIT) for (uint32_t e = (uint32_t)lane; e < nrows; e += 64u) ie[e] = 0;
-            __builtin_amdgcn_wave_barrier();
             if (f.has) {
                 const uint32_t index = f.index;
                 alive[f.n] = (int32_t)index;
@@ -1655,21 +1651,38 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
                 if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(in.e + (size_t)index * FRAME_LA);
                 const uint32_t grp = f.n / rpg, slot = f.n - grp * rpg;
                 uint32_t lr = grp * 64u + slot * n_step - row0;
+                idr[4 * lane] = r.dx; idr[4 * lane + 1] = r.dy; idr[4 * lane + 2] = r.dz; idr[4 * lane + 3] = __uint_as_float(have);
 #pragma unroll
                 for (uint32_t j = 0; j < FRAME_LA; j++, lr++) {
-                    if (j >= have) break;
+                    if (j >= n_step) break;                    // uniform
+                    const bool real = j < have;                // the reference's buffers are torch.zeros
                     const float t = st[j], dt = step_of(cfg, t), tn = t + dt;
-                    ix[3 * lr] = clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound);
-                    ix[3 * lr + 1] = clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound);
-                    ix[3 * lr + 2] = clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound);
-                    id[3 * lr] = r.dx; id[3 * lr + 1] = r.dy; id[3 * lr + 2] = r.dz;
-                    il[2 * lr] = dt; il[2 * lr + 1] = tn - last_t; last_t = tn;
-                    if (EDIT) ie[lr] = (uint8_t)(ste >> (8u * j));
+                    ix[3 * lr] = real ? clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound) : 0.f;
+                    ix[3 * lr + 1] = real ? clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound) : 0.f;
+                    ix[3 * lr + 2] = real ? clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound) : 0.f;
+                    il[2 * lr] = real ? dt : 0.f; il[2 * lr + 1] = real ? tn - last_t : 0.f;
+                    if (real) last_t = tn;
+                    if (EDIT) ie[lr] = real ? (uint8_t)(ste >> (8u * j)) : (uint8_t)0;
                 }
+                if (slot == rpg - 1u)                          // the group's padding rows (n_step = 3, 5, 6, 7: at most 4)
+                    for (uint32_t pr = rpg * n_step; pr < 64u; pr++) {
+                        const uint32_t q = grp * 64u + pr - row0;
+                        ix[3 * q] = 0.f; ix[3 * q + 1] = 0.f; ix[3 * q + 2] = 0.f; il[2 * q] = 0.f; il[2 * q + 1] = 0.f;
+                        if (EDIT) ie[q] = 0;
+                    }
             }
             __builtin_amdgcn_wave_barrier();                    // wave-private image: one wave's LDS accesses execute in order, nothing to wait for
             float* ox = xyzs + 3 * (size_t)row0; float* od = dirs + 3 * (size_t)row0; float* ol = deltas + 2 * (size_t)row0;
-            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) { ox[e] = ix[e]; od[e] = id[e]; }
+            const uint32_t inv_ns = 65536u / n_step + 1u;      // pos / n_step for pos < 64 (checked exhaustively)
+            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) {
+                ox[e] = ix[e];
+                const uint32_t lr = (e * 21846u) >> 16, comp = e - 3u * lr;        // e / 3 for e < 4096
+                const uint32_t row = row0 + lr, pos = row & 63u, slot = (pos * inv_ns) >> 16, j = pos - slot * n_step;
+                const uint32_t rl = min((row >> 6) * rpg + min(slot, rpg - 1u) - n0, 63u);
+                const float4 dh = reinterpret_cast<const float4*>(idr)[rl];
+                const float dv = comp == 0u ? dh.x : comp == 1u ? dh.y : dh.z;
+                od[e] = (slot < rpg && j < __float_as_uint(dh.w)) ? dv : 0.f;
+            }
             for (uint32_t e = (uint32_t)lane; e < nrows * 2u; e += 64u) ol[e] = il[e];
             if (EDIT) for (uint32_t e = (uint32_t)lane; e < nrows; e += 64u) edit_occ[row0 + e] = ie[e];
         }
@@ -2186,7 +2199,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // the lookahead chain more than the quieter emit kernel gains.)
     // rows of n_step >= 3 iterations through a wave-private LDS image (k_frame_emit); the host knows a lagging bound of n_alive,
     // so whether an iteration can have n_step >= 3 at all (budget / bound_alive >= 3) decides if the launch asks for the LDS
-    static const int emit_lds_on = [] { const char* e = getenv("LAE_FRAME_EMIT_LDS"); return e ? (atoi(e) != 0) : 1; }();
+    static const int emit_lds_min = [] { const char* e = getenv("LAE_FRAME_EMIT_LDS"); return e ? atoi(e) : 3; }();   // smallest n_step that takes the LDS path; 0: never (A/B)
     static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
     unsigned long long* flag_go = g_frame.flags;
     unsigned long long* flag_look = g_frame.flags + 1;
@@ -2246,7 +2259,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         // caller's chain: the samples of this iteration come from the previous lookahead
         join_side();
         const uint32_t emit_blocks = lae::cdiv(list_waves, FRAME_BLOCK / 64);
-        const int emit_lds = emit_lds_on && max_n_step >= 3u && (uint64_t)budget >= 3ull * bound_alive ? 1 : 0;
+        const int emit_lds = emit_lds_min >= 3 && max_n_step >= (uint32_t)emit_lds_min && (uint64_t)budget >= (uint64_t)emit_lds_min * bound_alive ? emit_lds_min : 0;
         const uint32_t emit_lds_bytes = emit_lds ? (FRAME_BLOCK / 64) * EMIT_IMG_FLOATS * 4u : 0u;
         if (edit_grid)
             k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
