@@ -1377,6 +1377,21 @@ static float fwd_level_cost(bool hashed, uint32_t resolution) {
     if (lr <= 10.0f) return 2.3f + (lr - 9.1f) * (2.2f / 0.9f);
     return 4.5f;
 }
+// The same for a FRAME's rows (ray-major: neighbouring rows are neighbouring samples of one ray, neighbouring rays neighbouring
+// pixels), from per-block stamps of frame-loop launches (tools/frame_grid_spans.py, profiles/r4_frame_grid_spans.txt): a level
+// alone on an XCD took 27 / 32 / 33 / 39 / 40 / 44 / 46 / 54 / 58 / 71 / 83 us for resolutions 80 ... 2048 and a dense level 21 --
+// the finest levels cost 2.8-4x a dense one, not 4.5x, and rise steadily instead of jumping at ~1000: with the training table
+// the XCDs that carry ONE fine level finished at 58 / 71 us of an 87 us launch.
+static float fwd_level_cost_frame(bool hashed, uint32_t resolution) {
+    if (!hashed) return 1.0f;
+    const float lr = log2f((float)resolution);
+    if (lr <= 6.3f) return 1.29f;
+    if (lr <= 9.1f) return 1.29f + (lr - 6.3f) * (0.91f / 2.8f);
+    return 2.2f + (lr - 9.1f) * (1.75f / 1.9f);
+}
+static int g_fwd_frame_sched = -1;                         // LAE_GRID_FWD_FRAME_SCHED: 0 training table, 1 (default) frame table, 2 frame table + the costliest levels in halves
+// (measured, 800x800 / 1080p / one rank's shard of it: 0: 10.9 / 67.2 / 11.15 ms, 1: 10.95 / 62.2 / 10.9, 2: 11.1 / 63.7 / 10.9 -- a level in two
+// halves costs 2 x 48 us against 83 whole: its table then streams into two L2s)
 static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // level l on XCD l mod 8, one level at a time
     for (int x = 0; x < 8; x++) fs.nseg[x] = 0;
     for (uint32_t l = 0; l < L; l++) {
@@ -1385,23 +1400,35 @@ static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // le
     }
 }
 // returns the largest number of blocks any XCD owns
-static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const int32_t* offs) {
+static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const int32_t* offs, bool frame = false) {
     bool ok = offs != nullptr && L <= 32 && nb >= 64;
     float cost[MAX_LEVELS]; bool dense[MAX_LEVELS];
+    if (g_fwd_frame_sched < 0) { const char* e = getenv("LAE_GRID_FWD_FRAME_SCHED"); g_fwd_frame_sched = e ? atoi(e) : 1; }
+    const int fmode = frame ? g_fwd_frame_sched : 0;
     if (ok) {
+        float total = 0.f;
         for (uint32_t l = 0; l < L; l++) {
             const uint32_t res = (uint32_t)ceilf(sc.scale[l]) + 1;
             const uint64_t size = (uint64_t)(offs[l + 1] - offs[l]);
             const uint64_t full = (uint64_t)(res + 1) * (res + 1) * (res + 1);
             dense[l] = full <= size;
-            cost[l] = fwd_level_cost(!dense[l], res);
+            cost[l] = fmode ? fwd_level_cost_frame(!dense[l], res) : fwd_level_cost(!dense[l], res);
+            total += cost[l];
         }
-        struct Item { float cost; uint32_t level; bool piece; };
+        // a whole hashed level is one item (its 2 MB table then lives in ONE L2); in a frame a level that alone exceeds an XCD's
+        // fair share would set the launch's span, so it goes out as two halves of its chunk range (two L2s hold its table)
+        struct Item { float cost; uint32_t level; bool piece; uint32_t c0, n; };
         std::vector<Item> items;
         const uint32_t piece = lae::cdiv(nb, 8u);
         for (uint32_t l = 0; l < L; l++) {
-            if (!dense[l]) items.push_back(Item{cost[l] * nb, l, false});
-            else for (uint32_t k = 0; k < 8 && k * piece < nb; k++) items.push_back(Item{cost[l] * std::min(piece, nb - k * piece), l, true});
+            if (!dense[l]) {
+                if (fmode == 2 && cost[l] > 0.97f * total / 8.0f) {
+                    const uint32_t h = nb / 2;
+                    items.push_back(Item{cost[l] * h, l, false, 0u, h});
+                    items.push_back(Item{cost[l] * (nb - h), l, false, h, nb - h});
+                } else items.push_back(Item{cost[l] * nb, l, false, 0u, nb});
+            }
+            else for (uint32_t k = 0; k < 8 && k * piece < nb; k++) items.push_back(Item{cost[l] * std::min(piece, nb - k * piece), l, true, 0u, 0u});
         }
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
         float load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1412,7 +1439,7 @@ static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const Lev
             for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
             load[best] += it.cost;
             if (it.piece) pieces[best][it.level]++;
-            else if (fs.nseg[best] < FWD_MAX_SEG) fs.seg[best][fs.nseg[best]++] = FwdSeg{it.level, 0u, nb};
+            else if (fs.nseg[best] < FWD_MAX_SEG) fs.seg[best][fs.nseg[best]++] = FwdSeg{it.level, it.c0, it.n};
             else ok = false;
         }
         for (uint32_t l = 0; l < L && ok; l++) {
@@ -1444,7 +1471,7 @@ static void launch_fwd(const FwdArgs& a) {
     if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
         if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
             FwdSched fs;
-            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr);
+            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr);
             k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
                                                                       fs, a.os_b, a.os_l, a.B_dev);
             return;

@@ -1090,9 +1090,11 @@ __global__ void k_frame_coarse_mark(const uint8_t* __restrict__ grid, uint32_t C
 }
 // Chebyshev distance (in coarse cells, saturating at FRAME_CG_CAP) to the nearest marked cell: rounds of 3x3x3 dilation on the
 // 1024 x-rows of the mask held as 32-bit words; one workgroup.
+__device__ __forceinline__ void frame_coarse_octants(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ coct, uint32_t (*rows)[1024]);
 __global__ __launch_bounds__(1024) void k_frame_coarse_dist(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ cdist) {
     static_assert(FRAME_CG == 32, "one 32-bit word per x-row");
     __shared__ uint32_t rows[2][1024];
+    if (blockIdx.x == 1) { frame_coarse_octants(cmask, cdist + FRAME_CG * FRAME_CG * FRAME_CG, rows); return; }   // the second workgroup: the octant flags
     const uint32_t tid = threadIdx.x, y = tid & 31u, z = tid >> 5;
     uint32_t cur = cmask[tid];
     for (uint32_t x = 0; x < 32u; x++) cdist[tid * 32u + x] = ((cur >> x) & 1u) ? 0 : (uint8_t)FRAME_CG_CAP;
@@ -1116,9 +1118,9 @@ __global__ __launch_bounds__(1024) void k_frame_coarse_dist(const uint32_t* __re
 // Per coarse cell and direction octant (bit o = (dx < 0) | (dy < 0) << 1 | (dz < 0) << 2): is the whole sub-box from this cell to
 // the octant's corner of the volume unmarked?  A ray's coordinates are monotone in t, so from a point in this cell it never
 // leaves that sub-box: ONE byte load answers "nothing ahead" for the common case of a ray that has passed the marked region's
-// extent on some axis (the sphere trace below answers the rest, at 5-10 dependent loads).  One workgroup, after k_frame_coarse_mark.
-__global__ __launch_bounds__(1024) void k_frame_coarse_octants(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ coct) {
-    __shared__ uint32_t a[1024], b[1024];
+// extent on some axis (the sphere trace below answers the rest, at 5-10 dependent loads).  Workgroup 1 of k_frame_coarse_dist.
+__device__ __forceinline__ void frame_coarse_octants(const uint32_t* __restrict__ cmask, uint8_t* __restrict__ coct, uint32_t (*rows)[1024]) {
+    uint32_t* a = rows[0]; uint32_t* b = rows[1];
     const uint32_t tid = threadIdx.x, y = tid & 31u, z = tid >> 5;
     const uint32_t w = cmask[tid];
     uint32_t clear[8];
@@ -2154,6 +2156,9 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
     const int coop_max = coop_max_env >= 0 ? coop_max_env : (finish_queue ? FRAME_QUEUE_MAX : FRAME_COOP_MAX);
     static const int max_rounds = [] { const char* e = getenv("LAE_FRAME_MAX_ROUNDS"); return e ? atoi(e) : FRAME_MAX_ROUNDS; }();
+    // the first walk of a frame is another regime: every ray that hits anything first crosses empty space, a wave's lanes finish
+    // at very different times and a low bound sends tens of thousands of rays to the one-wave-per-ray kernel
+    static const int coop_max0 = [] { const char* e = getenv("LAE_FRAME_COOP_MAX0"); return e ? atoi(e) : 0; }();   // -1: as the loop's; sweep -1 / 0 / 2 / 4 / 8 / 32: 10.80 / 10.70 / 10.81 / 10.79 / 10.82 / 11.09 ms at 800x800
     uint32_t look_no = 0;
 
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
@@ -2170,11 +2175,11 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, coop_max, max_rounds, cdist);
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist);
             if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid, cdist);
         } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, coop_max, max_rounds, cdist);
+                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist);
             if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr, cdist);
         }
     };
@@ -2183,8 +2188,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     if (cdist) {                                          // the bitfield is the caller's and may have changed since the last frame
         if (hipMemsetAsync(cmask, 0, 4ull * FRAME_CG * FRAME_CG, s) != hipSuccess) return LAE_ELAUNCH;
         k_frame_coarse_mark<<<lae::cdiv(C * (H * H * H / 8u), 256), 256, 0, s>>>(grid, C, H, bound, cmask);
-        k_frame_coarse_dist<<<1, 1024, 0, s>>>(cmask, cdist_buf);
-        k_frame_coarse_octants<<<1, 1024, 0, s>>>(cmask, cdist_buf + FRAME_CG * FRAME_CG * FRAME_CG);
+        k_frame_coarse_dist<<<2, 1024, 0, s>>>(cmask, cdist_buf);
     }
     const FrameSegs no_segs{nullptr, nullptr, nullptr, 0u, 0u};
     lookahead(-1, nullptr, no_segs, rec[0], rec[0], lae::cdiv(N, 64), N, s);
@@ -2230,7 +2234,13 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         // n_alive to 0 only together with done), and a zero bound would size the next launches to zero workgroups
         if (dn || na == 0) done = true;
     };
+#ifdef LAE_GRID_STAMPS
+    static const uint32_t stop_after = [] { const char* e = getenv("LAE_FRAME_STOP_AFTER"); return e ? (uint32_t)atoi(e) : 0u; }();   // probe builds: the frame ends after that many iterations (tools/frame_grid_spans.py)
+#endif
     for (; it <= max_steps && !done; it++) {
+#ifdef LAE_GRID_STAMPS
+        if (stop_after && it >= stop_after) break;
+#endif
         poll();
         if (done) break;
         if (it >= seen_iter + LAG) {                       // do not run further ahead than LAG iterations
