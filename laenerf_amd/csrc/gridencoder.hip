@@ -38,7 +38,7 @@ __constant__ uint32_t k_primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2
 // in-kernel phase stamps of the binned backward for tools/grid_bwd_stamps.py (compiled in only with -DLAE_GRID_STAMPS: the
 // 100 MHz wall clock as thread 0 of a block passes each phase; slot = block, 32 stamps each)
 #ifdef LAE_GRID_STAMPS
-__device__ unsigned long long g_grid_stamps[8192 * 32];
+__device__ unsigned long long g_grid_stamps[32768 * 32];     // (8 MB, probe builds only: a 1080p frame's encoder launch is 216 k blocks)
 #define GRID_STAMP(slot, i) do { if (threadIdx.x == 0 && (uint32_t)(i) < 32u) g_grid_stamps[(size_t)(slot) * 32 + (i)] = wall_clock64(); } while (0)
 #define GRID_NOTE(slot, i, v) do { if (threadIdx.x == 0 && (uint32_t)(i) < 32u) g_grid_stamps[(size_t)(slot) * 32 + (i)] = (v); } while (0)
 #else
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd(
 //    levels, one 64-byte sector per (y, z) corner row and sample: ~57 us per level and 433 k samples whatever the
 //    kernel does), so whole hashed levels are packed longest-first and the cheap dense levels (tables <= 0.8 MB, harmless
 //    to replicate in several L2s) fill the gaps in eighths.
-struct FwdSeg { uint32_t level, c0, n; };                  // chunks [c0, c0 + n) of `level`
+struct FwdSeg { uint32_t level, c0, n, cnt; };             // chunks [c0, c0 + n) of `level`; cnt > 0: the n chunks (j / cnt) * 8 + c0 + j % cnt instead (residues c0 .. c0 + cnt - 1 mod 8)
 constexpr int FWD_MAX_SEG = 12;
 struct FwdSched { uint32_t nseg[8]; FwdSeg seg[8][FWD_MAX_SEG]; };
 
@@ -306,7 +306,12 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     const uint32_t ns = sched.nseg[xcd];
     for (uint32_t q = 0; q < ns; q++) {
         const uint32_t n = sched.seg[xcd][q].n;
-        if (j < n) { level = sched.seg[xcd][q].level; chunk = sched.seg[xcd][q].c0 + j; break; }
+        if (j < n) {
+            const uint32_t cnt = sched.seg[xcd][q].cnt;
+            level = sched.seg[xcd][q].level;
+            chunk = cnt ? (j / cnt) * 8u + sched.seg[xcd][q].c0 + j % cnt : sched.seg[xcd][q].c0 + j;
+            break;
+        }
         j -= n;
     }
     if (level == 0xffffffffu) return;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     const half2_t h2 = {r0, r1};
     *out = h2;
 #ifdef LAE_GRID_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
+    if (threadIdx.x == 0 && blockIdx.x < 32768u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
         g_grid_stamps[(size_t)blockIdx.x * 4] = st_t0; g_grid_stamps[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_grid_stamps[(size_t)blockIdx.x * 4 + 2] = level;
     }
 #endif
@@ -1359,6 +1364,7 @@ struct FwdArgs {
     void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
     const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
     const int32_t* offsets_host = nullptr;                      // the caller's host copy of `offsets` (L + 1 ints) or NULL
+    const float* level_cost = nullptr;                          // frame loop: measured per-level chunk costs (balance only) or NULL
 };
 
 // ---- schedule of k_grid_fwd_lean (see the kernel's header).  Relative cost of one chunk of a level, calibrated on the
@@ -1396,11 +1402,12 @@ static void fwd_sched_default(FwdSched& fs, uint32_t L, uint32_t nb) {     // le
     for (int x = 0; x < 8; x++) fs.nseg[x] = 0;
     for (uint32_t l = 0; l < L; l++) {
         const uint32_t x = l & 7u;
-        fs.seg[x][fs.nseg[x]++] = FwdSeg{l, 0u, nb};
+        fs.seg[x][fs.nseg[x]++] = FwdSeg{l, 0u, nb, 0u};
     }
 }
 // returns the largest number of blocks any XCD owns
-static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const int32_t* offs, bool frame = false) {
+static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const LevelScales& sc, const int32_t* offs, bool frame = false,
+                                const float* cost_override = nullptr) {
     bool ok = offs != nullptr && L <= 32 && nb >= 64;
     float cost[MAX_LEVELS]; bool dense[MAX_LEVELS];
     if (g_fwd_frame_sched < 0) { const char* e = getenv("LAE_GRID_FWD_FRAME_SCHED"); g_fwd_frame_sched = e ? atoi(e) : 1; }
@@ -1413,6 +1420,7 @@ static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const Lev
             const uint64_t full = (uint64_t)(res + 1) * (res + 1) * (res + 1);
             dense[l] = full <= size;
             cost[l] = fmode ? fwd_level_cost_frame(!dense[l], res) : fwd_level_cost(!dense[l], res);
+            if (frame && cost_override) cost[l] = cost_override[l];
             total += cost[l];
         }
         // a whole hashed level is one item (its 2 MB table then lives in ONE L2); in a frame a level that alone exceeds an XCD's
@@ -1439,16 +1447,28 @@ static uint32_t fwd_sched_build(FwdSched& fs, uint32_t L, uint32_t nb, const Lev
             for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
             load[best] += it.cost;
             if (it.piece) pieces[best][it.level]++;
-            else if (fs.nseg[best] < FWD_MAX_SEG) fs.seg[best][fs.nseg[best]++] = FwdSeg{it.level, it.c0, it.n};
+            else if (fs.nseg[best] < FWD_MAX_SEG) fs.seg[best][fs.nseg[best]++] = FwdSeg{it.level, it.c0, it.n, 0u};
             else ok = false;
         }
         for (uint32_t l = 0; l < L && ok; l++) {
             if (!dense[l]) continue;
             uint32_t c0 = 0;
+            if (fmode) {
+                // a frame's launch is sized by a host BOUND of the row count: the chunks beyond the live rows are empty, and with
+                // contiguous eighths the XCDs holding the last ones would idle while the first ones do all of a dense level
+                // (1080p frame: 86-93 us of dense work on two XCDs, 6 on another) -- an XCD takes every 8th chunk instead
+                for (int x = 0; x < 8; x++) {
+                    if (!pieces[x][l]) continue;
+                    if (fs.nseg[x] < FWD_MAX_SEG) fs.seg[x][fs.nseg[x]++] = FwdSeg{l, c0, lae::cdiv(nb, 8u) * pieces[x][l], pieces[x][l]}; else ok = false;
+                    c0 += pieces[x][l];
+                }
+                if (c0 != std::min(8u, lae::cdiv(nb, piece))) ok = false;
+                continue;
+            }
             for (int x = 0; x < 8; x++) {
                 if (!pieces[x][l]) continue;
                 const uint32_t n = std::min(pieces[x][l] * piece, nb - c0);
-                if (fs.nseg[x] < FWD_MAX_SEG) fs.seg[x][fs.nseg[x]++] = FwdSeg{l, c0, n}; else ok = false;
+                if (fs.nseg[x] < FWD_MAX_SEG) fs.seg[x][fs.nseg[x]++] = FwdSeg{l, c0, n, 0u}; else ok = false;
                 c0 += n;
             }
             if (c0 != nb) ok = false;
@@ -1471,7 +1491,12 @@ static void launch_fwd(const FwdArgs& a) {
     if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
         if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
             FwdSched fs;
-            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr);
+            static const std::vector<float> env_cost = [] {      // probe: LAE_GRID_FWD_COSTS="c0,c1,...": per-level chunk costs of frame launches
+                std::vector<float> v; const char* e = getenv("LAE_GRID_FWD_COSTS");
+                while (e && *e) { char* end; v.push_back(strtof(e, &end)); if (end == e) break; e = *end ? end + 1 : end; }
+                return v; }();
+            const float* co = a.level_cost ? a.level_cost : (env_cost.size() >= a.L ? env_cost.data() : nullptr);
+            const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr, co);
             k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
                                                                       fs, a.os_b, a.os_l, a.B_dev);
             return;

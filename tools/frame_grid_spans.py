@@ -35,7 +35,7 @@ for rep in range(3):
     with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
         r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(H, W))
     torch.cuda.synchronize()
-buf = np.zeros((8192 * 8, 4), dtype=np.uint64)
+buf = np.zeros((32768 * 8, 4), dtype=np.uint64)
 assert fn(buf.ctypes.data, buf.nbytes) == 0
 st = buf.astype(np.int64)
 ok = st[:, 1] > 0
