@@ -8,7 +8,8 @@ from gpu_util import DEV, N, T, bits_from_half, half_from_bits
 
 pytestmark = pytest.mark.gpu
 
-CASES = [(32, 64, 2), (32, 64, 3), (48, 64, 2), (64, 64, 2), (16, 16, 2), (32, 32, 4), (32, 128, 2), (48, 128, 3), (32, 256, 2)]
+CASES = [(32, 64, 2), (32, 64, 3), (48, 64, 2), (48, 64, 3), (64, 64, 2),   # (48, 64, *): the fused backward's instantiations with an ODD number of input k-steps (the K = 16 tail hazard, csrc/ffmlp.hip mfma_ksteps)
+         (16, 16, 2), (32, 32, 4), (32, 128, 2), (48, 128, 3), (32, 256, 2)]
 
 
 def close_f16(a, b, rel=4e-3, floor=2e-3):

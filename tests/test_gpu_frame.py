@@ -296,7 +296,7 @@ print("HASH", h.hexdigest())
 @pytest.mark.parametrize("bound,n", [(1, 40000), (2, 20011)])
 def test_lookahead_variants_render_the_same_bits(bound, n):
     """the lookahead's A/B switches (stragglers finished by the finishing kernel or inside the lane kernel, visits of an empty
-    stretch probed together or one by one, event flags) change WHEN probes are issued and WHO walks a ray, never a sample: the
+    stretch probed together or one by one, coarse-field early stop, emit path, encoder schedule) change WHEN probes are issued and WHO walks a ray, never a sample: the
     frame must come out bit for bit the same.  The switches are read once per process: fresh child processes."""
     import os
     import subprocess
@@ -304,7 +304,13 @@ def test_lookahead_variants_render_the_same_bits(bound, n):
     from conftest import ROOT
     hashes = {}
     for name, env in (("default", {}), ("in-wave stragglers", {"LAE_FRAME_FINISH_QUEUE": "0"}), ("plain visits", {"LAE_FRAME_SPEC": "0"}),
-                      ("queue everything up to 48", {"LAE_FRAME_COOP_MAX": "48"}), ("default event flags", {"LAE_FRAME_EVENT_FLAGS": "0"})):
+                      ("queue everything up to 48", {"LAE_FRAME_COOP_MAX": "48"}),
+                      # round 4: the "nothing ahead" test off, rows stored straight from the lanes, the training cost table for the
+                      # encoder's XCD schedule / the finest level in halves, stragglers of the first walk handed over, hand-over
+                      # of whole waves after 4 lane rounds
+                      ("no coarse field", {"LAE_FRAME_COARSE": "0"}), ("emit without LDS", {"LAE_FRAME_EMIT_LDS": "0"}),
+                      ("training schedule", {"LAE_GRID_FWD_FRAME_SCHED": "0"}), ("level halves", {"LAE_GRID_FWD_FRAME_SCHED": "2"}),
+                      ("first walk queues", {"LAE_FRAME_COOP_MAX0": "16", "LAE_FRAME_MAX_ROUNDS": "4"})):
         e = dict(os.environ, **env)
         out = subprocess.run([sys.executable, "-c", _AB_SCRIPT.format(root=ROOT, bound=bound, n=n)], capture_output=True, text=True, timeout=600, env=e)
         lines = [l for l in out.stdout.splitlines() if l.startswith("HASH ")]
