@@ -1042,7 +1042,7 @@ constexpr uint32_t FRAME_LA = 8;               // recorded samples per ray (>= m
 __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const float* __restrict__ nears,
                              RayAcc* __restrict__ acc, float* __restrict__ tc, uint32_t* __restrict__ q_counts) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n == 0) { ctrl[0] = FrameCtrl{}; q_counts[0] = 0u; q_counts[1] = 0u; }   // state "before iteration 0": step = 0, nothing issued, no straggler queued
+    if (n == 0) { ctrl[0] = FrameCtrl{}; q_counts[0] = 0u; q_counts[1] = 0u; q_counts[2] = 0u; q_counts[3] = 0u; }   // state "before iteration 0": step = 0, nothing issued, no straggler queued
     if (n >= N) return;
     const float t0 = nears[n];
     tc[n] = t0;
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
     uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds,
-    const uint8_t* __restrict__ cdist) {
+    const uint8_t* __restrict__ cdist, uint32_t admit_cap, int admit_round) {
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LOOK_NOTE(0, wall_clock64());
@@ -1387,6 +1387,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     if (__ballot(has_ray) == 0ull) return;
     if (!has_ray) index = 0;
     uint32_t st_rounds = 0;
+    bool admit_tried = false;
     [[maybe_unused]] uint32_t st_coop = 0, st_passes = 0;
     Ray r{};
     float t = 0.f, far = 0.f, tend0 = 0.f;
@@ -1523,7 +1524,20 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         // waves to the finishing kernel after max_rounds rounds costs more than it saves: one wave per ray there is ~7x
         // the work of a lane here.  Round 4, LAE_FRAME_MAX_ROUNDS = 1 / 2 / 3: 15.3 / 15.1 / 14.5 ms per 800x800 frame
         // against 11.9, 92 against 71 ms at 1080p.)
-        if (__builtin_popcountll(um) > coop_max && !(q_tasks && st_rounds >= (uint32_t)max_rounds)) continue;
+        if (__builtin_popcountll(um) > coop_max && !(q_tasks && st_rounds >= (uint32_t)max_rounds)) {
+            // A wave whose rays left a surface together keeps every lane busy, but it is as slow as one ray's walk: ~1 us per visit,
+            // 100+ us to the next surface -- and in a frame's late iterations (few rays alive, most of the chip idle) the whole
+            // iteration waits for it (a shard of the 1080p frame: iterations 15-47 waited 65 us each on average for lookaheads of
+            // 100-140 us while encoder + head took 150 -> 30 us).  One wave per ray walks ~14 cells per microsecond at 7x the
+            // work, so such a wave hands ALL its unfinished rays over after `admit_round` rounds -- as long as the launch's total
+            // of rays admitted this way stays below `admit_cap` (early iterations have thousands of such waves: they walk on).
+            if (!(q_tasks && admit_cap && !admit_tried && st_rounds >= (uint32_t)admit_round)) continue;
+            admit_tried = true;
+            uint32_t before = 0;
+            if (lane == 0) before = atomicAdd(q_count + 2, (uint32_t)__builtin_popcountll(um));
+            before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+            if (before + (uint32_t)__builtin_popcountll(um) > admit_cap) continue;
+        }
         LOOK_NOTE(2, wall_clock64());
         if (q_tasks) {
             // few stragglers: hand them to k_frame_lookahead_finish (one wave per ray, every SIMD of the chip) instead of
@@ -1570,7 +1584,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
     uint32_t max_n_step, const uint32_t* __restrict__ q_count, uint32_t* __restrict__ q_count_next, const LookTask* __restrict__ q_tasks,
     LookRec out, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const uint8_t* __restrict__ cdist) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *q_count_next = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { q_count_next[0] = 0u; q_count_next[2] = 0u; }   // task count and admitted-rays count of the next launch
     const uint32_t n_tasks = *q_count;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2144,7 +2158,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     float* deltas = reinterpret_cast<float*>(take(8 * cap));
     uint8_t* edit_occ = take(cap);
     void* feats = take((uint64_t)L * cap * 4);
-    uint32_t* q_counts = reinterpret_cast<uint32_t*>(take(256));            // [2], used alternately by consecutive lookaheads
+    uint32_t* q_counts = reinterpret_cast<uint32_t*>(take(256));            // [0], [1]: task counts, used alternately by consecutive lookaheads; [2], [3]: rays admitted from whole waves
     LookTask* q_tasks = reinterpret_cast<LookTask*>(take(12ull * N));
     static_assert(sizeof(LookTask) == 12, "LookTask layout");
     uint32_t* cmask = reinterpret_cast<uint32_t*>(take(4ull * FRAME_CG * FRAME_CG));
@@ -2159,6 +2173,8 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // the first walk of a frame is another regime: every ray that hits anything first crosses empty space, a wave's lanes finish
     // at very different times and a low bound sends tens of thousands of rays to the one-wave-per-ray kernel
     static const int coop_max0 = [] { const char* e = getenv("LAE_FRAME_COOP_MAX0"); return e ? atoi(e) : 0; }();   // -1: as the loop's; sweep -1 / 0 / 2 / 4 / 8 / 32: 10.80 / 10.70 / 10.81 / 10.79 / 10.82 / 11.09 ms at 800x800
+    static const uint32_t admit_cap = [] { const char* e = getenv("LAE_FRAME_ADMIT_CAP"); return e ? (uint32_t)atoi(e) : 4096u; }();   // 0: never (A/B)
+    static const int admit_round = [] { const char* e = getenv("LAE_FRAME_ADMIT_ROUND"); return e ? atoi(e) : 2; }();
     uint32_t look_no = 0;
 
     const MarchCfg cfg = make_cfg(bound, dt_gamma, max_steps, C, H);
@@ -2175,11 +2191,11 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist);
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round);
             if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid, cdist);
         } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist);
+                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round);
             if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr, cdist);
         }
     };
