@@ -1607,9 +1607,12 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead_finish(
 // polls `go`): at its beginning (go_early: the lookahead of this iteration needs nothing this kernel writes -- only that the
 // previous head kernel is complete, which this kernel running proves) or when its last-dispatched workgroup is done (the
 // lookahead then does not compete with this kernel, which is on the caller's critical path, for the memory system).
-constexpr uint32_t EMIT_IMG_ROWS = 64u * FRAME_LA + 4u * (FRAME_LA + 1u) + 28u;      // rows of 64 rays + the padding of the groups they touch; x 32 B + 1 B (edit flag)
-constexpr uint32_t EMIT_IMG_FLOATS = 5u * EMIT_IMG_ROWS + 256u + EMIT_IMG_ROWS / 4u;   // xyz + delta rows, 64 x (direction, samples held), edit flags
-static_assert(EMIT_IMG_ROWS % 4u == 0u, "the edit flags follow the floats");
+// rows of 64 rays with n_step samples each + the padding of the groups they touch (a multiple of 16: the edit flags follow the
+// floats, and every wave's image stays 16-byte aligned)
+__host__ __device__ constexpr uint32_t emit_img_rows(uint32_t n_step) { return (64u * n_step + 4u * (64u / (64u / n_step) + 2u) + 15u) & ~15u; }
+static_assert(emit_img_rows(3) % 16u == 0u && emit_img_rows(8) >= 64u * 8u + 4u * 10u, "image sizing");
+// xyz + delta rows (20 B each), 64 x (direction, samples held), edit flags
+__host__ __device__ constexpr uint32_t emit_img_floats(uint32_t rows) { return 5u * rows + 256u + rows / 4u; }
 template <bool EDIT>
 __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, FrameSegs sg, uint32_t N, uint32_t row_budget, uint32_t max_steps,
@@ -1617,7 +1620,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     const float* __restrict__ rays_d, MarchCfg cfg, float* __restrict__ xyzs, float* __restrict__ dirs,
     float* __restrict__ deltas, uint8_t* __restrict__ edit_occ, const float* __restrict__ noises,
     FrameMirror* __restrict__ mirror, uint64_t frame_id, unsigned long long* __restrict__ go, unsigned long long go_value, int go_early,
-    int use_lds) {
+    int use_lds, uint32_t img_rows) {
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (go && go_early && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1641,18 +1644,20 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     // padding rows between them) are ONE contiguous range: the lanes build it in a wave-private LDS image and the wave
     // stores it with consecutive lanes on consecutive words.
     extern __shared__ float emit_lds[];
-    if (use_lds && c.n_step >= (uint32_t)use_lds && !c.done) {
+    // (img_rows: capacity of a wave's image as the host sized it from its lagging bound of n_alive; an iteration whose n_step
+    // outgrew it stores straight from the lanes)
+    if (use_lds && c.n_step >= (uint32_t)use_lds && !c.done && 64u * c.n_step + 4u * (64u / rpg + 2u) <= img_rows) {
         const unsigned long long hm = __ballot(f.has);
         if (hm) {                                              // valid lanes are a prefix of the wave (frame_locate)
             const uint32_t cnt = (uint32_t)__builtin_popcountll(hm), n_step = c.n_step;
-            float* img = emit_lds + (size_t)(threadIdx.x >> 6) * EMIT_IMG_FLOATS;
-            float* ix = img; float* il = img + 3 * EMIT_IMG_ROWS; float* idr = img + 5 * EMIT_IMG_ROWS;   // xyz rows, delta rows, per RAY: direction + samples held
-            uint8_t* ie = reinterpret_cast<uint8_t*>(img + 5 * EMIT_IMG_ROWS + 256);
+            float* img = emit_lds + (size_t)(threadIdx.x >> 6) * emit_img_floats(img_rows);
+            float* ix = img; float* il = img + 3 * img_rows; float* idr = img + 5 * img_rows;   // xyz rows, delta rows, per RAY: direction + samples held
+            uint8_t* ie = reinterpret_cast<uint8_t*>(img + 5 * img_rows + 256);
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.n);
             const uint32_t g0 = n0 / rpg, row0 = g0 * 64u + (n0 - g0 * rpg) * n_step;
             const uint32_t nl = n0 + cnt - 1u, gl = nl / rpg, sl = nl - gl * rpg;
             const uint32_t row1 = sl == rpg - 1u ? gl * 64u + 64u : gl * 64u + (sl + 1u) * n_step;   // the last slot of a group takes its padding rows along
-            const uint32_t nrows = row1 - row0;                // <= 64 n_step + 4 (groups + 1) <= EMIT_IMG_ROWS
+            const uint32_t nrows = row1 - row0;                // <= 64 n_step + 4 (groups + 1) <= img_rows
             if (f.has) {
                 const uint32_t index = f.index;
                 alive[f.n] = (int32_t)index;
@@ -2285,16 +2290,20 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         // caller's chain: the samples of this iteration come from the previous lookahead
         join_side();
         const uint32_t emit_blocks = lae::cdiv(list_waves, FRAME_BLOCK / 64);
-        const int emit_lds = emit_lds_min >= 3 && max_n_step >= (uint32_t)emit_lds_min && (uint64_t)budget >= (uint64_t)emit_lds_min * bound_alive ? emit_lds_min : 0;
-        const uint32_t emit_lds_bytes = emit_lds ? (FRAME_BLOCK / 64) * EMIT_IMG_FLOATS * 4u : 0u;
+        const int emit_lds = emit_lds_min >= 2 && max_n_step >= (uint32_t)emit_lds_min && (uint64_t)budget >= (uint64_t)emit_lds_min * bound_alive ? emit_lds_min : 0;
+        // the image is sized for one n_step more than the bound implies (the bound lags a few iterations): 5 KB per wave at
+        // n_step = 3, 13 KB at 8 -- at the full size only three workgroups fit a CU and the kernel ran in two rounds
+        const uint32_t n_lb = (uint32_t)std::min<uint64_t>((uint64_t)budget / std::max(bound_alive, 1u), (uint64_t)max_n_step);
+        const uint32_t img_rows = emit_img_rows(std::min(std::max(n_lb, 1u) + 1u, max_n_step));
+        const uint32_t emit_lds_bytes = emit_lds ? (FRAME_BLOCK / 64) * emit_img_floats(img_rows) * 4u : 0u;
         if (edit_grid)
             k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                 xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
-                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds);
+                                                                overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds, img_rows);
         else
             k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                  xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
-                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds);
+                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds, img_rows);
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
                                      gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
         // head + compositing: one wave per run of 64-row groups; the survivors of wave u go, in order, to segment u of
