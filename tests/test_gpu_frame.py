@@ -277,6 +277,70 @@ def test_frame_loop_ends_when_every_ray_dies_at_once(kind):
                 assert np.array_equal(N(a["weights_sum"]), N(b["weights_sum"]))
 
 
+@pytest.mark.parametrize("bound,density", [(1, 0.004), (2, 0.002), (2, 0.05), (1, 0.0), (2, 0.0)])
+def test_frame_loop_on_sparse_random_occupancy(bound, density):
+    """the lookahead's "nothing ahead" test (coarse occupancy field, csrc/raymarching.hip k_frame_coarse_*) must never end a walk
+    that still has a sample in front of it: isolated occupied cells scattered over every cascade (most rays cross long empty
+    stretches between hits, many graze marked coarse cells), rays from outside the volume, from inside it, axis-parallel and
+    nearly axis-parallel ones -- frame loop and operator loop bit for bit"""
+    net, r = make(bound=bound, seed=7, table_amp=0.3)
+    rng = np.random.default_rng(11)
+    bits = (rng.random(r.cascade * 128 ** 3) < density)
+    bits[-64:] = True                                                       # the top level's far corner: cells positions clamp into
+    targets = None
+    if density == 0.0:
+        # the dangerous case for an early stop: a volume that is empty except for 40 isolated cells per cascade (and one
+        # small box), with rays aimed exactly at those cells from far away -- most of each ray's path passes the test
+        from laenerf_amd import synthetic as S
+        cx, cy, cz = S._morton_inverse_table(128)
+        targets = []
+        for c in range(r.cascade):
+            pick = rng.choice(128 ** 3, 40, replace=False)
+            bits[c * 128 ** 3 + pick] = True
+            b_c = min(2.0 ** c, float(bound))
+            ctr = np.stack([cx[pick], cy[pick], cz[pick]], 1).astype(np.float32)
+            targets.append(((ctr + 0.5) / 128 * 2 - 1) * b_c)
+            box = (np.abs(cx - 40) < 3) & (np.abs(cy - 90) < 3) & (np.abs(cz - 64) < 3)
+            bits[c * 128 ** 3 + np.nonzero(box)[0]] = True
+        targets = np.concatenate(targets).astype(np.float32)
+    packed = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    r.density_bitfield = T(packed)
+    n = 6000
+    o, d = rays(n, seed=9, bound=bound)
+    o, d = N(o).copy(), N(d).copy()
+    # a third of the rays start inside the volume with random directions
+    k = n // 3
+    o[:k] = rng.uniform(-0.6 * bound, 0.6 * bound, (k, 3)).astype(np.float32)
+    dd = rng.standard_normal((k, 3)).astype(np.float32)
+    d[:k] = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    # axis-parallel and nearly axis-parallel rays (a zero / tiny direction component: 1 / d is inf / huge)
+    for j, ax in enumerate((0, 1, 2)):
+        base = k + 40 * j
+        o[base:base + 40] = rng.uniform(-0.5 * bound, 0.5 * bound, (40, 3)).astype(np.float32)
+        v = np.zeros((40, 3), np.float32); v[:, ax] = np.where(rng.random(40) < 0.5, 1.0, -1.0)
+        v[20:, (ax + 1) % 3] = 1e-4
+        d[base:base + 40] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    if targets is not None:                                                 # the last 2000 rays: from a sphere around the volume at a target cell
+        m = 2000
+        tg = targets[rng.integers(0, len(targets), m)] + rng.uniform(-0.3, 0.3, (m, 3)).astype(np.float32) * (2.0 * bound / 128)
+        src = rng.standard_normal((m, 3)).astype(np.float32)
+        src = src / np.linalg.norm(src, axis=1, keepdims=True) * (2.5 * bound)
+        v = tg - src
+        o[-m:] = src; d[-m:] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    o, d = T(o), T(d)
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=False)
+        b = r.render_eval(o, d, bg_color=1, max_steps=1024, frame_loop=True, want_stats=True)
+    hit = N(a["weights_sum"]) > 0
+    assert hit.mean() > (0.3 if targets is None else 0.2)
+    if targets is not None:
+        assert hit[-2000:].mean() > 0.8                                     # the aimed rays do find their isolated cell (outer-cascade cells inside the inner box are never probed)
+    for key in ("image", "weights_sum"):
+        assert np.array_equal(N(a[key]), N(b[key])), key
+    assert np.array_equal(N(a["depth"])[hit], N(b["depth"])[hit])
+    assert np.array_equal(np.isnan(N(a["depth"])), np.isnan(N(b["depth"])))
+
+
 _AB_SCRIPT = r"""
 import hashlib, sys, torch
 sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
