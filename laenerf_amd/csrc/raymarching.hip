@@ -1062,31 +1062,46 @@ __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const flo
 // Conservative: a failed test changes nothing (the lane walks on), a passed one only skips visits that emit nothing.
 constexpr uint32_t FRAME_CG = 32;              // coarse cells per axis
 constexpr uint32_t FRAME_CG_CAP = 16;          // distances saturate here
-__global__ void k_frame_coarse_mark(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H, float bound, uint32_t* __restrict__ cmask) {
-    const uint32_t per_level = H * H * H / 8u;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= C * per_level) return;
-    if (grid[b] == 0) return;
-    const uint32_t level = b / per_level, m = (b - level * per_level) << 3;
-    const uint32_t vx = morton_compact(m), vy = morton_compact(m >> 1), vz = morton_compact(m >> 2);   // even: the block's low corner
-    const float bl = fminf(scalbnf(1.0f, (int)level), bound), vs = 2.0f * bl / (float)H, inv_s = (float)FRAME_CG / (2.0f * bound);
-    const bool top = level + 1u == C;             // positions beyond the top level's box clamp into its border cells (probe_at)
-    int c0[3], c1[3];
-    const uint32_t v[3] = {vx, vy, vz};
+// one thread per 4 bitfield bytes (4 Morton-consecutive 2x2x2 blocks); a workgroup first collects its marks in an LDS copy of the
+// mask and flushes the words it set (one global atomic per word and workgroup: per byte, the atomics of a scene with a wall
+// across the volume took 65 us)
+__global__ __launch_bounds__(1024) void k_frame_coarse_mark(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H, float bound, uint32_t* __restrict__ cmask) {
+    __shared__ uint32_t lm[FRAME_CG * FRAME_CG];
+    for (uint32_t i = threadIdx.x; i < FRAME_CG * FRAME_CG; i += blockDim.x) lm[i] = 0u;
+    __syncthreads();
+    const uint32_t per_level = H * H * H / 8u, total = C * per_level;
+    const float inv_s = (float)FRAME_CG / (2.0f * bound);
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w * 4u < total; w += gridDim.x * blockDim.x) {
+        const uint32_t word = reinterpret_cast<const uint32_t*>(grid)[w];       // (H >= 4: per_level is a multiple of 4, the bitfield 4-byte aligned)
+        if (word == 0u) continue;
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        float lo = -bl + ((float)v[a] - 1.0f) * vs, hi = -bl + ((float)v[a] + 3.0f) * vs;   // cells v-1 .. v+2
-        if (top && v[a] == 0u) lo = -bound;
-        if (top && v[a] + 2u >= H) hi = bound;
-        c0[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((lo + bound) * inv_s)));
-        c1[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((hi + bound) * inv_s)));
-    }
-    const uint32_t xm = (c1[0] >= 31 ? ~0u : ((2u << c1[0]) - 1u)) & ~((1u << c0[0]) - 1u);
-    for (int z = c0[2]; z <= c1[2]; z++)
-        for (int y = c0[1]; y <= c1[1]; y++) {
-            uint32_t* w = cmask + z * (int)FRAME_CG + y;
-            if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & xm) != xm) atomicOr(w, xm);
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (((word >> (8u * k)) & 0xffu) == 0u) continue;
+            const uint32_t b = w * 4u + k;
+            const uint32_t level = b / per_level, m = (b - level * per_level) << 3;
+            const uint32_t v[3] = {morton_compact(m), morton_compact(m >> 1), morton_compact(m >> 2)};   // even: the block's low corner
+            const float bl = fminf(scalbnf(1.0f, (int)level), bound), vs = 2.0f * bl / (float)H;
+            const bool top = level + 1u == C;             // positions beyond the top level's box clamp into its border cells (probe_at)
+            int c0[3], c1[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                float lo = -bl + ((float)v[a] - 1.0f) * vs, hi = -bl + ((float)v[a] + 3.0f) * vs;   // cells v-1 .. v+2
+                if (top && v[a] == 0u) lo = -bound;
+                if (top && v[a] + 2u >= H) hi = bound;
+                c0[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((lo + bound) * inv_s)));
+                c1[a] = max(0, min((int)FRAME_CG - 1, (int)floorf((hi + bound) * inv_s)));
+            }
+            const uint32_t xm = (c1[0] >= 31 ? ~0u : ((2u << c1[0]) - 1u)) & ~((1u << c0[0]) - 1u);
+            for (int z = c0[2]; z <= c1[2]; z++)
+                for (int y = c0[1]; y <= c1[1]; y++)
+                    if ((lm[z * (int)FRAME_CG + y] & xm) != xm) atomicOr(&lm[z * (int)FRAME_CG + y], xm);
         }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < FRAME_CG * FRAME_CG; i += blockDim.x) {
+        const uint32_t mine = lm[i];
+        if (mine && (__hip_atomic_load(cmask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mine) != mine) atomicOr(cmask + i, mine);
+    }
 }
 // Chebyshev distance (in coarse cells, saturating at FRAME_CG_CAP) to the nearest marked cell: rounds of 3x3x3 dilation on the
 // 1024 x-rows of the mask held as 32-bit words; one workgroup.
@@ -2169,7 +2184,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     uint32_t* cmask = reinterpret_cast<uint32_t*>(take(4ull * FRAME_CG * FRAME_CG));
     uint8_t* cdist_buf = take(2ull * FRAME_CG * FRAME_CG * FRAME_CG);   // distances, then octant flags
     static const bool coarse_on = [] { const char* e = getenv("LAE_FRAME_COARSE"); return !e || atoi(e) != 0; }();   // 0: no "nothing ahead" test (A/B)
-    const uint8_t* cdist = coarse_on && H >= 2 && (H & (H - 1u)) == 0u ? cdist_buf : nullptr;   // Morton bytes are 2x2x2 blocks when H is a power of two
+    const uint8_t* cdist = coarse_on && H >= 4 && (H & (H - 1u)) == 0u && (reinterpret_cast<uintptr_t>(grid) & 3u) == 0u ? cdist_buf : nullptr;   // Morton bytes are 2x2x2 blocks when H is a power of two
     static const bool finish_queue = [] { const char* e = getenv("LAE_FRAME_FINISH_QUEUE"); return !e || atoi(e) != 0; }();   // 0: stragglers finished inside the lane kernel (A/B)
     static const int spec_visits = [] { const char* e = getenv("LAE_FRAME_SPEC"); return e ? atoi(e) : 1; }();   // 0: every visit waits for its own probe (A/B)
     static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
@@ -2208,7 +2223,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, acc, rec[0].tc, q_counts);
     if (cdist) {                                          // the bitfield is the caller's and may have changed since the last frame
         if (hipMemsetAsync(cmask, 0, 4ull * FRAME_CG * FRAME_CG, s) != hipSuccess) return LAE_ELAUNCH;
-        k_frame_coarse_mark<<<lae::cdiv(C * (H * H * H / 8u), 256), 256, 0, s>>>(grid, C, H, bound, cmask);
+        k_frame_coarse_mark<<<std::min(64u, lae::cdiv(C * (H * H * H / 8u), 4096u)), 1024, 0, s>>>(grid, C, H, bound, cmask);
         k_frame_coarse_dist<<<2, 1024, 0, s>>>(cmask, cdist_buf);
     }
     const FrameSegs no_segs{nullptr, nullptr, nullptr, 0u, 0u};
