@@ -1040,8 +1040,9 @@ constexpr uint32_t FRAME_SEG_SLACK = 200;      // a segment's stride exceeds bou
 constexpr uint32_t FRAME_LA = 8;               // recorded samples per ray (>= max_n_step)
 
 __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const float* __restrict__ nears,
-                             RayAcc* __restrict__ acc, float* __restrict__ tc, uint32_t* __restrict__ q_counts) {
+                             RayAcc* __restrict__ acc, float* __restrict__ tc, uint32_t* __restrict__ q_counts, uint32_t* __restrict__ cmask) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cmask && blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < 32u * 32u; i += blockDim.x) cmask[i] = 0u;   // the coarse mask of k_frame_coarse_mark (FRAME_CG^2 words)
     if (n == 0) { ctrl[0] = FrameCtrl{}; q_counts[0] = 0u; q_counts[1] = 0u; q_counts[2] = 0u; q_counts[3] = 0u; }   // state "before iteration 0": step = 0, nothing issued, no straggler queued
     if (n >= N) return;
     const float t0 = nears[n];
@@ -1061,7 +1062,7 @@ __global__ void k_frame_init(FrameCtrl* __restrict__ ctrl, uint32_t N, const flo
 // and, if every point of the rest of the ray keeps at least one coarse cell between itself and any marked cell, is done.
 // Conservative: a failed test changes nothing (the lane walks on), a passed one only skips visits that emit nothing.
 constexpr uint32_t FRAME_CG = 32;              // coarse cells per axis
-constexpr uint32_t FRAME_CG_CAP = 16;          // distances saturate here
+constexpr uint32_t FRAME_CG_CAP = 8;           // distances saturate here (a step of the trace is at most 7 cells; 16: twice the rounds of the one-workgroup transform, 22 us)
 // one thread per 4 bitfield bytes (4 Morton-consecutive 2x2x2 blocks); a workgroup first collects its marks in an LDS copy of the
 // mask and flushes the words it set (one global atomic per word and workgroup: per byte, the atomics of a scene with a wall
 // across the volume took 65 us)
@@ -2220,9 +2221,8 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         }
     };
     k_near_far<<<lae::cdiv(N, 256), 256, 0, s>>>(rays_o, rays_d, aabb, N, min_near, nears, fars);
-    k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, acc, rec[0].tc, q_counts);
+    k_frame_init<<<lae::cdiv(N, 256), 256, 0, s>>>(ctrl, N, nears, acc, rec[0].tc, q_counts, cdist ? cmask : nullptr);
     if (cdist) {                                          // the bitfield is the caller's and may have changed since the last frame
-        if (hipMemsetAsync(cmask, 0, 4ull * FRAME_CG * FRAME_CG, s) != hipSuccess) return LAE_ELAUNCH;
         k_frame_coarse_mark<<<std::min(64u, lae::cdiv(C * (H * H * H / 8u), 4096u)), 1024, 0, s>>>(grid, C, H, bound, cmask);
         k_frame_coarse_dist<<<2, 1024, 0, s>>>(cmask, cdist_buf);
     }
