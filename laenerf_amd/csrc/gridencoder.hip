@@ -1393,7 +1393,9 @@ static float fwd_level_cost_frame(bool hashed, uint32_t resolution) {
     const float lr = log2f((float)resolution);
     if (lr <= 6.3f) return 1.29f;
     if (lr <= 9.1f) return 1.29f + (lr - 6.3f) * (0.91f / 2.8f);
-    return 2.2f + (lr - 9.1f) * (1.75f / 1.9f);
+    if (lr <= 11.0f) return 2.2f + (lr - 9.1f) * (1.75f / 1.9f);
+    static const float top_slope = [] { const char* e = getenv("LAE_GRID_FWD_FRAME_SLOPE"); return e ? (float)atof(e) : 0.5f; }();   // beyond resolution 2048 (bound-2 scenes: finest levels 2819 / 4096) the rise flattens: slope 0.92 / 0.5 / 0.2 / 0 -> 1080p frame 60.8 / 59.7 / 59.9 / 61.4 ms
+    return 3.95f + (lr - 11.0f) * top_slope;
 }
 static int g_fwd_frame_sched = -1;                         // LAE_GRID_FWD_FRAME_SCHED: 0 training table, 1 (default) frame table, 2 frame table + the costliest levels in halves
 // (measured, 800x800 / 1080p / one rank's shard of it: 0: 10.9 / 67.2 / 11.15 ms, 1: 10.95 / 62.2 / 10.9, 2: 11.1 / 63.7 / 10.9 -- a level in two
