@@ -1,6 +1,6 @@
 """per-iteration table of a frame-loop kernel trace: lookahead / finishing kernel against emit / encoder / head, wall per iteration,
 and how long the lookahead chain ended after the head kernel (what the next iteration waits for).
-python tools/r4_iter_table.py <kernel_trace.csv> [every]"""
+python tools/frame_iter_table.py <kernel_trace.csv> [every]"""
 import csv, sys
 path = sys.argv[1]; every = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows = []
