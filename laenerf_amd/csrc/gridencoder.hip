@@ -400,7 +400,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
 // ---- constants and predicates of the binned backward (defined here because the generic kernel below is its companion)
 constexpr uint32_t PART_SHIFT = 12, PART = 1u << PART_SHIFT;   // table entries per partition (= per accumulate workgroup)
 constexpr uint32_t BK_MAX = 512;              // partitions per level the binned path handles (level size <= 2^21 entries)
-constexpr uint32_t BK_TARGET = 16;            // target workgroups per level (levels with fewer partitions are split into sub-ranges)
+constexpr uint32_t BK_TARGET = 32;            // target workgroups per level (levels with fewer partitions are split into sub-ranges).  Round 4: 16 -> 32
+                                              // (same-box A/B, 16 / 32 / 64: lego step 0.3514 / 0.3508 / 0.3547 ms, style step 0.396 / 0.367 / 0.368, flower step 0.700 / 0.666 / 0.647:
+                                              // the smallest levels' few cells take every sample's LDS atomics, more sub-ranges spread them over more CUs)
 
 struct LevelBins { uint32_t P, SUB; };
 __host__ __device__ __forceinline__ LevelBins level_bins_of(uint32_t hashmap_size) {
@@ -518,7 +520,7 @@ constexpr int ACC_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
 constexpr bool WIDE_COARSE_UNITS = false;                      // true: 16 samples per lane on those levels (round 3 experiment: accumulate 62.4 -> 58.4 us, but fill 58.3 -> 80.1 and count 27.5 -> 38.0 -- the wide blocks walk four dependent load groups and form the pass's tail; step 0.356 -> 0.433 ms)
-constexpr uint32_t SUB_RECS = 16;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
+constexpr uint32_t SUB_RECS = 32;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
 constexpr uint32_t TICKET_WORDS = TICKET_ARRIVALS + MAX_LEVELS * SUB_RECS;
 template <typename T> constexpr uint32_t sub_rec_words() { return (sizeof(T) == 2 ? 2 * PART : PART) + PART / 64; }
