@@ -297,7 +297,7 @@ struct FwdSched { uint32_t nseg[8]; FwdSeg seg[8][FWD_MAX_SEG]; };
 __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
     half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
-    const uint32_t* __restrict__ B_dev, uint32_t pass_chunks) {
+    const uint32_t* __restrict__ B_dev) {
     const uint32_t xcd = blockIdx.x & 7u;
 #ifdef LAE_GRID_STAMPS
     const unsigned long long st_t0 = wall_clock64();
@@ -315,13 +315,9 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
         j -= n;
     }
     if (level == 0xffffffffu) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
     if (B_dev) B = min(B, *B_dev);
-    // Frame launches are sized for the rows the host EXPECTS (pass_chunks chunks per level: its lagging bound of the rays alive x
-    // the n_step that bound implies), not for the worst case: a launch sized for the row budget had 130 k of its 216 k
-    // workgroups find no rows in every iteration of a 1080p frame (~0.3 ns each: 40 of 245 us).  Should the device hold more
-    // rows than expected (n_step rose since the host last looked), every workgroup goes round again, pass_chunks further on.
-    for (uint32_t b = chunk * GRID_BLOCK + threadIdx.x; b < B; b += pass_chunks * GRID_BLOCK) {
-    [&]() {
+    if (b >= B) return;
     const LevelInfo<3> li = level_info<3>(sc, offsets, level, 0u, false);
     const char* __restrict__ tabb = reinterpret_cast<const char*>(grid + (size_t)li.table_off * 2);
 
@@ -391,9 +387,6 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     }
     const half2_t h2 = {r0, r1};
     *out = h2;
-    }();
-    if (pass_chunks == 0u) break;
-    }
 #ifdef LAE_GRID_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 32768u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
         g_grid_stamps[(size_t)blockIdx.x * 4] = st_t0; g_grid_stamps[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_grid_stamps[(size_t)blockIdx.x * 4 + 2] = level;
@@ -1372,7 +1365,6 @@ struct FwdArgs {
     const float* inputs; const void* emb; const int32_t* offsets; void* out; uint32_t B, L; LevelScales sc;
     void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
     const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
-    uint32_t B_likely = 0;                                      // frame loop: the rows the host expects (<= B_launch); the lean kernel is sized for them and loops if there are more
     const int32_t* offsets_host = nullptr;                      // the caller's host copy of `offsets` (L + 1 ints) or NULL
     const float* level_cost = nullptr;                          // frame loop: measured per-level chunk costs (balance only) or NULL
 };
@@ -1499,8 +1491,7 @@ static int g_fwd_mode = 0;                                 // 0: lean kernel + b
 
 template <typename T, int D, int C>
 static void launch_fwd(const FwdArgs& a) {
-    const uint32_t nb_safe = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
-    const uint32_t nb = a.B_dev ? (lae::cdiv(a.B_likely ? a.B_likely : a.B_launch, GRID_BLOCK) + 7u) / 8u * 8u : nb_safe;   // frame, lean kernel: chunks per pass, a multiple of 8 (strided dense pieces)
+    const uint32_t nb = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
     if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
         if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
             FwdSched fs;
@@ -1511,13 +1502,13 @@ static void launch_fwd(const FwdArgs& a) {
             const float* co = a.level_cost ? a.level_cost : (env_cost.size() >= a.L ? env_cost.data() : nullptr);
             const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr, co);
             k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
-                                                                      fs, a.os_b, a.os_l, a.B_dev, a.B_dev ? nb : 0u);
+                                                                      fs, a.os_b, a.os_l, a.B_dev);
             return;
         }
     }
     const bool xcd = (a.L % 8) == 0;
-    k_grid_fwd<T, D, C><<<nb_safe * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
-                                                                a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb_safe,
+    k_grid_fwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
+                                                                a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb,
                                                                 xcd, a.os_b, a.os_l, a.B_dev);
 }
 template <typename T, int D>
@@ -1836,7 +1827,7 @@ static int tv_c(const float* inputs, const float* emb, float* grad, const int32_
 int lae::grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
                             uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                             int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
-                            const int32_t* offsets_host, uint32_t B_likely) {
+                            const int32_t* offsets_host) {
     if (B_launch == 0) return LAE_OK;
     FwdArgs a;
     a.offsets_host = offsets_host;
@@ -1846,7 +1837,7 @@ int lae::grid_forward_frame(const float* inputs, const void* embeddings, const i
     a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
     a.dy_dx = nullptr; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
     a.stream = stream; a.os_b = 2; a.os_l = (uint64_t)B_cap * 2;
-    a.B_dev = B_dev; a.B_launch = std::min(B_launch, B_cap); a.B_likely = std::min(B_likely, a.B_launch);
+    a.B_dev = B_dev; a.B_launch = std::min(B_launch, B_cap);
     launch_fwd<half_t, 3, 2>(a);
     return LAE_OK;
 }

@@ -110,6 +110,17 @@ def main():
     torch.cuda.synchronize()
     same = lambda x, y: bool(torch.equal(x.view(torch.int32), y.view(torch.int32)))
     checks["sharded_frame_equals_direct_bits"] = all(same(a[k], direct[k]) and same(b[k], direct[k]) for k in ("image", "depth", "weights_sum"))
+    if os.environ.get("LAE_DIST_CHECK_DEBUG"):
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            ref = r.render_eval(o, d, bg_color=1, max_steps=1024, max_n_step=1, frame_loop=False)
+            d2 = render(o, d); d3 = render(o, d)
+        torch.cuda.synchronize()
+        for nm, fr in (("ref(operator loop)", ref), ("direct again", d2), ("direct again 2", d3), ("a", a), ("b", b)):
+            for k in ("image", "depth", "weights_sum"):
+                x, y = fr[k].float(), direct[k].float()
+                ne = (x.view(x.shape[0], -1) != y.view(y.shape[0], -1)).any(dim=1) & ~(torch.isnan(x.view(x.shape[0], -1)).any(dim=1) & torch.isnan(y.view(y.shape[0], -1)).any(dim=1))
+                idx = ne.nonzero().flatten()
+                print(f"[rank {rank}] {nm}.{k}: {int(ne.sum())} rays differ, max abs {float(torch.nan_to_num(x - y).abs().max()):.3e}, first {idx[:8].tolist()}", file=sys.stderr, flush=True)
     checks["frame_hits_geometry"] = bool((direct["weights_sum"] > 0).float().mean() > 0.05)
     frame_hash = hashlib.sha256(a["image"].cpu().numpy().tobytes()).hexdigest()
     hashes = [None] * world
