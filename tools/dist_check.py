@@ -114,13 +114,25 @@ def main():
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
             ref = r.render_eval(o, d, bg_color=1, max_steps=1024, max_n_step=1, frame_loop=False)
             d2 = render(o, d); d3 = render(o, d)
+            ref2 = r.render_eval(o, d, bg_color=1, max_steps=1024, max_n_step=1, frame_loop=False)
         torch.cuda.synchronize()
+        ne = (ref["image"] != ref2["image"]).any(dim=1)
+        print(f"[rank {rank}] operator loop twice: {int(ne.sum())} rays differ", file=sys.stderr, flush=True)
+        ne = (d2["image"] != d3["image"]).any(dim=1)
+        print(f"[rank {rank}] frame loop twice: {int(ne.sum())} rays differ", file=sys.stderr, flush=True)
         for nm, fr in (("ref(operator loop)", ref), ("direct again", d2), ("direct again 2", d3), ("a", a), ("b", b)):
             for k in ("image", "depth", "weights_sum"):
                 x, y = fr[k].float(), direct[k].float()
                 ne = (x.view(x.shape[0], -1) != y.view(y.shape[0], -1)).any(dim=1) & ~(torch.isnan(x.view(x.shape[0], -1)).any(dim=1) & torch.isnan(y.view(y.shape[0], -1)).any(dim=1))
                 idx = ne.nonzero().flatten()
-                print(f"[rank {rank}] {nm}.{k}: {int(ne.sum())} rays differ, max abs {float(torch.nan_to_num(x - y).abs().max()):.3e}, first {idx[:8].tolist()}", file=sys.stderr, flush=True)
+                runs = []
+                if idx.numel():
+                    ii = idx.tolist(); st = ii[0]; pv = ii[0]
+                    for v in ii[1:]:
+                        if v > pv + 4: runs.append((st, pv - st + 1)); st = v
+                        pv = v
+                    runs.append((st, pv - st + 1))
+                print(f"[rank {rank}] {nm}.{k}: {int(ne.sum())} rays differ, max abs {float(torch.nan_to_num(x - y).abs().max()):.3e}, runs (start, length) {runs[:12]}", file=sys.stderr, flush=True)
     checks["frame_hits_geometry"] = bool((direct["weights_sum"] > 0).float().mean() > 0.05)
     frame_hash = hashlib.sha256(a["image"].cpu().numpy().tobytes()).hexdigest()
     hashes = [None] * world
