@@ -294,30 +294,9 @@ struct FwdSeg { uint32_t level, c0, n, cnt; };             // chunks [c0, c0 + n
 constexpr int FWD_MAX_SEG = 12;
 struct FwdSched { uint32_t nseg[8]; FwdSeg seg[8][FWD_MAX_SEG]; };
 
-__global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
-    const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
-    half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
-    const uint32_t* __restrict__ B_dev) {
-    const uint32_t xcd = blockIdx.x & 7u;
-#ifdef LAE_GRID_STAMPS
-    const unsigned long long st_t0 = wall_clock64();
-#endif
-    uint32_t j = blockIdx.x >> 3, level = 0xffffffffu, chunk = 0;
-    const uint32_t ns = sched.nseg[xcd];
-    for (uint32_t q = 0; q < ns; q++) {
-        const uint32_t n = sched.seg[xcd][q].n;
-        if (j < n) {
-            const uint32_t cnt = sched.seg[xcd][q].cnt;
-            level = sched.seg[xcd][q].level;
-            chunk = cnt ? (j / cnt) * 8u + sched.seg[xcd][q].c0 + j % cnt : sched.seg[xcd][q].c0 + j;
-            break;
-        }
-        j -= n;
-    }
-    if (level == 0xffffffffu) return;
-    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
-    if (B_dev) B = min(B, *B_dev);
-    if (b >= B) return;
+// one (sample row, level) of the lean forward: shared by k_grid_fwd_lean and by the frame loop's overflow launch below
+__device__ __forceinline__ void grid_fwd_lean_row(const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
+                                                  half_t* __restrict__ outputs, const LevelScales& sc, uint64_t os_b, uint64_t os_l, uint32_t level, uint32_t b) {
     const LevelInfo<3> li = level_info<3>(sc, offsets, level, 0u, false);
     const char* __restrict__ tabb = reinterpret_cast<const char*>(grid + (size_t)li.table_off * 2);
 
@@ -387,6 +366,33 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     }
     const half2_t h2 = {r0, r1};
     *out = h2;
+}
+
+__global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
+    const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
+    half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
+    const uint32_t* __restrict__ B_dev) {
+    const uint32_t xcd = blockIdx.x & 7u;
+#ifdef LAE_GRID_STAMPS
+    const unsigned long long st_t0 = wall_clock64();
+#endif
+    uint32_t j = blockIdx.x >> 3, level = 0xffffffffu, chunk = 0;
+    const uint32_t ns = sched.nseg[xcd];
+    for (uint32_t q = 0; q < ns; q++) {
+        const uint32_t n = sched.seg[xcd][q].n;
+        if (j < n) {
+            const uint32_t cnt = sched.seg[xcd][q].cnt;
+            level = sched.seg[xcd][q].level;
+            chunk = cnt ? (j / cnt) * 8u + sched.seg[xcd][q].c0 + j % cnt : sched.seg[xcd][q].c0 + j;
+            break;
+        }
+        j -= n;
+    }
+    if (level == 0xffffffffu) return;
+    const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
+    if (B_dev) B = min(B, *B_dev);
+    if (b >= B) return;
+    grid_fwd_lean_row(inputs, grid, offsets, outputs, sc, os_b, os_l, level, b);
 #ifdef LAE_GRID_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 32768u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
         g_grid_stamps[(size_t)blockIdx.x * 4] = st_t0; g_grid_stamps[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_grid_stamps[(size_t)blockIdx.x * 4 + 2] = level;
@@ -394,6 +400,23 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
 #endif
 }
 
+
+// Frame loop, rows [b0, *B_dev): the rows beyond what the host EXPECTED when it sized the lean launch (its lagging bound of the rays
+// alive x the n_step that bound implies).  A launch sized for the worst case -- the row budget -- had 130 k of its 216 k workgroups
+// find no rows in the iterations of a 1080p frame (~0.3 ns each: 40 of 245 us).  Rows exist here only in the few iterations after
+// n_step rose on the device; then one workgroup takes 256 rows through ALL levels (straight-line code, one copy per level: no
+// XCD placement for these rows, and no loop around the row code -- see DESIGN.md section 8).
+__global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean_tail(
+    const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
+    half_t* __restrict__ outputs, uint32_t B, LevelScales sc, uint32_t L, uint64_t os_b, uint64_t os_l,
+    const uint32_t* __restrict__ B_dev, uint32_t b0) {
+    const uint32_t b = b0 + blockIdx.x * GRID_BLOCK + threadIdx.x;
+    B = min(B, *B_dev);
+    if (b >= B) return;
+#pragma unroll
+    for (uint32_t level = 0; level < 16u; level++)
+        if (level < L) grid_fwd_lean_row(inputs, grid, offsets, outputs, sc, os_b, os_l, level, b);
+}
 // ---------------------------------------------------------------- K14
 // gridencoder.cu:248-340: scatter w*grad into grad_grid.  v1: one no-return atomic per
 // (corner, channel pair): global_atomic_add_f32 / global_atomic_pk_add_f16.
@@ -1365,6 +1388,7 @@ struct FwdArgs {
     const float* inputs; const void* emb; const int32_t* offsets; void* out; uint32_t B, L; LevelScales sc;
     void* dy_dx; uint32_t gridtype; bool align; uint32_t interp; uint64_t os_b, os_l; hipStream_t stream;
     const uint32_t* B_dev = nullptr; uint32_t B_launch = 0;     // frame loop: device-side row count, host bound for the launch
+    uint32_t B_likely = 0;                                      // frame loop: the rows the host expects (<= B_launch): the scheduled launch covers them, k_grid_fwd_lean_tail the rest
     const int32_t* offsets_host = nullptr;                      // the caller's host copy of `offsets` (L + 1 ints) or NULL
     const float* level_cost = nullptr;                          // frame loop: measured per-level chunk costs (balance only) or NULL
 };
@@ -1491,7 +1515,13 @@ static int g_fwd_mode = 0;                                 // 0: lean kernel + b
 
 template <typename T, int D, int C>
 static void launch_fwd(const FwdArgs& a) {
-    const uint32_t nb = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
+    const uint32_t nb_safe = lae::cdiv(a.B_dev ? a.B_launch : a.B, GRID_BLOCK);
+    // frame, lean kernel: the scheduled launch is sized for the expected rows (a multiple of 8 chunks: strided dense pieces)
+    // -- when that spares enough workgroups to pay for the second launch (~4 us in the iteration's chain against ~0.3 ns per
+    // workgroup that finds no rows, L of them per chunk: from ~2000 chunks on; an 800x800 frame stays with one launch)
+    static const uint32_t tail_min_chunks = [] { const char* e = getenv("LAE_GRID_FWD_TAIL_MIN"); return e ? (uint32_t)atoi(e) : 2048u; }();
+    uint32_t nb = a.B_dev && a.B_likely ? std::min((lae::cdiv(a.B_likely, GRID_BLOCK) + 7u) / 8u * 8u, nb_safe) : nb_safe;
+    if (nb_safe - nb < tail_min_chunks) nb = nb_safe;
     if constexpr (std::is_same<T, half_t>::value && D == 3 && C == 2) {
         if (g_fwd_mode != 2 && !a.dy_dx && a.interp == 0 && !a.align && a.gridtype == 0 && a.L <= 8 * FWD_MAX_SEG && a.L <= MAX_LEVELS) {
             FwdSched fs;
@@ -1501,14 +1531,17 @@ static void launch_fwd(const FwdArgs& a) {
                 return v; }();
             const float* co = a.level_cost ? a.level_cost : (env_cost.size() >= a.L ? env_cost.data() : nullptr);
             const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr, co);
-            k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc,
+            k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, std::min(a.B, nb * (uint32_t)GRID_BLOCK), a.sc,
                                                                       fs, a.os_b, a.os_l, a.B_dev);
+            if (nb < nb_safe)                                  // rows beyond the expected ones, if the device has any
+                k_grid_fwd_lean_tail<<<nb_safe - nb, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc, a.L,
+                                                                                 a.os_b, a.os_l, a.B_dev, nb * (uint32_t)GRID_BLOCK);
             return;
         }
     }
     const bool xcd = (a.L % 8) == 0;
-    k_grid_fwd<T, D, C><<<nb * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
-                                                                a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb,
+    k_grid_fwd<T, D, C><<<nb_safe * a.L, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const T*)a.emb, a.offsets, (T*)a.out, a.B, a.L,
+                                                                a.sc, (T*)a.dy_dx, a.gridtype, a.align, a.interp, nb_safe,
                                                                 xcd, a.os_b, a.os_l, a.B_dev);
 }
 template <typename T, int D>
@@ -1827,7 +1860,7 @@ static int tv_c(const float* inputs, const float* emb, float* grad, const int32_
 int lae::grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
                             uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                             int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
-                            const int32_t* offsets_host) {
+                            const int32_t* offsets_host, uint32_t B_likely) {
     if (B_launch == 0) return LAE_OK;
     FwdArgs a;
     a.offsets_host = offsets_host;
@@ -1837,7 +1870,7 @@ int lae::grid_forward_frame(const float* inputs, const void* embeddings, const i
     a.sc.in_shift = in_shift; a.sc.in_scale = in_scale;
     a.dy_dx = nullptr; a.gridtype = gridtype; a.align = align_corners != 0; a.interp = interp;
     a.stream = stream; a.os_b = 2; a.os_l = (uint64_t)B_cap * 2;
-    a.B_dev = B_dev; a.B_launch = std::min(B_launch, B_cap);
+    a.B_dev = B_dev; a.B_launch = std::min(B_launch, B_cap); a.B_likely = std::min(B_likely, a.B_launch);
     launch_fwd<half_t, 3, 2>(a);
     return LAE_OK;
 }

@@ -2239,6 +2239,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // the lookahead chain more than the quieter emit kernel gains.)
     // rows of n_step >= 3 iterations through a wave-private LDS image (k_frame_emit); the host knows a lagging bound of n_alive,
     // so whether an iteration can have n_step >= 3 at all (budget / bound_alive >= 3) decides if the launch asks for the LDS
+    static const int grid_tail = [] { const char* e = getenv("LAE_FRAME_GRID_TAIL"); return e ? atoi(e) : 1; }();   // 0: one encoder launch sized for the worst case (A/B)
     static const int emit_lds_min = [] { const char* e = getenv("LAE_FRAME_EMIT_LDS"); return e ? atoi(e) : 3; }();   // smallest n_step that takes the LDS path; 0: never (A/B)
     static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
     unsigned long long* flag_go = g_frame.flags;
@@ -2319,8 +2320,11 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
             k_frame_emit<false><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                  xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
                                                                  overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds, img_rows);
+        // rows the host EXPECTS: its bound of the rays alive x the n_step that bound implies (a second, small launch covers the
+        // rows beyond, which exist only in the iterations after n_step rose on the device)
+        const uint32_t rows_likely = grid_tail ? (uint32_t)std::min<uint64_t>(frame_padded_rows((uint64_t)bound_alive * std::max(n_lb, 1u)), rows_launch) : rows_launch;
         rc = lae::grid_forward_frame(xyzs, table_f16, offsets, feats, (uint32_t)cap, rows_launch, &cur->n_rows, L, S, base_resolution,
-                                     gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host);
+                                     gridtype, align_corners, interp, in_shift, in_scale, s, offsets_host, rows_likely);
         // head + compositing: one wave per run of 64-row groups; the survivors of wave u go, in order, to segment u of
         // stride R (> the rays a wave can own: bound_alive / units + 64 / units + 64) with their count
         if (rc == LAE_OK) {
