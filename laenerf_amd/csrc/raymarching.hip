@@ -2250,7 +2250,9 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     uint32_t bound_alive = N, seen_iter = 0;
     bool done = false;
     int rc = LAE_OK;
-    const uint32_t LAG = 4;
+    static const uint32_t LAG = [] { const char* e = getenv("LAE_FRAME_LAG"); return e ? (uint32_t)std::max(atoi(e), 1) : 2u; }();   // iterations the host may run ahead of the mirror.  Launches are sized from the mirror's n_alive: the fresher it is the fewer
+                                                           // workgroups find nothing to do (1 / 2 / 3 / 4 / 6: 800x800 9.99 / 10.01 / 10.03 / 10.15 / 10.23 ms, 1080p 56.4 / 56.4 / 57.4 / 57.4 / 58.4, shard 8.45 / 8.44 / 8.56 / 8.62 / 8.75;
+                                                           // the host needs ~45 us to launch an iteration that takes the device 130+: two iterations of slack are enough on this pool)
     uint32_t it = 0, nu_prev = 0, R_prev = 0;             // survivor segments (= waves of the previous k_frame_head) and their stride
     auto join_side = [&]() {                               // every exit path: the caller's stream owns the workspace again
         if (overlap && it > 0) k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | it, hung_d);
