@@ -240,7 +240,7 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
             dist.barrier()
 
     def frame():
-        return render_frame_sharded(render, o, d, rank, world)
+        return render_frame_sharded(render, o, d, rank, world, image_hw=(H, W))
     for _ in range(max(warmup, 2)):
         res = frame()
     sync()
@@ -263,7 +263,7 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
                 ts = []
                 for it in range(5):
                     torch.cuda.synchronize(); t1 = time.perf_counter()
-                    render_frame_sharded(lambda ro, rd: render(ro, rd, whole=True), o, d, 0, 1)
+                    render_frame_sharded(lambda ro, rd: render(ro, rd, whole=True), o, d, 0, 1, image_hw=(H, W))
                     torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
                 n1_ms = sorted(ts[2:])[1] * 1e3
             sync()
@@ -331,12 +331,15 @@ def frame1080(dev, frames=5):
             out = fn()
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         return sorted(ts[2:])[len(ts[2:]) // 2], out
-    t, res = timed(lambda: render_frame_sharded(render, o, d, 0, 1))
+    t, res = timed(lambda: render_frame_sharded(render, o, d, 0, 1, image_hw=(H, W)))
     whole = dict(stats)
-    t8, _ = timed(lambda: render_shard(render, o, d, 0, 8))
+    from laenerf_amd.dist import pixel_tile_order
+    order = pixel_tile_order((H, W), dev)                      # a rank's shard = its tiles of the pixel-tile ray order
+    ot, dt_ = o[order[0]], d[order[0]]
+    t8, _ = timed(lambda: render_shard(render, ot, dt_, 0, 8))
     ref8 = dict(stats)
     budget["rows"] = H * W                                     # the whole frame's row budget on the shard (what --gpus 8 runs)
-    t8b, _ = timed(lambda: render_shard(render, o, d, 0, 8))
+    t8b, _ = timed(lambda: render_shard(render, ot, dt_, 0, 8))
     budget["rows"] = 0
     return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
             "iterations": whole["iterations"], "samples_through_network": whole["rows"],

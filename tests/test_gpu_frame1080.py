@@ -62,6 +62,15 @@ def test_frame1080_partitions_reproduce_the_whole_frame_bit_for_bit(bonsai):
     one = render_frame_sharded(fn, o, d, 0, 1)                 # W = 1 through the public entry point
     for k in ("image", "depth", "weights_sum"):
         assert torch.equal(_bits(one[k]), _bits(whole[k])), k
+    tiled = render_frame_sharded(fn, o, d, 0, 1, image_hw=(H, W))   # rays dealt and rendered in 8 x 8 pixel tiles, results in the caller's order
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(_bits(tiled[k]), _bits(whole[k])), k
+    from laenerf_amd.dist import pixel_tile_order
+    order = pixel_tile_order((H, W), o.device)
+    blocks = [render_shard(fn, o[order[0]], d[order[0]], rank, 8) for rank in range(8)]
+    full = assemble_frame(blocks, H * W)
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(_bits(full[k][order[1]]), _bits(whole[k])), k
     for world in (2, 8):
         blocks = [render_shard(fn, o, d, rank, world) for rank in range(world)]       # the W ranks, one after the other
         assert len({b.shape for b in blocks}) == 1 and blocks[0].shape[1] == 5        # equal shards (all-gather requirement)

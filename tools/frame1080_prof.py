@@ -14,6 +14,10 @@ net, r = bench.eval_model(dev, bound=2, seed=1234)
 H, W = 1080, 1920
 o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
 o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+if os.environ.get("LAE_TILE", "8,8") != "0":                 # rays in th x tw pixel tiles (laenerf_amd.dist.PIXEL_TILE, what bench.py renders); "0": scanline order (A/B)
+    th, tw = (int(v) for v in os.environ.get("LAE_TILE", "8,8").split(","))
+    idx, inv = r._tile_perm(H, W, th, tw, dev)
+    o, d = o[idx].contiguous(), d[idx].contiguous()
 stats = {}
 if os.environ.get("LAE_FRAME_OVERLAP") == "0":              # lookahead in line on the caller's stream (A/B)
     from laenerf_amd.backend import raymarching_backend as _rb
