@@ -1775,6 +1775,103 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit(
     }
 }
 
+// k_frame_emit for iterations whose n_step is CERTAINLY 8 (the host's bound of n_alive already gives budget / bound >= 8, and 8
+// is the cap): rows of ray n are 8 n .. 8 n + 7, no padding.  The general kernel's LDS image for 64 rays x 8 samples is 13 KB per wave --
+// three workgroups per CU, 768 resident of the 1024 such a launch has: it ran in two rounds (22-24 us against 12-15 for n_step
+// 3-7).  Here a wave's rays go through a 32-ray image in two passes (6 KB per wave).  A separate kernel on purpose: the same two
+// passes inside k_frame_emit changed its register allocation and slowed EVERY path.
+constexpr uint32_t EMIT8_ROWS = 256;                       // 32 rays x 8 samples
+constexpr uint32_t EMIT8_FLOATS = 5u * EMIT8_ROWS + 128u + EMIT8_ROWS / 4u;   // xyz + delta rows, 32 x (direction, samples held), edit flags
+template <bool EDIT>
+__global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit8(
+    const FrameCtrl* __restrict__ prev, FrameCtrl* __restrict__ cur, FrameSegs sg, uint32_t N, uint32_t row_budget, uint32_t max_steps,
+    uint32_t max_n_step, int32_t* __restrict__ alive, LookRec in, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, MarchCfg cfg, float* __restrict__ xyzs, float* __restrict__ dirs,
+    float* __restrict__ deltas, uint8_t* __restrict__ edit_occ, const float* __restrict__ noises,
+    FrameMirror* __restrict__ mirror, uint64_t frame_id, unsigned long long* __restrict__ go, unsigned long long go_value, int go_early) {
+    __shared__ float emit8_lds[(FRAME_BLOCK / 64) * EMIT8_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (go && go_early && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const FrameSlot f = frame_locate(sg, N, wv, lane);
+    const FrameCtrl c = frame_next_ctrl(*prev, f.n_alive, row_budget, max_steps, max_n_step);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *cur = c;
+        mirror->total_rows = c.total_rows; mirror->iters = c.iter; mirror->n_alive = c.n_alive; mirror->done = c.done;   // done last
+        __threadfence_system();
+        mirror->tag = frame_id;
+        for (uint32_t row = c.n_rows; row < ((c.n_rows + 15u) & ~15u); row++) {     // pad rows of the last 16-row MLP tile
+            xyzs[3 * (size_t)row] = 0.f; xyzs[3 * (size_t)row + 1] = 0.f; xyzs[3 * (size_t)row + 2] = 0.f;
+            dirs[3 * (size_t)row] = 0.f; dirs[3 * (size_t)row + 1] = 0.f; dirs[3 * (size_t)row + 2] = 0.f;
+            deltas[2 * (size_t)row] = 0.f; deltas[2 * (size_t)row + 1] = 0.f;
+        }
+    }
+    const unsigned long long hm = __ballot(f.has);
+    if (!c.done && c.n_step == 8u && hm) {                     // (n_step == 8 by construction of the launch; valid lanes are a prefix of the wave)
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(hm);
+        float* img = emit8_lds + (size_t)(threadIdx.x >> 6) * EMIT8_FLOATS;
+        float* ix = img; float* il = img + 3 * EMIT8_ROWS; float* idr = img + 5 * EMIT8_ROWS;
+        uint8_t* ie = reinterpret_cast<uint8_t*>(img + 5 * EMIT8_ROWS + 128);
+        const uint32_t n_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.n);
+        Ray r{};
+        uint32_t have = 0;
+        float last_t = 0.f;
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+        unsigned long long ste = 0ull;
+        if (f.has) {
+            const uint32_t index = f.index;
+            alive[f.n] = (int32_t)index;
+            r = load_ray(rays_o, rays_d, index);
+            have = min(in.cnt[index], 8u);
+            last_t = in.tc[index];
+            if (sg.nu == 0) last_t = perturbed_start(cfg, last_t, noises, f.n);
+            ra = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[0];
+            rb = reinterpret_cast<const float4*>(in.t + (size_t)index * FRAME_LA)[1];
+            if (EDIT) ste = *reinterpret_cast<const unsigned long long*>(in.e + (size_t)index * FRAME_LA);
+        }
+        const float st[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2u; h++) {
+            const uint32_t lane_lo = h * 32u;
+            if (lane_lo >= cnt) break;
+            const uint32_t cnt_h = min(cnt - lane_lo, 32u), row0 = (n_first + lane_lo) * 8u, nrows = cnt_h * 8u;
+            if (f.has && (uint32_t)lane >= lane_lo && (uint32_t)lane < lane_lo + 32u) {
+                const uint32_t li = (uint32_t)lane - lane_lo;
+                idr[4 * li] = r.dx; idr[4 * li + 1] = r.dy; idr[4 * li + 2] = r.dz; idr[4 * li + 3] = __uint_as_float(have);
+                float lt = last_t;
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++) {
+                    const uint32_t lr = li * 8u + j;
+                    const bool real = j < have;                // the reference's buffers are torch.zeros
+                    const float t = st[j], dt = step_of(cfg, t), tn = t + dt;
+                    ix[3 * lr] = real ? clampf(fmaf(t, r.dx, r.ox), -cfg.bound, cfg.bound) : 0.f;
+                    ix[3 * lr + 1] = real ? clampf(fmaf(t, r.dy, r.oy), -cfg.bound, cfg.bound) : 0.f;
+                    ix[3 * lr + 2] = real ? clampf(fmaf(t, r.dz, r.oz), -cfg.bound, cfg.bound) : 0.f;
+                    il[2 * lr] = real ? dt : 0.f; il[2 * lr + 1] = real ? tn - lt : 0.f;
+                    if (real) lt = tn;
+                    if (EDIT) ie[lr] = real ? (uint8_t)(ste >> (8u * j)) : (uint8_t)0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                    // wave-private image: one wave's LDS accesses execute in order
+            float* ox = xyzs + 3 * (size_t)row0; float* od = dirs + 3 * (size_t)row0; float* ol = deltas + 2 * (size_t)row0;
+            for (uint32_t e = (uint32_t)lane; e < nrows * 3u; e += 64u) {
+                ox[e] = ix[e];
+                const uint32_t lr = (e * 21846u) >> 16, comp = e - 3u * lr;        // e / 3 for e < 4096
+                const float4 dh = reinterpret_cast<const float4*>(idr)[lr >> 3];
+                const float dv = comp == 0u ? dh.x : comp == 1u ? dh.y : dh.z;
+                od[e] = (lr & 7u) < __float_as_uint(dh.w) ? dv : 0.f;
+            }
+            for (uint32_t e = (uint32_t)lane; e < nrows * 2u; e += 64u) ol[e] = il[e];
+            if (EDIT) for (uint32_t e = (uint32_t)lane; e < nrows; e += 64u) edit_occ[row0 + e] = ie[e];
+            __builtin_amdgcn_wave_barrier();                    // the second pass overwrites the image
+        }
+    }
+    if (go && !go_early) {
+        const int last = __syncthreads_or((f.has && f.n + 1u == f.n_alive) || ((c.done || f.n_alive == 0u) && blockIdx.x == 0));
+        if (last && threadIdx.x == 0) { __threadfence(); __hip_atomic_store(go, go_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+}
+
 // renderer.py:381-383: the accumulators go out to the caller's arrays with the background blend and the depth normalisation
 __global__ void k_frame_finish(uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
                                const RayAcc* __restrict__ acc, float* __restrict__ weights_sum, float* __restrict__ depth,
@@ -2314,7 +2411,16 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t n_lb = (uint32_t)std::min<uint64_t>((uint64_t)budget / std::max(bound_alive, 1u), (uint64_t)max_n_step);
         const uint32_t img_rows = emit_img_rows(std::min(std::max(n_lb, 1u) + 1u, max_n_step));
         const uint32_t emit_lds_bytes = emit_lds ? (FRAME_BLOCK / 64) * emit_img_floats(img_rows) * 4u : 0u;
-        if (edit_grid)
+        static const int emit8_on = [] { const char* e = getenv("LAE_FRAME_EMIT8"); return e ? atoi(e) : 1; }();   // 0: the general emit kernel for n_step = 8 too (A/B)
+        if (emit8_on && emit_lds && n_lb >= 8u && edit_grid)
+            k_frame_emit8<true><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+                                                                 xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
+                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
+        else if (emit8_on && emit_lds && n_lb >= 8u)
+            k_frame_emit8<false><<<emit_blocks, FRAME_BLOCK, 0, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
+                                                                  xyzs, dirs, deltas, nullptr, noises, mirror_d, frame_id,
+                                                                  overlap ? flag_go : nullptr, fbase | (it + 1u), go_early);
+        else if (edit_grid)
             k_frame_emit<true><<<emit_blocks, FRAME_BLOCK, emit_lds_bytes, s>>>(prev, cur, sg, N, budget, max_steps, max_n_step, alive, rec[p], rays_o, rays_d, cfg,
                                                                 xyzs, dirs, deltas, edit_occ, noises, mirror_d, frame_id,
                                                                 overlap ? flag_go : nullptr, fbase | (it + 1u), go_early, emit_lds, img_rows);

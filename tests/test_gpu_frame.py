@@ -376,7 +376,7 @@ def test_lookahead_variants_render_the_same_bits(bound, n):
                       ("training schedule", {"LAE_GRID_FWD_FRAME_SCHED": "0"}), ("level halves", {"LAE_GRID_FWD_FRAME_SCHED": "2"}),
                       ("first walk queues", {"LAE_FRAME_COOP_MAX0": "16", "LAE_FRAME_MAX_ROUNDS": "4"}),
                       ("whole waves never handed over", {"LAE_FRAME_ADMIT_CAP": "0"}), ("one worst-case encoder launch", {"LAE_FRAME_GRID_TAIL": "0"}),
-                      ("overflow launch always", {"LAE_GRID_FWD_TAIL_MIN": "0"}), ("host one iteration ahead", {"LAE_FRAME_LAG": "1"}), ("host six iterations ahead", {"LAE_FRAME_LAG": "6"}), ("handed over after one round", {"LAE_FRAME_ADMIT_ROUND": "1", "LAE_FRAME_ADMIT_CAP": "100000"})):
+                      ("overflow launch always", {"LAE_GRID_FWD_TAIL_MIN": "0"}), ("host one iteration ahead", {"LAE_FRAME_LAG": "1"}), ("general emit kernel at 8 samples per ray", {"LAE_FRAME_EMIT8": "0"}), ("host six iterations ahead", {"LAE_FRAME_LAG": "6"}), ("handed over after one round", {"LAE_FRAME_ADMIT_ROUND": "1", "LAE_FRAME_ADMIT_CAP": "100000"})):
         e = dict(os.environ, **env)
         out = subprocess.run([sys.executable, "-c", _AB_SCRIPT.format(root=ROOT, bound=bound, n=n)], capture_output=True, text=True, timeout=600, env=e)
         lines = [l for l in out.stdout.splitlines() if l.startswith("HASH ")]
