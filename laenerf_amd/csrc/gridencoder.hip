@@ -428,10 +428,10 @@ constexpr uint32_t BK_TARGET = 32;            // target workgroups per level (le
                                               // the smallest levels' few cells take every sample's LDS atomics, more sub-ranges spread them over more CUs)
 
 struct LevelBins { uint32_t P, SUB; };
-__host__ __device__ __forceinline__ LevelBins level_bins_of(uint32_t hashmap_size) {
+__host__ __device__ __forceinline__ LevelBins level_bins_of(uint32_t hashmap_size, uint32_t bk_target = BK_TARGET) {
     LevelBins lb;
     lb.P = (hashmap_size + PART - 1) >> PART_SHIFT;
-    lb.SUB = lb.P >= BK_TARGET ? 1u : (BK_TARGET + lb.P - 1) / lb.P;
+    lb.SUB = lb.P >= bk_target ? 1u : (bk_target + lb.P - 1) / lb.P;
     return lb;
 }
 // A level goes through the binned pipeline when its partitions fit the directory rows; anything larger is left to the
@@ -543,7 +543,7 @@ constexpr int ACC_THREADS = 1024;
 constexpr uint32_t BWD_MAX_SAMPLES = 1u << 24;                  // byte offsets of the buffer loads (walk: 12 B per sample; accumulate: 8 B per item, 8 items per sample and level) stay below 2^31
 constexpr uint32_t COARSE_RES = 64;                            // levels coarser than this: consecutive queue items often repeat an entry (same ray, same cell)
 constexpr bool WIDE_COARSE_UNITS = false;                      // true: 16 samples per lane on those levels (round 3 experiment: accumulate 62.4 -> 58.4 us, but fill 58.3 -> 80.1 and count 27.5 -> 38.0 -- the wide blocks walk four dependent load groups and form the pass's tail; step 0.356 -> 0.433 ms)
-constexpr uint32_t SUB_RECS = 32;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
+constexpr uint32_t SUB_RECS = 64;                              // merge records per level: one per partition of a level that is split (P < BK_TARGET)
 constexpr uint32_t TICKET_ARRIVALS = 2;                        // tickets[0] = work queue; [2 + level * SUB_RECS + p] = arrivals
 constexpr uint32_t TICKET_WORDS = TICKET_ARRIVALS + MAX_LEVELS * SUB_RECS;
 template <typename T> constexpr uint32_t sub_rec_words() { return (sizeof(T) == 2 ? 2 * PART : PART) + PART / 64; }
@@ -1008,7 +1008,7 @@ template <typename T>
 __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t L, LevelScales sc, uint32_t gridtype,
     bool align_corners, BwdPlan plan, const typename BVal<T>::type* __restrict__ qvals, const uint16_t* __restrict__ qkeys,
-    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag) {
+    unsigned long long* __restrict__ partials, int32_t* __restrict__ nf_flag, uint32_t bk_target) {
     using V = typename BVal<T>::type;
     constexpr bool HALF = sizeof(T) == 2;
     constexpr uint32_t ACCW = HALF ? 2 * PART : PART;
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(ACC_THREADS, 8) void k_bwd_acc(
     __shared__ uint32_t s_ticket, s_arr;
     const uint32_t tid = threadIdx.x;
     if (tid < L) {
-        const LevelBins lb = level_bins_of((uint32_t)(offsets[tid + 1] - offsets[tid]));
+        const LevelBins lb = level_bins_of((uint32_t)(offsets[tid + 1] - offsets[tid]), bk_target);
         s_cnt[tid] = lb.P <= BK_MAX ? lb.P * lb.SUB : 0u;
         s_sub[tid] = lb.SUB;
     }
@@ -1751,7 +1751,11 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
         k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
     else
         k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
-    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag);
+    // workgroups per level: 32 up to ~400 k samples, 64 beyond (same-box A/B in round 4: lego, 258 k samples, 0.3508 / 0.3547 ms per
+    // step at 32 / 64; flower, 658 k, 0.666 / 0.647) -- the smallest levels' few cells take every sample's LDS atomics
+    static const uint32_t bk_env = [] { const char* e = getenv("LAE_GRID_BWD_BK_TARGET"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), (int)SUB_RECS) : 0u; }();
+    const uint32_t bk_target = bk_env ? bk_env : (B >= 400000u ? 64u : BK_TARGET);
+    k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag, bk_target);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made
     // (its blocks return at once for the levels the binned path has handled).

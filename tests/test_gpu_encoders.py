@@ -137,11 +137,12 @@ def test_grid_backward_modes_agree(O, kw):
     G.grid_encode_backward(T(g), T(x), T(table), T(offsets), ge, B, D, C, L, np.log2(pls), 16, None, None, gt, False, 0)
 
 
-@pytest.mark.parametrize("B,gscale", [(30000, 1e-1), (30001, 1e-1), (29999, 1e-1), (1022, 1e-1), (30000, 60.0), (20000, 2e-6)])
+@pytest.mark.parametrize("B,gscale", [(30000, 1e-1), (30001, 1e-1), (29999, 1e-1), (1022, 1e-1), (30000, 60.0), (20000, 2e-6), (400001, 1e-1)])
 def test_grid_backward_fp16_exact_sum(O, B, gscale):
     """fp16 mode of the binned pipeline = correctly rounded exact sum of the fp16-rounded contributions (int64 fixed point):
     compare with a float64 accumulation of the same rounded contributions; also deterministic across runs.  Batch sizes that
-    are not a multiple of the 4 samples a lane reads at once: the last lane's 1-3 samples must not be lost."""
+    are not a multiple of the 4 samples a lane reads at once: the last lane's 1-3 samples must not be lost.  From 400 k samples on
+    the accumulate pass deals 64 instead of 32 workgroups per level (more sub-ranges per partition, same exact sums)."""
     from laenerf_amd.backend import gridencoder_backend as G
     offsets, pls, table, x = grid_case(O, B=B)
     L, C = 16, 2
@@ -159,7 +160,7 @@ def test_grid_backward_fp16_exact_sum(O, B, gscale):
     assert err.max() < 2e-3 * np.abs(ref32).max() + 1e-6        # one fp16 rounding of the sum (+ per-contribution rounding)
 
 
-@pytest.mark.parametrize("B", [50000, 4099])
+@pytest.mark.parametrize("B", [50000, 4099, 400003])
 def test_grid_backward_fp16_bit_exact_on_lattice_points(O, B):
     """samples ON the vertices of a level whose scale is a power of two (resolution 17 -> scale 16, x = (k + 0.5) / 16):
     the interpolation weights are exactly 1 and 0, so every queue item is one of the fp16 gradients itself and the table
