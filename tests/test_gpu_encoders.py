@@ -171,6 +171,13 @@ def test_grid_backward_fp16_bit_exact_on_lattice_points(O, B):
     offsets, table, pls = offsets[:2].copy(), table[:offsets[1]], 1.0      # the first level alone: resolution 17, scale 16
     rng = np.random.default_rng(7)
     k = rng.integers(0, 16, (B, 3))
+    # neighbouring samples in different cells: a lane of the fill pass merges the (up to 4) consecutive samples it walks when
+    # they sit in one cell -- their fp32 sum becomes ONE fp16 item (test_..._same_cell_neighbours_merge_in_fp32 below)
+    while True:
+        same = np.zeros(B, bool)
+        for lag in (1, 2, 3): same[lag:] |= (k[lag:] == k[:-lag]).all(axis=1)
+        if not same.any(): break
+        k[same, 0] = (k[same, 0] + rng.integers(1, 16, int(same.sum()))) % 16
     x = ((k + 0.5) / 16.0).astype(np.float32)
     assert np.array_equal(x.astype(np.float64) * 16 + 0.5, k + 1.0)
     kinds = rng.integers(0, 4, (1, B, 2))
@@ -189,6 +196,32 @@ def test_grid_backward_fp16_bit_exact_on_lattice_points(O, B):
     zero = ((got_bits & 0x7fff) == 0) & ((want_bits & 0x7fff) == 0)               # +0 and -0 are the same gradient
     assert np.array_equal(np.where(zero, 0, got_bits), np.where(zero, 0, want_bits))
     assert (np.abs(want.astype(np.float64)) >= 128).any() and (np.abs(fix) < 1024).any()    # both conversion paths and subnormals were in play
+
+
+def test_grid_backward_same_cell_neighbours_merge_in_fp32(O):
+    """what a queue item is when consecutive samples share a cell: the lane that walks samples 4i .. 4i+3 adds the w*g of a run
+    of same-cell samples in fp32 and rounds that sum to fp16 ONCE (fewer roundings than one per sample, and far fewer than the
+    reference's one per atomicAdd(half2), gridencoder.cu:248-340).  Lattice points again (weights exactly 1 and 0): groups of
+    four samples in one cell with gradients whose fp32 sum is not an fp16 number."""
+    from laenerf_amd.backend import gridencoder_backend as G
+    offsets, _, table, _ = grid_case(O, L=2, base=17, desired=34, B=8)
+    offsets, table = offsets[:2].copy(), table[:offsets[1]]
+    B = 4 * 3000
+    rng = np.random.default_rng(11)
+    kc = rng.permutation(4096)[:B // 4]                                  # every group of four its own cell
+    k = np.repeat(np.stack([kc % 16, (kc // 16) % 16, kc // 256], axis=1), 4, axis=0)
+    x = ((k + 0.5) / 16.0).astype(np.float32)
+    gh = (rng.standard_normal((1, B, 2)) * np.array([300.0, 0.07, 5.0, 0.07])[None, np.arange(B) % 4, None]).astype(np.float16)
+    ge = torch.zeros(table.shape, device=DEV, dtype=torch.half)
+    G.grid_encode_backward(T(gh), T(x), T(table).half(), T(offsets), ge, B, 3, 2, 1, np.log2(1.0), 17, None, None, 0, False, 0)
+    idx = (k[::4, 0] + 1) + (k[::4, 1] + 1) * 18 + (k[::4, 2] + 1) * 324
+    g32 = gh[0].astype(np.float32).reshape(-1, 4, 2)
+    run = ((g32[:, 0] + g32[:, 1]) + g32[:, 2]) + g32[:, 3]              # the lane's order, fp32
+    want = np.zeros((table.shape[0], 2), np.float16); want[idx] = run.astype(np.float16)
+    exact = np.zeros((table.shape[0], 2), np.float16); exact[idx] = gh[0].astype(np.float64).reshape(-1, 4, 2).sum(axis=1).astype(np.float16)
+    got = N(ge)
+    assert np.array_equal(got, want)
+    assert np.abs(got.astype(np.float64) - exact.astype(np.float64)).max() <= 1.0       # at most one fp16 ulp (sums stay below 2048) from RN(exact sum)
 
 
 def test_grid_backward_reports_stored_nonfinite_values(O):
