@@ -275,7 +275,7 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
            "collective": "one all_gather_into_tensor of the [n/W, 5] fp32 block per frame" if world > 1 else "none (W = 1)",
            "backend": (dist.get_backend() if world > 1 else None), "world_size": (dist.get_world_size() if world > 1 else 1),
            "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
-           "parallelism": f"rays in 128-ray tiles dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}
+           "parallelism": f"rays in 8x8-pixel-tile order, 128-ray units (two pixel tiles) dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}
     if n1_ms is not None:
         out["n1_ms_per_frame"] = round(n1_ms, 3)
         out["speedup_vs_n1"] = round(n1_ms / ms, 3)
@@ -1020,7 +1020,7 @@ def main():
         }
         if sharded is not None:
             sharded["note"] = ("configs[3]-shaped (mip360/bonsai) 1080p inference frame, rays sharded over the ranks of THIS job "
-                               "(laenerf_amd/dist.py: 128-ray tiles round-robin, one all_gather_into_tensor per frame), 10 frames between "
+                               "(laenerf_amd/dist.py: 8x8-pixel-tile order, 128-ray units round-robin, one all_gather_into_tensor per frame), 10 frames between "
                                "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone (reference schedule)")
             out["frame1080"] = sharded                         # the north star's 8-GPU split (not `value`)
         if world == 1 and not args.no_frame:
