@@ -230,9 +230,10 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
     # the reference's rule on every rank.
     budget = 0 if (world == 1 or os.environ.get("LAE_FRAME_REFERENCE_SCHEDULE") == "1") else None
 
-    def render(ro, rd, whole=False):
+    def render(ro, rd, whole=None):
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
-            return r.render_eval(ro, rd, bg_color=1, max_steps=1024, row_budget=(0 if whole else world * ro.shape[0] if budget is None else budget))
+            return r.render_eval(ro, rd, bg_color=1, max_steps=1024,
+                                 row_budget=(whole if whole is not None else world * ro.shape[0] if budget is None else budget))
 
     def sync():
         torch.cuda.synchronize()
@@ -260,12 +261,15 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
         dist.all_gather_object(hashes, frame_hash)               # every rank holds the whole frame after the all-gather
         if with_n1:
             if rank == 0:                                        # the same model, the whole frame on ONE GPU, the others idle
-                ts = []
-                for it in range(5):
-                    torch.cuda.synchronize(); t1 = time.perf_counter()
-                    render_frame_sharded(lambda ro, rd: render(ro, rd, whole=True), o, d, 0, 1, image_hw=(H, W))
-                    torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
-                n1_ms = sorted(ts[2:])[1] * 1e3
+                n1_all = {}
+                for k in (0, 2, 4, 8):                           # 0 = the reference's rule; k x N rows per iteration otherwise
+                    ts = []
+                    for it in range(5):
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        render_frame_sharded(lambda ro, rd: render(ro, rd, whole=k * H * W), o, d, 0, 1, image_hw=(H, W))
+                        torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+                    n1_all["reference_rule" if k == 0 else f"{k}N"] = sorted(ts[2:])[1] * 1e3
+                n1_ms = n1_all["reference_rule"]
             sync()
     ms = dt / steps * 1e3
     tiles = -(-H * W // 128)
@@ -277,8 +281,12 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
            "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
            "parallelism": f"rays in 8x8-pixel-tile order, 128-ray units (two pixel tiles) dealt round-robin to {world} rank(s), one all-gather of [n/W,5] fp32 per frame"}
     if n1_ms is not None:
-        out["n1_ms_per_frame"] = round(n1_ms, 3)
-        out["speedup_vs_n1"] = round(n1_ms / ms, 3)
+        best = min(n1_all.values())
+        out["n1_ms_per_frame"] = round(n1_ms, 3)                 # the reference's schedule (renderer.py:363)
+        out["n1_row_budget_ms"] = {k: round(v, 3) for k, v in n1_all.items()}
+        out["best_n1_ms_per_frame"] = round(best, 3)             # the fastest one-GPU schedule: what strong scaling is quoted against
+        out["speedup_vs_n1"] = round(best / ms, 3)
+        out["speedup_vs_n1_reference_schedule"] = round(n1_ms / ms, 3)
     return out
 
 
@@ -333,6 +341,17 @@ def frame1080(dev, frames=5):
         return sorted(ts[2:])[len(ts[2:]) // 2], out
     t, res = timed(lambda: render_frame_sharded(render, o, d, 0, 1, image_hw=(H, W)))
     whole = dict(stats)
+    # the SAME whole frame on this one GPU with k x N rows per iteration (the boosted schedule a shard of a W-rank job runs,
+    # row_budget = W x its rays): strong scaling is quoted against the BEST one-GPU time, not against the reference rule's
+    boosted = {}
+    for k in (2, 4, 8):
+        budget["rows"] = k * H * W
+        tk, resk = timed(lambda: render_frame_sharded(render, o, d, 0, 1, image_hw=(H, W)))
+        boosted[f"{k}N"] = {"ms": round(tk * 1e3, 2), "iterations": stats["iterations"],
+                            "max_abs_image_diff_vs_reference_schedule": float((resk["image"] - res["image"]).abs().max())}
+    budget["rows"] = 0
+    best_key = min(boosted, key=lambda k: boosted[k]["ms"])
+    best_ms = min(t * 1e3, boosted[best_key]["ms"])
     from laenerf_amd.dist import pixel_tile_order
     order = pixel_tile_order((H, W), dev)                      # a rank's shard = its tiles of the pixel-tile ray order
     ot, dt_ = o[order[0]], d[order[0]]
@@ -345,8 +364,16 @@ def frame1080(dev, frames=5):
             "iterations": whole["iterations"], "samples_through_network": whole["rows"],
             "Msamples_per_s": round(whole["rows"] / t / 1e6, 1),
             "rays_hitting_geometry": round(float((res["weights_sum"] > 0).float().mean()), 3),
+            "reference_schedule_ms": round(t * 1e3, 2), "row_budget_ms": boosted,
+            "best_n1_ms_per_frame": round(best_ms, 2),
+            "best_n1_schedule": ("reference rule (N rows per iteration)" if best_ms == t * 1e3 else f"{best_key} rows per iteration"),
             "shard_of_8": {"ms": round(t8b * 1e3, 2), "iterations": stats["iterations"], "rays": int(-(-(-(-H * W // 128)) // 8) * 128),
                            "reference_schedule_ms": round(t8 * 1e3, 2), "reference_schedule_iterations": ref8["iterations"],
+                           "projected_speedup_at_8": {"vs_best_n1": round(best_ms / (t8b * 1e3), 2),
+                                                      "reference_rule_both_sides": round(t / t8, 2),
+                                                      "note": "one GPU's whole-frame time / this shard's time, before the 5.18 MB all-gather; "
+                                                              "`vs_best_n1` divides the fastest one-GPU schedule by the shard on the frame's "
+                                                              "row budget, `reference_rule_both_sides` keeps renderer.py:363's rule on both"},
                            "note": "rank 0's tiles of an 8-way round-robin split rendered alone on this one GPU, with the whole frame's "
                                    "row budget per iteration (what `--workload frame1080 --gpus 8` runs per rank) and with the "
                                    "reference's per-call rule"},
@@ -634,8 +661,50 @@ def cpu_baseline_cfg1(n_threads, budget_s=8.0):
                       f"backward incl. weight gradients, oracle operators for the hash grid / SH in {n_threads} chunks + torch CPU ops on {n_threads} threads, {dt:.1f} s"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside any rendezvous environment: start the N ranks ourselves, as a FRESH child --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
+    -- before this process has made any GPU call (subprocess, never exec), relay the child's stdout (rank 0's one JSON line) and
+    return its exit code; non-zero too when the child printed no line carrying `n_gpus: N`.  The driver's own torchrun form sets
+    WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                       # counts devices without initialising the GPU on this image
+    if n_dev < args.gpus and os.environ.get("LAE_BENCH_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {args.gpus} asks for {args.gpus} ranks on {args.gpus} GPUs of this node, which shows {n_dev}", file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    sys.stdout.write(child.stdout)
+    sys.stdout.flush()
+    if child.returncode != 0:
+        return child.returncode
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    try:
+        ok = len(lines) == 1 and json.loads(lines[0]).get("n_gpus") == args.gpus
+    except ValueError:
+        ok = False
+    if not ok:
+        print(f"bench.py: the {args.gpus}-rank child did not print one line with n_gpus == {args.gpus}", file=sys.stderr)
+        return 3
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                                   # no GPU call has happened in this process yet
+            raise SystemExit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a line that says n_gpus = WORLD_SIZE under a command that asked for --gpus N would be a silent non-measurement
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}: pass the same number to both",
+              file=sys.stderr)
+        raise SystemExit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -937,8 +1006,8 @@ def main():
         samples.append(step(n_warm + i))
     sync_all()
     dt = time.perf_counter() - t0
-    # spread: four more windows of the same K steps right after the timed one (a 9 ms window drifts by a few % on a box);
-    # `value` stays the first window, as the contract says (exactly K steps between the barriers)
+    # four more windows of the same K steps right after the first (a 7 ms window drifts by a few % on a box); every window is
+    # exactly K steps between barriers, `value` is their median
     windows = [dt]
     for wdw in range(1, 5):
         sync_all()
@@ -961,10 +1030,6 @@ def main():
     backend.enable_kernel_timing(False)
     if graph:
         timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
     # N > 1: the north star's split, beside the replica `value` -- the configs[3] frame ray-sharded over the ranks with ONE
     # all-gather per frame on the job's backend (RCCL under the driver), timed like `--workload frame1080`, and the same frame on
     # rank 0 alone for the speed-up.  Collective: every rank takes part, rank 0 reports.
@@ -972,6 +1037,12 @@ def main():
     if world > 1 and not args.no_frame:
         sharded = sharded_frame1080(world, rank, dev, backend_name, steps=10, warmup=2, with_n1=True)
 
+    if world > 1:                                           # every window: max over ranks (all ranks call the collective)
+        wmax = torch.tensor(windows, device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+        windows = [float(x) for x in wmax.tolist()]
+    first_window = windows[0]
+    dt = sorted(windows)[len(windows) // 2]                 # `value` = the MEDIAN of the five K-step windows
     if rank == 0:
         ms = dt / args.steps * 1e3
         gf = timing_grid.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
@@ -988,7 +1059,8 @@ def main():
             "metric": "Mrays/s, lego 800x800 train-step (4096 rays/step)",
             "value": round(world * args.rays * args.steps / dt / 1e6, 4),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": n_warm,
+            "n_gpus": world, "world_size": (dist.get_world_size() if world > 1 else 1),
+            "backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
             "config": {"workload": "configs[1]: lego-like 800x800 pinhole rays, 4096 random pixels of one view per step, L=16 T=2^19 F=2 hash grid "
@@ -1015,13 +1087,16 @@ def main():
                          "timed": "HIP events on the launch stream around the call in 20 eager steps after the timed region"},
             "windows": {"ms_per_step": [round(wd / args.steps * 1e3, 4) for wd in windows],
                         "min": round(min(windows) / args.steps * 1e3, 4), "median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
-                        "max": round(max(windows) / args.steps * 1e3, 4), "note": "5 consecutive windows of K steps; `value` is the first"},
+                        "max": round(max(windows) / args.steps * 1e3, 4), "first": round(first_window / args.steps * 1e3, 4),
+                        "note": "5 consecutive windows of exactly K steps, each between barriers + synchronize, max over ranks; "
+                                "`value` / `ms_per_step` are the MEDIAN window"},
             "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
         }
         if sharded is not None:
             sharded["note"] = ("configs[3]-shaped (mip360/bonsai) 1080p inference frame, rays sharded over the ranks of THIS job "
                                "(laenerf_amd/dist.py: 8x8-pixel-tile order, 128-ray units round-robin, one all_gather_into_tensor per frame), 10 frames between "
-                               "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone (reference schedule)")
+                               "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone on the reference schedule, "
+                               "best_n1_ms_per_frame: on the fastest of {reference rule, 2N, 4N, 8N rows per iteration}; speedup_vs_n1 divides THAT by ms_per_frame")
             out["frame1080"] = sharded                         # the north star's 8-GPU split (not `value`)
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)

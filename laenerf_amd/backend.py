@@ -76,16 +76,42 @@ def free_workspaces():
 
 
 # --------------------------------------------------------------------------- _raymarching
-# a loss value whose final sum was deferred (composite_rays_train_step(defer_loss=True)): (partials, n_part, n_elem, scale,
-# loss_out).  The fused head's backward takes it along; flush_pending_loss() finishes it with a launch of its own.
-_pending_loss = []
+# Loss values whose final sum was deferred (composite_rays_train_step(defer_loss=True)).  Round 5: keyed by
+# (device, data_ptr of the criterion node's grad_sigmas buffer) -- the tensor that autograd hands from the criterion node's
+# backward to the fused head's backward, i.e. the edge between exactly those two autograd nodes -- instead of one slot per
+# process: LAENeRF's flow holds two models, two optimizers and one scaler in one process (nerf/utils.py:969-972, 1041-1043), and
+# with one slot whichever head backward ran next summed whatever value was pending, also another model's on another stream.
+# Entry: (partials, n_part, n_elem, scale, loss_out, stream handle of the forward, made inside a capture?).  The head backward
+# that consumes THIS gradient buffer on THIS stream takes the value along in its reduction launch; everything else is finished
+# by flush_pending_loss() (a launch of its own, on the stream the value was made on).
+_pending_loss = {}
+_PENDING_MAX = 8                      # forwards whose backward never ran (no_grad loops) do not pile up: the oldest is finished
+deferred_loss_stats = {"carried": 0, "flushed": 0}
 
 
-def flush_pending_loss():
-    while _pending_loss:
-        partials, n_part, n_elem, scale, loss_out = _pending_loss.pop()
-        with torch.cuda.device(loss_out.device):
-            check(_lib.load().lae_loss_finish(ptr(partials), n_part, n_elem, ptr(scale), ptr(loss_out), stream()), "loss_finish")
+def _loss_key(grad_sigmas):
+    dev = grad_sigmas.device
+    return (dev.index if dev.index is not None else torch.cuda.current_device(), grad_sigmas.data_ptr())
+
+
+def _finish_entry(entry):
+    partials, n_part, n_elem, scale, loss_out, strm, _ = entry
+    with torch.cuda.device(loss_out.device):
+        check(_lib.load().lae_loss_finish(ptr(partials), n_part, n_elem, ptr(scale), ptr(loss_out), strm), "loss_finish")
+    deferred_loss_stats["flushed"] += 1
+
+
+def flush_pending_loss(device=None):
+    """finish every deferred loss value (of `device`, default all) that no head backward took along"""
+    for key in [k for k in _pending_loss if device is None or k[0] == device]:
+        _finish_entry(_pending_loss.pop(key))
+
+
+def retarget_pending_loss(old_grad_sigmas, new_grad_sigmas):
+    """the criterion node scaled its stored gradients by a general upstream gradient: the value now rides with the new tensor"""
+    e = _pending_loss.pop(_loss_key(old_grad_sigmas), None)
+    if e is not None:
+        _pending_loss[_loss_key(new_grad_sigmas)] = e
 
 
 class _RayMarching:
@@ -213,13 +239,21 @@ class _RayMarching:
             ptr(grad_image), ptr(grad_sigmas), ptr(grad_rgbs), ptr(loss_out), ptr(partials), int(bool(defer_loss)), stream()),
             "composite_rays_train_step")
         if defer_loss and N > 0:                      # N == 0: the library returned at once, there is nothing to finish
-            if _pending_loss and torch.cuda.is_current_stream_capturing():
-                # an older, eagerly made value would be finished INSIDE the capture: its buffers would be baked into the graph
-                # and freed with the entry; refuse instead
-                raise RuntimeError("composite_rays_train_step(defer_loss=True) inside a stream capture while an eager deferred loss is "
-                                   "pending: call laenerf_amd.backend.flush_pending_loss() before capturing")
-            flush_pending_loss()                      # an older value nobody finished (no backward ran): finish it now
-            _pending_loss[:] = [(partials, (N + 3) // 4, 3 * N, scale, loss_out)]
+            capturing = torch.cuda.is_current_stream_capturing()
+            key = _loss_key(grad_sigmas)
+            # entries that must be finished now: one under the same key (its gradient buffer was freed and reused: its backward
+            # can never run) and the oldest ones beyond the cap
+            stale = [k for k in _pending_loss if k == key]
+            others = [k for k in _pending_loss if k != key]
+            stale += others[:max(0, len(others) + 1 - _PENDING_MAX)]
+            for k in stale:
+                if capturing and not _pending_loss[k][6]:
+                    # an older, eagerly made value would be finished INSIDE the capture: its buffers would be baked into the
+                    # graph and freed with the entry; refuse instead
+                    raise RuntimeError("composite_rays_train_step(defer_loss=True) inside a stream capture while an eager deferred loss "
+                                       "is pending: call laenerf_amd.backend.flush_pending_loss() before capturing")
+                _finish_entry(_pending_loss.pop(k))
+            _pending_loss[key] = (partials, (N + 3) // 4, 3 * N, scale, loss_out, stream(), capturing)
 
     @staticmethod
     def composite_rays_train_backward_blend(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M,
@@ -513,10 +547,15 @@ class _FFMLP:
               grad_sigma_weights, grad_color_weights)
         need_cuda(*ts); need_contig(*ts)
         _FFMLP._half(enc, h, sigma_weights, color_weights, grad_h, grad_enc, grad_sigma_weights, grad_color_weights)
-        pend = _pending_loss.pop() if _pending_loss else None          # a deferred loss value rides in the reduction launch
-        if pend is not None and pend[0].device != grad_h.device:
-            _pending_loss.append(pend); pend = None
-        lp, ln, le, lsc, lo = pend if pend is not None else (None, 0, 0, None, None)
+        # the deferred loss value of the criterion node whose gradient THIS call consumes rides in the reduction launch -- only on
+        # the stream its partials were written on (another stream gives no ordering against them)
+        key = _loss_key(grad_sigmas)
+        pend = _pending_loss.get(key)
+        if pend is not None and pend[5] != stream():
+            pend = None
+        if pend is not None:
+            del _pending_loss[key]
+        lp, ln, le, lsc, lo = pend[:5] if pend is not None else (None, 0, 0, None, None)
         try:
             check(_lib.load().lae_nerf_head_backward(ptr(grad_sigmas), ptr(grad_rgbs), ptr(enc), ptr(dirs), ptr(h), ptr(rgbs),
                                                      ptr(sigma_weights), ptr(color_weights), M, float(density_scale),
@@ -525,8 +564,10 @@ class _FFMLP:
                                                      nonfinite_flag, ptr(lp), ln, le, ptr(lsc), ptr(lo), stream()), "nerf_head_backward")
         except RuntimeError:
             if pend is not None:
-                _pending_loss.append(pend)            # the launch failed: the value is still unfinished, flush_pending_loss() can finish it
+                _pending_loss[key] = pend             # the launch failed: the value is still unfinished, flush_pending_loss() can finish it
             raise
+        if pend is not None:
+            deferred_loss_stats["carried"] += 1
 
     @staticmethod
     def ffmlp_set_mode(mode):

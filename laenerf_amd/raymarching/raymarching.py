@@ -298,7 +298,10 @@ class _composite_rays_train_blend_mse(Function):
         grad_sigmas, grad_rgbs = ctx.saved_tensors
         if not _is_unit_root_grad(grad_loss):              # a general upstream gradient: d(loss) scales every sample gradient
             gl = grad_loss.float()
-            grad_sigmas, grad_rgbs = grad_sigmas * gl, grad_rgbs * gl
+            scaled = grad_sigmas * gl
+            from ..backend import retarget_pending_loss
+            retarget_pending_loss(grad_sigmas, scaled)     # a deferred loss value follows the tensor the head backward will receive
+            grad_sigmas, grad_rgbs = scaled, grad_rgbs * gl
         return grad_sigmas, grad_rgbs, None, None, None, None, None, None, None, None, None, None, None
 
 

@@ -271,10 +271,10 @@ def test_deferred_loss_value_is_finished_by_the_backward_pass():
             opt.backward(loss)                                   # the fused head's backward carries the sum
         elif how == "optimizer_backward_without_head":
             from laenerf_amd import backend
-            pend = list(backend._pending_loss); backend._pending_loss.clear()          # nobody takes it along ...
+            pend = dict(backend._pending_loss); backend._pending_loss.clear()          # nobody takes it along ...
             opt.backward(loss)
             assert torch.isnan(loss).item()
-            backend._pending_loss[:] = pend
+            backend._pending_loss.update(pend)
             opt.finish_loss()                                    # ... FusedAdam finishes it
         else:
             loss.backward()                                      # plain autograd backward: the head's backward carries it
@@ -373,3 +373,106 @@ def test_flower_shaped_full_size_properties(O):
     gr = torch.randn_like(y)
     y.backward(gr)
     assert enc.embeddings.grad.double().sum().item() == pytest.approx(gr.double().sum().item(), rel=1e-3, abs=1e-2)
+
+
+def test_deferred_loss_is_keyed_by_the_criterion_node_not_by_the_process():
+    """LAENeRF's flow holds two models, two optimizers and one scaler in one process (nerf/utils.py:969-972, 1041-1043).  The
+    deferred loss value of a criterion node is taken along ONLY by the head backward that consumes that node's gradient, on the
+    stream it was made on (round 4: one slot per process -- whichever head backward ran next summed whatever was pending).
+    Interleaved: two NeRF models (A forward, B forward, B backward, A backward), a LAENeRF palette step between A's forward and
+    backward, and backward on another stream than forward; every loss value holds the bits of the immediate sum."""
+    from types import SimpleNamespace
+    from laenerf_amd import backend, synthetic as S
+    from laenerf_amd.editing import LAENeRF
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+
+    def model(seed):
+        torch.manual_seed(seed)
+        net = NeRFNetwork(bound=1, log2_hashmap_size=14).to(DEV)
+        net.encoder.embeddings.data.uniform_(-0.3, 0.3)
+        r = NeRFRenderer(net, bound=1).to(DEV)
+        r.density_bitfield = T(S.pack_bits_np(S.sphere_density_grid(), 10.0))
+        net.train()
+        return net, r, FusedAdam(net, param_groups=net.get_params(1e-2), init_scale=512.0)
+    (netA, rA, optA), (netB, rB, optB) = model(5), model(6)
+    oA, dA = (T(x) for x in S.lego_like_rays(1000, seed=6))
+    oB, dB = (T(x) for x in S.lego_like_rays(1400, seed=7))
+    gtA, gtB = torch.rand(1000, 3, device=DEV), torch.rand(1400, 3, device=DEV)
+
+    def fwd(r, opt, o, d, gt, defer):
+        from laenerf_amd import raymarching as rm
+        with torch.autocast("cuda", dtype=torch.float16):
+            marched = r.march_train(o, d, perturb=False)
+            if defer:
+                return r.shade_train(marched, bg_color=1, gt=gt, scaler=opt)["loss"]
+            xyzs, dirs, deltas, rays, nears, fars = marched[:6]
+            sigmas, rgbs = r.network(xyzs, dirs) if hasattr(r, "network") else opt.module(xyzs, dirs)
+            return rm.composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, gt, 1, 1e-4, opt, defer_loss=False)[0]
+
+    def immediate(net, r, opt, o, d, gt):
+        from laenerf_amd import raymarching as rm
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            xyzs, dirs, deltas, rays, nears, fars = r.march_train(o, d, perturb=False)[:6]
+            sigmas, rgbs = net(xyzs, dirs)
+            loss = rm.composite_rays_train_blend_mse(sigmas, rgbs, deltas, rays, nears, fars, gt, 1, 1e-4, opt, defer_loss=False)[0]
+        opt.backward(loss)
+        out = (loss.detach().clone(), loss.unscaled.clone(), net.sigma_net.shadow.grad_half.clone())
+        opt.zero_grad()
+        return out
+    refA, refB = immediate(netA, rA, optA, oA, dA, gtA), immediate(netB, rB, optB, oB, dB, gtB)
+
+    def same(loss, net, ref):
+        assert torch.equal(loss.detach(), ref[0]) and torch.equal(loss.unscaled, ref[1]) and torch.equal(net.sigma_net.shadow.grad_half, ref[2])
+
+    # 1. two NeRF models interleaved on one stream: each value rides in ITS OWN head backward
+    backend.flush_pending_loss()
+    st0 = dict(backend.deferred_loss_stats)
+    lA = fwd(rA, optA, oA, dA, gtA, True)
+    lB = fwd(rB, optB, oB, dB, gtB, True)
+    assert torch.isnan(lA).item() and torch.isnan(lB).item() and len(backend._pending_loss) == 2
+    lB.backward(gradient=torch.ones_like(lB))                  # plain autograd backward of B: must not touch A's value
+    assert torch.isnan(lA).item() and len(backend._pending_loss) == 1
+    same(lB, netB, refB)
+    optA.backward(lA)
+    same(lA, netA, refA)
+    st1 = dict(backend.deferred_loss_stats)
+    assert st1["carried"] - st0["carried"] == 2 and st1["flushed"] == st0["flushed"] and not backend._pending_loss
+    optA.zero_grad(); optB.zero_grad()
+
+    # 2. a LAENeRF palette step (its own FusedAdam) between A's forward and A's backward
+    params = SimpleNamespace(bound=1, num_palette_bases=8, style_weight=0, weight_loss_uniform=1e-3, weight_loss_non_uniform=1e-3,
+                             offset_loss=1e-2, palette_loss_valid=1.0, palette_loss_distinct=1e-2)
+    torch.manual_seed(7)
+    m = LAENeRF(params, dir_encoding="sphere_harmonics").to(DEV).train()
+    optS = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
+    x = (torch.rand(5000, 3, device=DEV) - 0.5) * 0.6
+    dd = torch.nn.functional.normalize(torch.randn(5000, 3, device=DEV), dim=-1)
+    tgt = torch.rand(5000, 3, device=DEV)
+    lA = fwd(rA, optA, oA, dA, gtA, True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        lS = m.forward_train_loss(x, dd, tgt, params, optS, with_palet_loss=True)[0]
+    optS.backward(lS)                                          # FusedAdam.backward finishes what is pending: A's value too, on A's stream
+    optS.step()
+    assert torch.isfinite(lS).item()
+    optA.backward(lA)
+    same(lA, netA, refA)
+    optA.zero_grad()
+
+    # 3. forward on one stream, backward on another: the head backward does not take the value along (no ordering against the
+    # partials on that stream); it is finished on the stream it was made on
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        lA = fwd(rA, optA, oA, dA, gtA, True)
+    s2.wait_stream(s1)
+    st2 = dict(backend.deferred_loss_stats)
+    with torch.cuda.stream(s2):
+        lA.backward(gradient=torch.ones_like(lA))
+    assert backend.deferred_loss_stats["carried"] == st2["carried"] and len(backend._pending_loss) == 1
+    backend.flush_pending_loss()
+    torch.cuda.synchronize()
+    same(lA, netA, refA)
+    optA.zero_grad()

@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: sizing rules, parameter layout, error behaviour, no CPU fallback."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -129,3 +131,24 @@ def test_grid_forward_schedule_covers_every_chunk_once_and_balances(hip_lib):
             assert all(owners[l] == {l % 8} for l in range(L))
         elif L == 16:
             assert any(len(owners[l]) > 1 for l in range(L) if not hashed[l])   # dense levels are dealt out in pieces
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """`bench.py --gpus N` under a launcher that set another WORLD_SIZE, or on a node with fewer than N GPUs, exits non-zero
+    BEFORE any GPU call instead of printing a line for a different rank count (`--gpus 8` used to run one rank,
+    print n_gpus 1 and exit 0)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LAE_BENCH_SINGLE_DEVICE")}
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and not out.stdout.strip()
+    out = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and not out.stdout.strip()
+    import torch
+    if torch.cuda.device_count() < 64:
+        out = subprocess.run([sys.executable, bench, "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 2 and "asks for 64" in out.stderr and not out.stdout.strip()
