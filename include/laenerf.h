@@ -75,10 +75,10 @@ extern "C" {
 
 /* library identification: returns the static string "laenerf-hip gfx950 " LAE_ABI_TAG.  The tag changes whenever a
  * signature of this header changes incompatibly (abi2: round 2 added pointer arguments in the middle of the optimizer /
- * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step; abi4: round 4, lae_ffmlp_set_mode values 2 and 16-18 removed).  A binding compares
+ * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step; abi4: round 4, lae_ffmlp_set_mode values 2 and 16-18 removed; abi5: round 5, lae_render_frame_mode, frame-loop degrade path).  A binding compares
  * it with the tag it was written against BEFORE the first call: a stale .so used through newer prototypes would misalign
  * arguments silently (laenerf_amd/_lib.py does, and rebuilds or raises). */
-#define LAE_ABI_TAG "abi4"
+#define LAE_ABI_TAG "abi5"
 LAE_API const char* lae_version(void);
 /* last HIP error string recorded by a failed launch in this thread (or "") */
 LAE_API const char* lae_last_error(void);
@@ -239,9 +239,19 @@ LAE_API int lae_composite_rays_distill(uint32_t n_alive, uint32_t n_step, float 
  *   stats_out (host, may be NULL; makes the call wait for the loop's last iteration): [iterations, rows through the
  *   network, iterations launched]. */
 LAE_API uint64_t lae_render_frame_workspace_bytes(uint32_t N, uint32_t L, uint64_t row_budget);
-/* A/B switch: 1 (default) runs the lookahead marcher on a library-owned side stream beside the encoder / MLP kernels,
- * 0 runs it in-line on the caller's stream. */
+/* 1 (default) runs the lookahead marcher on a library-owned side stream beside the encoder / MLP kernels, 0 runs it
+ * in-line on the caller's stream (same image bit for bit).  CONCURRENCY REQUIREMENT of the overlapped form: the two streams
+ * are ordered by polled words in device memory, not by events, so they must make progress side by side.  The library probes
+ * that once per caller stream (a wait kernel on the caller's stream, then a signal kernel on the side stream) and runs in
+ * line by itself -- with one warning on stderr -- when they do not: both on one hardware queue (GPU_MAX_HW_QUEUES=1, many
+ * live streams of one priority), serialised dispatch (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING), a counter-collecting
+ * profiler.  A wait that still times out (~10 s) poisons its frame (outputs NaN, never a wrong image), the call renders
+ * the frame again in line and the process stays in line from then on; LAE_ELAUNCH only if that fails too.  The reference's
+ * loop has no such failure mode (nerf/renderer.py:335-387).  LAE_FRAME_OVERLAP=0 / 1 pins the mode (1 skips the probe). */
 LAE_API int lae_render_frame_set_overlap(int on);
+/* how the most recent frame ran: 1 = lookahead on the side stream, 0 = in line (switched off, probed as not concurrent, or
+ * degraded after a time-out); before the first frame: the configured mode */
+LAE_API int lae_render_frame_mode(void);
 LAE_API int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
                      const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
                      uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,

@@ -359,6 +359,12 @@ class _RayMarching:
         """A/B switch: lookahead marcher on a side stream beside the network kernels (default) or in-line"""
         check(_lib.load().lae_render_frame_set_overlap(int(bool(on))), "render_frame_set_overlap")
 
+    @staticmethod
+    def render_frame_mode():
+        """1 while frames overlap their lookahead on the side stream; 0 once switched off, probed as not concurrent, or degraded
+        after a cross-stream wait timed out (include/laenerf.h)"""
+        return int(_lib.load().lae_render_frame_mode())
+
     # MI355X-native extension (no reference counterpart): device-side alive-list compaction
     @staticmethod
     def compact_rays_alive(rays_alive, n_alive, out_alive, n_out_dev):

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(COMPACT_BLOCK) void k_compact_scatter(const int32_t
 // sample), so every iteration starts from bit-identical times to the host loop's.
 using lae::FrameCtrl;                          // lae_common.h (shared with the head kernel, ffmlp.hip)
 using lae::RayAcc;
-struct FrameMirror { volatile uint64_t tag; volatile uint32_t n_alive, done, total_rows, iters, hung; };   // pinned host memory; hung: a k_frame_wait gave up
+struct FrameMirror { volatile uint64_t tag; volatile uint32_t n_alive, done, total_rows, iters, hung; };   // pinned host memory; hung: low 32 bits of the frame number in which a k_frame_wait gave up (0: never)
 constexpr int FRAME_BLOCK = 256;
 constexpr uint32_t FRAME_SEG_MAX = 4096;       // survivor segments = waves of the head + compositing kernel (k_frame_head, ffmlp.hip)
 constexpr uint32_t FRAME_SEG_SLACK = 200;      // a segment's stride exceeds bound_alive / segments by < 66 + 63 + 64 (see the stride below)
@@ -1329,13 +1329,35 @@ __device__ __forceinline__ FrameSlot frame_locate(const FrameSegs& sg, uint32_t 
 __global__ void k_frame_signal(unsigned long long* __restrict__ flag, unsigned long long value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_frame_wait(const unsigned long long* __restrict__ flag, unsigned long long value, volatile uint32_t* __restrict__ hung) {
-    // bounded (~ seconds): a producer that never comes (a failed launch on the other stream) must not hang the device
-    for (uint32_t spin = 0; spin < (1u << 23); spin++) {
+// A wait that gives up POISONS its frame (round 5): it stores the frame's tag in a device word the lookahead
+// kernels test before they touch anything (the segments they would read are not there yet) and k_frame_finish tests before it
+// writes the outputs (NaN instead of an image composited from rows that were never marched), and in the pinned mirror for the
+// host, which then renders the frame again with the lookahead in line (lae_render_frame).  Later waits of a poisoned frame
+// return at once, so an aborted frame drains in one time-out, not one per queued wait.
+__global__ void k_frame_wait(const unsigned long long* __restrict__ flag, unsigned long long value, uint32_t* __restrict__ hung_dev,
+                             volatile uint32_t* __restrict__ hung_host, uint32_t tag, uint32_t spins) {
+    if (__hip_atomic_load(hung_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) return;
+    // bounded (2^23 polls ~ 10 s): a producer that never comes (a failed launch on the other stream, two streams that share one
+    // hardware queue) must not hang the device
+    for (uint32_t spin = 0; spin < spins; spin++) {
         if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) return;
         __builtin_amdgcn_s_sleep(4);
     }
-    if (threadIdx.x == 0) *hung = 1u;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(hung_dev, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        *hung_host = tag;
+    }
+}
+// one-time probe per caller stream (lae_render_frame): can a kernel on `a` see a store made by a kernel that was launched LATER
+// on `b`?  result: 1 = yes (the streams run side by side), 2 = no (one hardware queue, serialised dispatch, a profiler that
+// collects counters): the frame loop then runs its lookahead in line
+__global__ void k_frame_probe_wait(const unsigned long long* __restrict__ flag, unsigned long long value, volatile uint32_t* __restrict__ result,
+                                   uint32_t spins) {
+    for (uint32_t spin = 0; spin < spins; spin++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) { if (threadIdx.x == 0) *result = 1u; return; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (threadIdx.x == 0) *result = 2u;
 }
 // the next loop state from the previous one and the number of survivors (renderer.py:352,363,377); evaluated with the same
 // arguments by the emit kernel (which publishes it) and by the lookahead kernel (which only needs n_step and done)
@@ -1380,7 +1402,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ fars, MarchCfg cfg,
     const uint8_t* __restrict__ grid, const uint8_t* __restrict__ edit_grid, const float* __restrict__ noises,
     uint32_t* __restrict__ q_count, LookTask* __restrict__ q_tasks, int spec, int coop_max, int max_rounds,
-    const uint8_t* __restrict__ cdist, uint32_t admit_cap, int admit_round) {
+    const uint8_t* __restrict__ cdist, uint32_t admit_cap, int admit_round, const uint32_t* __restrict__ hung_dev, uint32_t hung_tag) {
+    if (*hung_dev == hung_tag) return;                     // a wait of this frame gave up: the survivor segments are not there (k_frame_wait)
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (FRAME_BLOCK / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     LOOK_NOTE(0, wall_clock64());
@@ -1876,9 +1899,17 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_emit8(
 __global__ void k_frame_finish(uint32_t N, const float* __restrict__ nears, const float* __restrict__ fars,
                                const RayAcc* __restrict__ acc, float* __restrict__ weights_sum, float* __restrict__ depth,
                                float* __restrict__ image, float* __restrict__ weights_edit, float* __restrict__ depth_edit,
-                               const float* __restrict__ bg_rays, float bg_r, float bg_g, float bg_b, int blend_bg, int scale_depth) {
+                               const float* __restrict__ bg_rays, float bg_r, float bg_g, float bg_b, int blend_bg, int scale_depth,
+                               const uint32_t* __restrict__ hung_dev, uint32_t hung_tag) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    if (*hung_dev == hung_tag) {                           // a cross-stream wait of this frame gave up: never hand out what was composited
+        const float q = __builtin_nanf("");
+        weights_sum[n] = q; depth[n] = q;
+        image[3 * (size_t)n] = q; image[3 * (size_t)n + 1] = q; image[3 * (size_t)n + 2] = q;
+        if (weights_edit) { weights_edit[n] = q; depth_edit[n] = q; }
+        return;
+    }
     const float4 a0 = reinterpret_cast<const float4*>(acc + n)[0], a1 = reinterpret_cast<const float4*>(acc + n)[1];
     float r = a0.z, g = a0.w, b = a1.x, d = a0.y;
     if (blend_bg) {
@@ -2188,6 +2219,14 @@ struct FrameHost {                                        // process-wide helper
     hipStream_t last_stream = nullptr;                    // stream of the previous frame (its tail may still be queued)
     bool have_last = false;
     bool ok = false;
+    // flags[2] (as uint32): tag of the frame a wait gave up in; flags[3]: the probe's word
+    int last_mode = -1;                                   // how the most recent frame ran: 1 overlapped, 0 in line, -1 no frame yet
+    bool degraded = false;                                // a frame's handshake gave up once: every later frame runs its lookahead in line
+    bool warned = false;
+    hipStream_t probed[8] = {};                           // caller streams whose concurrency with `side` was probed, and the verdicts
+    bool probed_ok[8] = {};
+    int n_probed = 0;
+    uint64_t probe_counter = 0;
     bool init() {
         if (ok) return true;
         void* hp = nullptr; void* dp = nullptr;
@@ -2211,11 +2250,46 @@ struct FrameHost {                                        // process-wide helper
 FrameHost g_frame;
 std::mutex g_frame_mtx;
 int g_frame_overlap = 1;                                  // 0: lookahead in-line on the caller's stream (A/B switch)
+uint32_t frame_wait_spins() {                             // polls before a k_frame_wait gives up; LAE_FRAME_WAIT_SPINS_LOG2 shortens it for the tests
+    static const uint32_t v = [] { const char* e = getenv("LAE_FRAME_WAIT_SPINS_LOG2"); const int l = e ? atoi(e) : 23; return 1u << std::min(std::max(l, 8), 26); }();
+    return v;
+}
+void frame_warn_once(const char* why) {
+    if (g_frame.warned) return;
+    g_frame.warned = true;
+    fprintf(stderr, "laenerf_amd: render_frame: %s; the lookahead marcher runs in line on the caller's stream from now on "
+                    "(same image bit for bit, ~10-25 %% slower frames)\n", why);
+}
+// Can the caller's stream and the side stream make progress side by side?  The handshake below needs it: a wait kernel on one
+// stream polls a word a kernel on the other stream stores.  Not when both map to one hardware queue (GPU_MAX_HW_QUEUES=1, many
+// live streams of one priority), when dispatch is serialised (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) or under a profiler
+// that collects counters.  Probed once per caller stream: a wait on `s`, THEN a signal on the side stream; ~15 us when it
+// passes, ~40 ms once when it does not.
+bool frame_streams_concurrent(hipStream_t s) {
+    for (int i = 0; i < g_frame.n_probed; i++)
+        if (g_frame.probed[i] == s) return g_frame.probed_ok[i];
+    volatile uint32_t* res_h = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(g_frame.mirror_h) + 128);
+    volatile uint32_t* res_d = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(g_frame.mirror_d) + 128);
+    *res_h = 0u;
+    const unsigned long long v = ++g_frame.probe_counter;
+    k_frame_probe_wait<<<1, 64, 0, s>>>(g_frame.flags + 3, v, res_d, 1u << 15);
+    k_frame_signal<<<1, 1, 0, g_frame.side>>>(g_frame.flags + 3, v);
+    bool ok = hipStreamSynchronize(g_frame.side) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && *res_h == 1u;
+    const int slot = g_frame.n_probed < 8 ? g_frame.n_probed++ : (int)(g_frame.probe_counter & 7u);
+    g_frame.probed[slot] = s; g_frame.probed_ok[slot] = ok;
+    return ok;
+}
 }  // namespace
 
 int lae_render_frame_set_overlap(int on) { g_frame_overlap = on ? 1 : 0; return LAE_OK; }
 
-int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
+// how the most recent frame ran: 1 = lookahead on the side stream, 0 = in line (switched off, probed as not concurrent, or degraded after a time-out)
+int lae_render_frame_mode(void) {
+    std::lock_guard<std::mutex> lk(g_frame_mtx);
+    return g_frame.last_mode >= 0 ? g_frame.last_mode : (g_frame_overlap != 0 && !g_frame.degraded ? 1 : 0);
+}
+
+static int render_frame_once(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
                      const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
                      uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,
                      uint32_t L, float S,
@@ -2224,30 +2298,16 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
                      uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
                      float bg_b, int blend_bg, int scale_depth, float* weights_sum, float* depth, float* image,
                      float* weights_edit, float* depth_edit, void* workspace, uint64_t workspace_bytes, uint32_t* stats_out,
-                     void* stream) {
-    if (N == 0) return LAE_OK;
-    if (!rays_o || !rays_d || !aabb || !grid || !table_f16 || !offsets || !sigma_weights || !color_weights || !weights_sum ||
-        !depth || !image || !workspace)
-        return LAE_ENULL;
-    if (edit_grid && (!weights_edit || !depth_edit)) return LAE_ENULL;
-    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0 || max_n_step == 0 || max_n_step > FRAME_LA || L != 16) return LAE_EINVAL;
-    if (workspace_bytes < lae_render_frame_workspace_bytes(N, L, row_budget)) return LAE_EINVAL;
+                     void* stream, const bool overlap, bool* gave_up) {
+    // one pass of the loop (g_frame_mtx held, arguments checked by lae_render_frame); *gave_up: a cross-stream wait timed out
+    // or the device made no progress -- the frame is poisoned (NaN) and both streams are drained
     hipStream_t s = STREAM(stream);
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-        lae::set_last_error_str("render_frame: the frame loop adapts its launches to the device state and cannot be stream-captured");
-        return LAE_EINVAL;
-    }
-    std::lock_guard<std::mutex> lk(g_frame_mtx);
-    if (!g_frame.init()) { lae::set_last_error_str("render_frame: could not create the pinned mirror / side stream / events"); return LAE_ELAUNCH; }
     FrameMirror* mirror_h = g_frame.mirror_h;
     FrameMirror* mirror_d = g_frame.mirror_d;
-    // One mirror / side stream / event ring per process (one process per GPU): frames on the SAME stream are ordered by the
-    // stream itself; a frame on another stream first waits for the previous frame's queued tail.
-    if (g_frame.have_last && g_frame.last_stream != s) (void)hipStreamSynchronize(g_frame.last_stream);
-    g_frame.last_stream = s; g_frame.have_last = true;
     const uint64_t frame_id = ++g_frame.frame_counter;
-    const bool overlap = g_frame_overlap != 0;
+    const uint32_t hung_tag = (uint32_t)frame_id;          // never 0
+    uint32_t* hung_dev = reinterpret_cast<uint32_t*>(g_frame.flags + 2);
+    const uint32_t spins = frame_wait_spins();
     hipStream_t ls = overlap ? g_frame.side : s;           // stream of the lookahead marcher
 
     // carve the workspace
@@ -2309,11 +2369,11 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t fin_blocks = std::min(FRAME_FINISH_BLOCKS, std::max(1u, lae::cdiv(n_bound, FRAME_BLOCK / 64)));
         if (edit_grid) {
             k_frame_lookahead<true><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round);
+                                                                 cfg, grid, edit_grid, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round, hung_dev, hung_tag);
             if (qt) k_frame_lookahead_finish<true><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, edit_grid, cdist);
         } else {
             k_frame_lookahead<false><<<blocks, FRAME_BLOCK, 0, q>>>(phase, pv, sg, N, budget, max_steps, max_n_step, in, out, rays_o, rays_d, fars,
-                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round);
+                                                                  cfg, grid, nullptr, noises, qc, qt, spec_visits, phase < 0 && coop_max0 >= 0 ? coop_max0 : coop_max, max_rounds, cdist, phase < 0 ? 0u : admit_cap, admit_round, hung_dev, hung_tag);
             if (qt) k_frame_lookahead_finish<false><<<fin_blocks, FRAME_BLOCK, 0, q>>>(max_n_step, qc, qc_next, qt, out, rays_o, rays_d, fars, cfg, grid, nullptr, cdist);
         }
     };
@@ -2343,7 +2403,6 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     unsigned long long* flag_look = g_frame.flags + 1;
     const unsigned long long fbase = (unsigned long long)frame_id << 32;
     volatile uint32_t* hung_d = &mirror_d->hung;
-    mirror_h->hung = 0;
     uint32_t bound_alive = N, seen_iter = 0;
     bool done = false;
     int rc = LAE_OK;
@@ -2352,7 +2411,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
                                                            // the host needs ~45 us to launch an iteration that takes the device 130+: two iterations of slack are enough on this pool)
     uint32_t it = 0, nu_prev = 0, R_prev = 0;             // survivor segments (= waves of the previous k_frame_head) and their stride
     auto join_side = [&]() {                               // every exit path: the caller's stream owns the workspace again
-        if (overlap && it > 0) k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | it, hung_d);
+        if (overlap && it > 0) k_frame_wait<<<1, 64, 0, s>>>(flag_look, fbase | it, hung_dev, hung_d, hung_tag, spins);
     };
     auto abort_frame = [&]() {                             // a launch failed: release whoever polls for work that will never come
         if (overlap) {
@@ -2360,6 +2419,13 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
             k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | 0xffffffffull);
             (void)hipStreamSynchronize(ls);
         }
+    };
+    auto give_up = [&]() {                                 // the handshake made no progress: drain both streams, the caller renders again in line
+        abort_frame();
+        (void)hipStreamSynchronize(s);
+        *gave_up = true;
+        lae::set_last_error_str("render_frame: device made no progress");
+        return LAE_ELAUNCH;
     };
     auto poll = [&]() {
         if (mirror_h->tag != frame_id) return;
@@ -2383,11 +2449,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
             const auto t0 = std::chrono::steady_clock::now();
             while (it >= seen_iter + LAG && !done) {
                 poll();
-                if (mirror_h->hung || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    lae::set_last_error_str("render_frame: device made no progress");
-                    abort_frame();
-                    return LAE_ELAUNCH;
-                }
+                if (mirror_h->hung == hung_tag || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return give_up();
             }
             if (done) break;
         }
@@ -2399,7 +2461,7 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
         const uint32_t rows_bound = (uint32_t)std::min<uint64_t>((uint64_t)budget, (uint64_t)max_n_step * bound_alive);
         const uint32_t rows_launch = (uint32_t)std::min<uint64_t>(frame_padded_rows(rows_bound), cap);
         // side chain: lookahead for the NEXT iteration's samples
-        if (overlap) k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 1u), hung_d);
+        if (overlap) k_frame_wait<<<1, 64, 0, ls>>>(flag_go, fbase | (it + 1u), hung_dev, hung_d, hung_tag, spins);
         lookahead((int)it, prev, sg, rec[p], rec[p ^ 1u], list_waves, bound_alive, ls);
         if (overlap) k_frame_signal<<<1, 1, 0, ls>>>(flag_look, fbase | (it + 1u));
         // caller's chain: the samples of this iteration come from the previous lookahead
@@ -2456,18 +2518,82 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     }
     join_side();
     k_frame_finish<<<lae::cdiv(N, 256), 256, 0, s>>>(N, nears, fars, acc, weights_sum, depth, image, edit_grid ? weights_edit : nullptr,
-                                                     edit_grid ? depth_edit : nullptr, bg_rays, bg_r, bg_g, bg_b, blend_bg, scale_depth);
+                                                     edit_grid ? depth_edit : nullptr, bg_rays, bg_r, bg_g, bg_b, blend_bg, scale_depth,
+                                                     hung_dev, hung_tag);
     rc = lae::check_launch("render_frame(finish)");
     if (rc) return rc;
+    if (mirror_h->hung == hung_tag) return give_up();      // a wait gave up behind the host's back (the finish kernel wrote NaN)
     if (stats_out) {
         // the loop ends either on `done` (mirror holds the final state) or after max_steps + 1 launched iterations
         const auto t0 = std::chrono::steady_clock::now();
         while (!(mirror_h->tag == frame_id && mirror_h->done)) {     // the done flag is the last word the device writes
+            if (mirror_h->hung == hung_tag) return give_up();
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
         }
         stats_out[0] = mirror_h->iters; stats_out[1] = mirror_h->total_rows; stats_out[2] = it;
     }
     return LAE_OK;
+}
+
+int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
+                     const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
+                     uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,
+                     uint32_t L, float S,
+                     uint32_t base_resolution, uint32_t gridtype, int align_corners, uint32_t interp,
+                     const void* sigma_weights, const void* color_weights, float density_scale, float T_thresh,
+                     uint32_t max_n_step, uint64_t row_budget, const float* noises, const float* bg_rays, float bg_r, float bg_g,
+                     float bg_b, int blend_bg, int scale_depth, float* weights_sum, float* depth, float* image,
+                     float* weights_edit, float* depth_edit, void* workspace, uint64_t workspace_bytes, uint32_t* stats_out,
+                     void* stream) {
+    if (N == 0) return LAE_OK;
+    if (!rays_o || !rays_d || !aabb || !grid || !table_f16 || !offsets || !sigma_weights || !color_weights || !weights_sum ||
+        !depth || !image || !workspace)
+        return LAE_ENULL;
+    if (edit_grid && (!weights_edit || !depth_edit)) return LAE_ENULL;
+    if (C == 0 || C > 8 || H == 0 || H > 1024 || max_steps == 0 || max_n_step == 0 || max_n_step > FRAME_LA || L != 16) return LAE_EINVAL;
+    if (workspace_bytes < lae_render_frame_workspace_bytes(N, L, row_budget)) return LAE_EINVAL;
+    hipStream_t s = STREAM(stream);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        lae::set_last_error_str("render_frame: the frame loop adapts its launches to the device state and cannot be stream-captured");
+        return LAE_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_frame_mtx);
+    if (!g_frame.init()) { lae::set_last_error_str("render_frame: could not create the pinned mirror / side stream / events"); return LAE_ELAUNCH; }
+    // One mirror / side stream / flag pair per process (one process per GPU): frames on the SAME stream are ordered by the
+    // stream itself; a frame on another stream first waits for the previous frame's queued tail.
+    if (g_frame.have_last && g_frame.last_stream != s) (void)hipStreamSynchronize(g_frame.last_stream);
+    g_frame.last_stream = s; g_frame.have_last = true;
+    // a wait of the PREVIOUS frame gave up after its call had returned (its outputs hold NaN, k_frame_finish): never overlap again
+    if (!g_frame.degraded && g_frame.frame_counter && g_frame.mirror_h->hung == (uint32_t)g_frame.frame_counter) {
+        g_frame.degraded = true;
+        frame_warn_once("a cross-stream wait of the previous frame timed out (that frame's outputs are NaN)");
+    }
+    // Lookahead beside the encoder / head kernels (a side stream, ordered by two polled words) needs the two streams to run
+    // CONCURRENTLY; when they cannot -- probed once per caller stream, or found out the hard way by a wait that gave up --
+    // the same kernels run in line on the caller's stream: the image has the same bits, the frame is slower.
+    static const int forced = [] { const char* e = getenv("LAE_FRAME_OVERLAP"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();   // 1: skip the probe (tests of the give-up path), 0: in line
+    bool overlap = g_frame_overlap != 0 && !g_frame.degraded && forced != 0;
+    if (overlap && forced < 0 && !frame_streams_concurrent(s)) {
+        overlap = false;
+        frame_warn_once("the caller's stream and the side stream do not run concurrently (one hardware queue, serialised dispatch or a counter-collecting profiler)");
+    }
+    bool gave_up = false;
+#define LAE_FRAME_ARGS rays_o, rays_d, N, aabb, min_near, grid, edit_grid, bound, dt_gamma, max_steps, C, H, table_f16, offsets, offsets_host, L, S, \
+        base_resolution, gridtype, align_corners, interp, sigma_weights, color_weights, density_scale, T_thresh, max_n_step, row_budget, noises,      \
+        bg_rays, bg_r, bg_g, bg_b, blend_bg, scale_depth, weights_sum, depth, image, weights_edit, depth_edit, workspace, workspace_bytes,           \
+        stats_out, stream
+    g_frame.last_mode = overlap ? 1 : 0;
+    int rc = render_frame_once(LAE_FRAME_ARGS, overlap, &gave_up);
+    if (gave_up && overlap) {                              // degrade instead of failing: once, in line, and remember it for the process
+        g_frame.degraded = true;
+        frame_warn_once("a cross-stream wait timed out");
+        gave_up = false;
+        g_frame.last_mode = 0;
+        rc = render_frame_once(LAE_FRAME_ARGS, false, &gave_up);
+    }
+#undef LAE_FRAME_ARGS
+    return rc;
 }
 
 }  // extern "C"

@@ -448,9 +448,9 @@ def test_deferred_loss_is_keyed_by_the_criterion_node_not_by_the_process():
     torch.manual_seed(7)
     m = LAENeRF(params, dir_encoding="sphere_harmonics").to(DEV).train()
     optS = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
-    x = (torch.rand(5000, 3, device=DEV) - 0.5) * 0.6
-    dd = torch.nn.functional.normalize(torch.randn(5000, 3, device=DEV), dim=-1)
-    tgt = torch.rand(5000, 3, device=DEV)
+    x = (torch.rand(5120, 3, device=DEV) - 0.5) * 0.6
+    dd = torch.nn.functional.normalize(torch.randn(5120, 3, device=DEV), dim=-1)
+    tgt = torch.rand(5120, 3, device=DEV)
     lA = fwd(rA, optA, oA, dA, gtA, True)
     with torch.autocast("cuda", dtype=torch.float16):
         lS = m.forward_train_loss(x, dd, tgt, params, optS, with_palet_loss=True)[0]
@@ -461,8 +461,8 @@ def test_deferred_loss_is_keyed_by_the_criterion_node_not_by_the_process():
     same(lA, netA, refA)
     optA.zero_grad()
 
-    # 3. forward on one stream, backward on another: the head backward does not take the value along (no ordering against the
-    # partials on that stream); it is finished on the stream it was made on
+    # 3. forward under one stream context, backward called under another: autograd runs every node's backward on the stream of
+    # its forward, so the value is still carried, on s1
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     s1.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s1):
@@ -471,8 +471,22 @@ def test_deferred_loss_is_keyed_by_the_criterion_node_not_by_the_process():
     st2 = dict(backend.deferred_loss_stats)
     with torch.cuda.stream(s2):
         lA.backward(gradient=torch.ones_like(lA))
-    assert backend.deferred_loss_stats["carried"] == st2["carried"] and len(backend._pending_loss) == 1
-    backend.flush_pending_loss()
+    assert backend.deferred_loss_stats["carried"] == st2["carried"] + 1 and not backend._pending_loss
+    torch.cuda.synchronize()
+    same(lA, netA, refA)
+    optA.zero_grad()
+
+    # 4. an entry whose partials were written on ANOTHER stream than the one the head backward runs on is not taken along (no
+    # ordering against them there): it is finished on its own stream by flush_pending_loss
+    lA = fwd(rA, optA, oA, dA, gtA, True)
+    (key, e), = backend._pending_loss.items()
+    s2.wait_stream(torch.cuda.current_stream())
+    backend._pending_loss[key] = e[:5] + (s2.cuda_stream,) + e[6:]
+    st3 = dict(backend.deferred_loss_stats)
+    lA.backward(gradient=torch.ones_like(lA))
+    assert backend.deferred_loss_stats["carried"] == st3["carried"] and len(backend._pending_loss) == 1 and torch.isnan(lA).item()
+    optA.finish_loss()
+    assert backend.deferred_loss_stats["flushed"] == st3["flushed"] + 1 and not backend._pending_loss
     torch.cuda.synchronize()
     same(lA, netA, refA)
     optA.zero_grad()

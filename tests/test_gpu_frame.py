@@ -374,7 +374,7 @@ def test_lookahead_variants_render_the_same_bits(bound, n):
                       # of whole waves after 4 lane rounds
                       ("no coarse field", {"LAE_FRAME_COARSE": "0"}), ("emit without LDS", {"LAE_FRAME_EMIT_LDS": "0"}),
                       ("training schedule", {"LAE_GRID_FWD_FRAME_SCHED": "0"}), ("level halves", {"LAE_GRID_FWD_FRAME_SCHED": "2"}),
-                      ("first walk queues", {"LAE_FRAME_COOP_MAX0": "16", "LAE_FRAME_MAX_ROUNDS": "4"}),
+                      ("first walk queues", {"LAE_FRAME_COOP_MAX0": "16", "LAE_FRAME_MAX_ROUNDS": "4"}), ("lookahead in line", {"LAE_FRAME_OVERLAP": "0"}),
                       ("whole waves never handed over", {"LAE_FRAME_ADMIT_CAP": "0"}), ("one worst-case encoder launch", {"LAE_FRAME_GRID_TAIL": "0"}),
                       ("overflow launch always", {"LAE_GRID_FWD_TAIL_MIN": "0"}), ("host one iteration ahead", {"LAE_FRAME_LAG": "1"}), ("general emit kernel at 8 samples per ray", {"LAE_FRAME_EMIT8": "0"}), ("host six iterations ahead", {"LAE_FRAME_LAG": "6"}), ("handed over after one round", {"LAE_FRAME_ADMIT_ROUND": "1", "LAE_FRAME_ADMIT_CAP": "100000"})):
         e = dict(os.environ, **env)
@@ -383,3 +383,56 @@ def test_lookahead_variants_render_the_same_bits(bound, n):
         assert out.returncode == 0 and len(lines) == 1, (name, out.stdout[-1000:], out.stderr[-2000:])
         hashes[name] = lines[0]
     assert len(set(hashes.values())) == 1, hashes
+
+
+def _degrade_child(env):
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "frame_degrade_child.py")], capture_output=True, text=True, timeout=600, env=e)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (env, out.stdout[-1000:], out.stderr[-3000:])
+    warnings = [l for l in out.stderr.splitlines() if "laenerf_amd: render_frame:" in l]
+    return json.loads(lines[0]), warnings
+
+
+def test_frame_loop_degrades_to_the_inline_lookahead_instead_of_failing():
+    """The overlapped frame loop orders its two streams with polled words, which needs them to run side by side (the reference's
+    loop, nerf/renderer.py:335-387, has no such requirement).  Fresh child processes (the environment must be set before the
+    first HIP call): (a) default; (b) dispatch serialised (AMD_SERIALIZE_KERNEL=3) and (c) every stream on ONE hardware queue
+    (GPU_MAX_HW_QUEUES=1 with the side stream at the caller's priority -- at its default, high, priority it has a queue of
+    its own): the probe finds out, frames are rendered in line; (d) as (c) with the probe skipped (LAE_FRAME_OVERLAP=1) and a
+    short wait time-out: the first frame's handshake gives up, the frame is poisoned, rendered AGAIN in line inside the same
+    call, and the process stays in line; (e) 40 live torch streams, the frame on one of them.  Every frame of every child has
+    the same bits; at most one warning per process."""
+    base, w0 = _degrade_child({})
+    assert base["mode"] == 1 and not w0 and all(f["finite"] for f in base["frames"])
+    sha = base["frames"][0]["sha"]
+    assert all(f["sha"] == sha for f in base["frames"])
+    report = {"default": base}
+
+    def same_bits(res):
+        assert [f["sha"] for f in res["frames"]] == [sha, sha] and all(f["finite"] for f in res["frames"]), res
+    ser, w1 = _degrade_child({"AMD_SERIALIZE_KERNEL": "3"})
+    same_bits(ser)
+    assert ser["mode"] == 0 and len(w1) == 1 and "do not run concurrently" in w1[0]
+    alias = {"GPU_MAX_HW_QUEUES": "1", "LAE_FRAME_SIDE_PRIO": "0"}
+    one_q, w2 = _degrade_child(alias)
+    same_bits(one_q)
+    assert (one_q["mode"] == 1 and not w2) or (one_q["mode"] == 0 and len(w2) == 1)   # side by side after all, or said so once
+    hung, w3 = _degrade_child(dict(alias, LAE_FRAME_OVERLAP="1", LAE_FRAME_WAIT_SPINS_LOG2="16"))
+    same_bits(hung)
+    if one_q["mode"] == 0:                                      # the queues really alias on this box: the give-up path ran
+        assert hung["mode"] == 0 and len(w3) == 1 and "timed out" in w3[0]
+    many, w4 = _degrade_child({"LAE_TEST_LIVE_STREAMS": "40"})
+    same_bits(many)
+    assert len(w4) <= 1
+    inline, w5 = _degrade_child({"LAE_FRAME_OVERLAP": "0"})
+    same_bits(inline)
+    assert inline["mode"] == 0 and not w5
+    report.update({"serialised dispatch": (ser, w1), "one hw queue": (one_q, w2), "one hw queue, probe skipped": (hung, w3),
+                   "40 live streams": (many, w4), "in line": inline})
+    print("frame-loop degrade paths:", report)
