@@ -297,81 +297,17 @@ struct FwdSched { uint32_t nseg[8]; FwdSeg seg[8][FWD_MAX_SEG]; };
 // one (sample row, level) of the lean forward: shared by k_grid_fwd_lean and by the frame loop's overflow launch below
 __device__ __forceinline__ void grid_fwd_lean_row(const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
                                                   half_t* __restrict__ outputs, const LevelScales& sc, uint64_t os_b, uint64_t os_l, uint32_t level, uint32_t b) {
-    const LevelInfo<3> li = level_info<3>(sc, offsets, level, 0u, false);
-    const char* __restrict__ tabb = reinterpret_cast<const char*>(grid + (size_t)li.table_off * 2);
-
-    struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
-    const F3 in = *reinterpret_cast<const F3*>(inputs + (size_t)b * 3);
-    const float xin[3] = {in.x, in.y, in.z};
-    float fr[3];
-    uint32_t pg[3];
-    bool oob = false;
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        const float x01 = (xin[d] + sc.in_shift) * sc.in_scale;
-        oob |= (x01 < 0.0f) | (x01 > 1.0f);
-        const float p = fmaf(x01, li.scale, 0.5f);
-        const float fl = floorf(p);
-        pg[d] = (uint32_t)fl;
-        fr[d] = p - (float)pg[d];
-    }
-    half2_t* out = reinterpret_cast<half2_t*>(outputs + (size_t)b * os_b + (size_t)level * os_l);
-    if (oob) { const half2_t z = {(half_t)0.0f, (half_t)0.0f}; *out = z; return; }   // gridencoder.cu:118-135
-
-    uint32_t cw[8];                                        // corner idx = x + 2y + 4z, two halves each
-    if (li.use_hash && li.pow2) {
-        const uint32_t m4 = (li.hashmap_size - 1u) << 2;
-        const uint32_t hy0 = (pg[1] * 2654435761u) << 2, hy1 = hy0 + (2654435761u << 2);
-        const uint32_t hz0 = (pg[2] * 805459861u) << 2, hz1 = hz0 + (805459861u << 2);
-        const uint32_t x0 = pg[0] << 2, x1 = x0 + 4u;
-        const uint32_t h[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
-        if ((pg[0] & 1u) == 0 && li.hashmap_size >= 2) {   // idx(x + 1) == idx(x) ^ 1: one aligned 8-byte load per row
-#pragma unroll
-            for (int yz = 0; yz < 4; yz++) {
-                const uint32_t o0 = (x0 ^ h[yz]) & m4;
-                const uint2 w = *reinterpret_cast<const uint2*>(tabb + (o0 & ~4u));
-                cw[2 * yz] = (o0 & 4u) ? w.y : w.x;
-                cw[2 * yz + 1] = (o0 & 4u) ? w.x : w.y;
-            }
-        } else {
-#pragma unroll
-            for (int yz = 0; yz < 4; yz++) {
-                cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + ((x0 ^ h[yz]) & m4));
-                cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + ((x1 ^ h[yz]) & m4));
-            }
-        }
-    } else if (!li.use_hash && li.nowrap) {
-        const uint32_t base = (pg[0] + pg[1] * li.stride[1] + pg[2] * li.stride[2]) << 2;     // stride[0] == 1
-        const uint32_t dy = li.stride[1] << 2, dz = li.stride[2] << 2;
-#pragma unroll
-        for (int yz = 0; yz < 4; yz++) {
-            const uint32_t o0 = base + ((yz & 1) ? dy : 0u) + ((yz >> 1) ? dz : 0u);
-            cw[2 * yz] = *reinterpret_cast<const uint32_t*>(tabb + o0);
-            cw[2 * yz + 1] = *reinterpret_cast<const uint32_t*>(tabb + o0 + 4u);
-        }
-    } else {
-#pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-            const uint32_t pl[3] = {pg[0] + (idx & 1), pg[1] + ((idx >> 1) & 1), pg[2] + (idx >> 2)};
-            cw[idx] = *reinterpret_cast<const uint32_t*>(tabb + ((size_t)cell_index<3>(li, pl) << 2));
-        }
-    }
-    half_t r0 = (half_t)0.0f, r1 = (half_t)0.0f;
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-        const float w = (((idx & 1) ? fr[0] : 1 - fr[0]) * ((idx & 2) ? fr[1] : 1 - fr[1])) * ((idx & 4) ? fr[2] : 1 - fr[2]);
-        const half2_t v = __builtin_bit_cast(half2_t, cw[idx]);
-        accum(r0, w, v[0]);
-        accum(r1, w, v[1]);
-    }
-    const half2_t h2 = {r0, r1};
-    *out = h2;
+#include "grid_fwd_lean_row.inc"
 }
 
 __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
     const float* __restrict__ inputs, const half_t* __restrict__ grid, const int32_t* __restrict__ offsets,
     half_t* __restrict__ outputs, uint32_t B, LevelScales sc, FwdSched sched, uint64_t os_b, uint64_t os_l,
-    const uint32_t* __restrict__ B_dev) {
+    const uint32_t* __restrict__ B_dev
+#ifdef LAE_GRID_FWD_LOOP_PROBE
+    , uint32_t pass_chunks                                 // fault probe only (below): 0 = one trip
+#endif
+    ) {
     const uint32_t xcd = blockIdx.x & 7u;
 #ifdef LAE_GRID_STAMPS
     const unsigned long long st_t0 = wall_clock64();
@@ -389,10 +325,33 @@ __global__ __launch_bounds__(GRID_BLOCK) void k_grid_fwd_lean(
         j -= n;
     }
     if (level == 0xffffffffu) return;
+#ifndef LAE_GRID_FWD_LOOP_PROBE
     const uint32_t b = chunk * GRID_BLOCK + threadIdx.x;
     if (B_dev) B = min(B, *B_dev);
     if (b >= B) return;
     grid_fwd_lean_row(inputs, grid, offsets, outputs, sc, os_b, os_l, level, b);
+#else
+    // FAULT PROBE, never in the shipped library (tools/grid_loop_fault.sh builds it into tools/ubench/bin/): round 4's reverted
+    // "workgroups loop over the overflow rows" form of this kernel (commit 4541188).  With the row statements inside a
+    // by-reference lambda inside this loop (variant 1) a few hundred rays of a frame differed from run to run as soon as a SECOND
+    // PROCESS rendered frames on the GPU -- also with one trip (pass_chunks = 0, what the probe launches); the same loop around the
+    // __forceinline__ function (variant 2) never did.  Round 5 bisected the two listings (they differ in the scalar prologue's
+    // schedule and in ONE vector instruction) by hand-patched assembly: the instruction is
+    //       v_pk_mul_f32 v[20:21], v[6:7], v[22:23] op_sel:[0,1] op_sel_hi:[0,1]          (variant 2: v[22:23], v[6:7] op_sel:[1,0] op_sel_hi:[1,0])
+    // i.e. the gfx950 packed-fp32 erratum of laenerf_amd/build.py: beside the other process's MFMA kernels the low product is
+    // sometimes a.lo x 0.  Built WITHOUT the build's operand swap the probe still shows it; with the swap it is gone.
+    if (B_dev) B = min(B, *B_dev);
+    for (uint32_t b = chunk * GRID_BLOCK + threadIdx.x; b < B; b += pass_chunks * GRID_BLOCK) {
+#if LAE_GRID_FWD_LOOP_PROBE == 2
+        grid_fwd_lean_row(inputs, grid, offsets, outputs, sc, os_b, os_l, level, b);
+#else
+        [&]() {
+#include "grid_fwd_lean_row.inc"
+        }();
+#endif
+        if (pass_chunks == 0u) break;
+    }
+#endif
 #ifdef LAE_GRID_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 32768u * 8u) {            // (same-address atomics per XCD stretched the launch from 50 to 290 us: plain stores, a slot per block)
         g_grid_stamps[(size_t)blockIdx.x * 4] = st_t0; g_grid_stamps[(size_t)blockIdx.x * 4 + 1] = wall_clock64(); g_grid_stamps[(size_t)blockIdx.x * 4 + 2] = level;
@@ -1532,7 +1491,11 @@ static void launch_fwd(const FwdArgs& a) {
             const float* co = a.level_cost ? a.level_cost : (env_cost.size() >= a.L ? env_cost.data() : nullptr);
             const uint32_t per_xcd = fwd_sched_build(fs, a.L, nb, a.sc, g_fwd_mode == 0 ? a.offsets_host : nullptr, a.B_dev != nullptr, co);
             k_grid_fwd_lean<<<per_xcd * 8, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, std::min(a.B, nb * (uint32_t)GRID_BLOCK), a.sc,
-                                                                      fs, a.os_b, a.os_l, a.B_dev);
+                                                                      fs, a.os_b, a.os_l, a.B_dev
+#ifdef LAE_GRID_FWD_LOOP_PROBE
+                                                                      , 0u
+#endif
+                                                                      );
             if (nb < nb_safe)                                  // rows beyond the expected ones, if the device has any
                 k_grid_fwd_lean_tail<<<nb_safe - nb, GRID_BLOCK, 0, a.stream>>>(a.inputs, (const half_t*)a.emb, a.offsets, (half_t*)a.out, a.B, a.sc, a.L,
                                                                                  a.os_b, a.os_l, a.B_dev, nb * (uint32_t)GRID_BLOCK);

@@ -436,3 +436,53 @@ def test_frame_loop_degrades_to_the_inline_lookahead_instead_of_failing():
     report.update({"serialised dispatch": (ser, w1), "one hw queue": (one_q, w2), "one hw queue, probe skipped": (hung, w3),
                    "40 live streams": (many, w4), "in line": inline})
     print("frame-loop degrade paths:", report)
+
+
+def _neighbour_check(*args):
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_neighbour_check.py"), *args], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, TMPDIR="/tmp"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_kernels_keep_their_bits_beside_a_process_that_keeps_the_matrix_pipe_busy():
+    """gfx950 packed-fp32 erratum (laenerf_amd/build.py): beside another wave's MFMA instructions
+    `v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1]` with a VGPR SRC1 sometimes takes SRC1's high half as zero.  This was round 4's
+    unexplained "two-process fault"; the reference's flow shares a GPU between trainer and renderer (nerf/gui.py:1985-2028).  In a
+    fresh child process, with tools/ubench/bin/spinner (back-to-back v_mfma loops) as a SECOND PROCESS on the GPU: the fp16
+    hash-grid backward, the SH encoder, a palette step's gradients and an inference frame must keep the bits they have alone.
+    Where a library built WITHOUT the build's operand swap is at hand (tools/grid_loop_fault.sh leaves one), the same check must
+    fail on it -- the test has teeth."""
+    import os
+    from conftest import ROOT
+    res = _neighbour_check("--reps", "25")
+    print("beside an MFMA neighbour:", res)
+    assert res["ok"] is True, res
+    raw = os.path.join(ROOT, "tools", "ubench", "bin", "liblaenerf_raw.so")
+    if os.path.exists(raw):
+        bad = _neighbour_check("--reps", "25", "--lib", raw)
+        print("library without the operand swap:", bad)
+        assert bad["ok"] is False and bad["grid_backward_fp16"]["runs_that_differ"] > 0, bad
+
+
+def test_two_processes_rendering_frames_keep_their_bits():
+    """round 4's two-rank soak inside the suite (tools/two_rank_soak.sh ran outside it): two PROCESSES render the same frame on
+    one GPU, 120 and 360 times; every frame of both must equal its process's first frame bit for bit (tools/grid_loop_fault.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "grid_loop_fault.py"), "--frames", "120", "--neighbour", "same"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, TMPDIR="/tmp"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-3000:])
+    j = json.loads(lines[0])
+    assert j["frames_that_differ"] == 0 and j["neighbour_result"]["frames_that_differ"] == 0, j
+    assert j["neighbour_result"]["frames"] == 360

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Do the training-side kernels give the same bits while ANOTHER PROCESS keeps the matrix pipe busy?  (gfx950 packed-fp32 erratum,
+laenerf_amd/build.py)  Computes, alone: the fp16 hash-grid backward (fill + accumulate passes), the SH
+encoder forward (degree 4, with dy_dx), a LAENeRF palette step's gradients and an inference frame; then starts
+tools/ubench/bin/spinner mfma as a second process and repeats each `--reps` times, comparing bits.  One JSON line.
+    python tools/mfma_neighbour_check.py [--lib path.so] [--reps 30] [--neighbour mfma|none]"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default="")
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--neighbour", default="mfma")
+    args = ap.parse_args()
+    if args.lib:
+        os.environ["LAE_HIP_LIB"] = os.path.abspath(args.lib)
+    spinner = os.path.join(ROOT, "tools", "ubench", "bin", "spinner")
+    if args.neighbour != "none" and not os.path.exists(spinner):
+        os.makedirs(os.path.dirname(spinner), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", spinner, os.path.join(ROOT, "tools", "ubench", "spinner.hip")],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from oracle import oracle as O
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.backend import gridencoder_backend as G, shencoder_backend as SH
+    from laenerf_amd.editing import LAENeRF
+    from laenerf_amd.network import NeRFNetwork
+    from laenerf_amd.optim import FusedAdam
+    from laenerf_amd.renderer import NeRFRenderer
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    offsets, pls = O.grid_offsets(num_levels=16, desired_resolution=2048)
+    B, L, C = 120000, 16, 2
+    x = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).to(dev)
+    g = torch.from_numpy((rng.standard_normal((L, B, C)) * 0.1).astype(np.float32)).to(dev).half()
+    table = torch.zeros(int(offsets[-1]), C, device=dev, dtype=torch.half)
+    offs = torch.from_numpy(offsets).to(dev)
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((B, 3)).astype(np.float32)), dim=-1).to(dev)
+
+    def grid_bwd():
+        ge = torch.zeros_like(table)
+        G.grid_encode_backward(g, x, table, offs, ge, B, 3, C, L, float(np.log2(pls)), 16, None, None, 0, False, 0)
+        return ge
+
+    def sh_fwd():
+        out = torch.empty(B, 16, device=dev)
+        dd = torch.empty(B, 48, device=dev)
+        SH.sh_encode_forward(dirs, out, B, 3, 4, dd)
+        return torch.cat([out, dd], 1)
+
+    params = SimpleNamespace(bound=1, num_palette_bases=8, style_weight=0, weight_loss_uniform=1e-3, weight_loss_non_uniform=1e-3,
+                             offset_loss=1e-2, palette_loss_valid=1.0, palette_loss_distinct=1e-2)
+    torch.manual_seed(7)
+    m = LAENeRF(params, dir_encoding="sphere_harmonics").to(dev).train()
+    opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
+    px = (torch.rand(40000, 3, device=dev) - 0.5) * 0.6
+    pd = torch.nn.functional.normalize(torch.randn(40000, 3, device=dev), dim=-1)
+    pt = torch.rand(40000, 3, device=dev)
+
+    def palette_grads():
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = m.forward_train_loss(px, pd, pt, params, opt, with_palet_loss=True)[0]
+        opt.backward(loss)
+        return torch.cat([m.encoder.shadow.grad_half.float().flatten()[:2000000], m.weight_net.shadow.grad_half.float().flatten(),
+                          m.offset_net.shadow.grad_half.float().flatten(), m.color_palette.grad.float().flatten() if m.color_palette.grad is not None else torch.zeros(1, device=dev)])
+
+    torch.manual_seed(1234)
+    net = NeRFNetwork(bound=1).to(dev).eval()
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    r = NeRFRenderer(net, bound=1, min_near=0.2).to(dev).eval()
+    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    o, d = S.frame_rays(160, 160)
+    o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+
+    def frame():
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            return r.render_eval(o, d, bg_color=1, max_steps=1024)["image"].clone()
+    work = {"grid_backward_fp16": grid_bwd, "sh_forward_deg4": sh_fwd, "palette_step_gradients": palette_grads, "inference_frame": frame}
+    ref = {k: f() for k, f in work.items()}
+    torch.cuda.synchronize()
+    child = None
+    if args.neighbour != "none":
+        child = subprocess.Popen([spinner, args.neighbour, "600"], stdout=subprocess.PIPE, text=True)
+        assert "ready" in child.stdout.readline()
+    out = {"lib": os.path.basename(args.lib) or "shipped", "neighbour": args.neighbour, "reps": args.reps}
+    try:
+        for k, f in work.items():
+            bad, worst = 0, 0
+            for _ in range(args.reps):
+                got = f()
+                ne = (got.contiguous().view(torch.int32) != ref[k].contiguous().view(torch.int32)) if got.dtype == torch.float32 else (got != ref[k])
+                n = int(ne.sum())
+                bad += 1 if n else 0
+                worst = max(worst, n)
+            out[k] = {"runs_that_differ": bad, "max_elements_differing": worst}
+    finally:
+        if child is not None:
+            child.kill(); child.wait()
+    out["ok"] = all(v["runs_that_differ"] == 0 for v in out.values() if isinstance(v, dict))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
