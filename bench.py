@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 GRID_FWD_BYTES_FP16 = 588        # SURVEY.md 8d / BASELINE.md 4: 12 + 16*8*2*2 + 16*2*2 bytes per sample
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS_F16 = 2500.0    # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (the 2:1-sparsity figure is never used)
+# fused head: sigma net 32->64->64->16 + colour net 32->64->64->64->16, 2 FLOP per multiply-add
+HEAD_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 16) + 2 * (32 * 64 + 64 * 64 + 64 * 64 + 64 * 16)      # 36 864 per sample
+HEAD_BWD_FLOP = 2 * HEAD_FWD_FLOP                                                                    # dX and dW products: 73 728
 
 
 def parse():
@@ -151,9 +155,79 @@ def cpu_baseline(n_rays_hint, n_threads):
     with ThreadPoolExecutor(n_threads) as ex:
         tot = sum(ex.map(lambda a: one_chunk(*a), work))
     dt = time.perf_counter() - t0
+    # also the ONE-thread figure (same chunks of 16+ rays, sequential, ~3 s) and the CPU's name
+    n1 = int(min(n_rays, max(64, 3.0 / (t_cal / 64))))
+    t1 = time.perf_counter()
+    for c in np.array_split(np.arange(n1), max(1, n1 // 64)):
+        one_chunk(o[c], d[c], noises[c])
+    dt1 = time.perf_counter() - t1
     return {"value": round(n_rays / dt / 1e6, 6), "unit": "Mrays/s", "cores": n_threads, "kind": "port",
+            "cpu_model": cpu_model(), "one_thread": {"value": round(n1 / dt1 / 1e6, 6), "unit": "Mrays/s", "rays": n1, "seconds": round(dt1, 1)},
             "sample": f"{n_rays} rays = {n_steps} step(s) of the same 4096-ray workload ({tot} samples), forward+backward "
                       f"without optimizer, oracle/lae_oracle.c on {n_threads} threads, {dt:.1f} s"}
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def roofline_more(tm, dev):
+    """the kernels furthest below their roofline, priced like `roofline` (HIP events on the launch stream around each operator in
+    20 eager steps): hash-grid backward against HBM on its 588 algorithmic bytes per sample (fill + accumulate
+    on the main stream, and with the counting pass + scans that run ahead on the side stream), fused head forward / backward
+    against the dense fp16 MFMA peak, and the same encoder kernel on the tile-ordered rows of an inference frame."""
+    def per(name):
+        e = tm.get(name)
+        if not e or not e["calls"]:
+            return None
+        return e["ms"] / e["calls"] * 1e3, e["units"] / e["calls"]            # us per launch, units per launch
+    out = {}
+    gb, gp = per("grid_encode_backward"), per("grid_backward_plan")
+    if gb:
+        us_main, n = gb
+        us_all = us_main + (gp[0] if gp else 0.0)
+        for key, us in (("grid_backward_main_stream", us_main), ("grid_backward_total", us_all)):
+            gbs = n * GRID_FWD_BYTES_FP16 / (us * 1e-6) / 1e9
+            out[key] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "avg_us": round(us, 2), "samples_per_launch": int(n), "bytes_per_sample": GRID_FWD_BYTES_FP16}
+        out["grid_backward_main_stream"]["kernels"] = "k_bwd_walk<FILL> + k_bwd_acc"
+        out["grid_backward_total"]["kernels"] = "k_bwd_walk<COUNT> + k_bwd_scan_units/parts (side stream, ahead) + k_bwd_walk<FILL> + k_bwd_acc"
+    for key, name, flop, kern in (("head_forward", "nerf_head_forward", HEAD_FWD_FLOP, "k_nerf_head_fwd5"),
+                                  ("head_backward", "nerf_head_backward", HEAD_BWD_FLOP, "k_mlp_bwd_wave x2 + k_dw_reduce2")):
+        e = per(name)
+        if e:
+            us, n = e
+            tf = n * flop / (us * 1e-6) / 1e12
+            out[key] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS_F16, 4),
+                        "avg_us": round(us, 2), "samples_per_launch": int(n), "flop_per_sample": flop, "kernels": kern}
+    # the encoder on tile-ordered frame rows: the operator loop of one 800x800 frame goes through the timed backend operator
+    try:
+        from laenerf_amd import backend, synthetic as S
+        net, r = eval_model(dev)
+        o, d = S.frame_rays(800, 800)
+        o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
+            r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(800, 800), frame_loop=False)       # warm-up
+            backend.enable_kernel_timing(True, only=("grid_encode_forward",))
+            r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(800, 800), frame_loop=False)
+        e = backend.collect_kernel_timing().get("grid_encode_forward")
+        backend.enable_kernel_timing(False)
+        if e and e["calls"]:
+            gbs = e["units"] * GRID_FWD_BYTES_FP16 / (e["ms"] * 1e-3) / 1e9
+            out["frame_encoder"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                    "launches": e["calls"], "rows": int(e["units"]), "sum_ms": round(e["ms"], 3), "bytes_per_sample": GRID_FWD_BYTES_FP16,
+                                    "kernels": "k_grid_fwd_lean on the tile-ordered rows of one 800x800 inference frame (operator loop, summed over its iterations)"}
+    except Exception as ex:                                    # a diagnostic must never take the line down
+        out["frame_encoder"] = {"error": repr(ex)}
+    out["timed"] = "HIP events on the launch stream around each operator, 20 eager steps after the timed region (frame_encoder: one operator-loop frame)"
+    return out
 
 
 def eval_model(dev, bound=1, seed=4321):
@@ -1027,6 +1101,20 @@ def main():
         zero_grad()
         step_body(o, d, gt)
     timing_all = backend.collect_kernel_timing()
+    # the same 20 steps with the hash-grid backward in its two halves (counting pass + scans = what the side stream runs ahead;
+    # fill + accumulate = what stays on the main stream), HIP events around each: the `roofline_more` objects below
+    if fused_loss and not args.no_optimizer and not args.dp:
+        for i in range(n_diag):
+            o, d, gt = batches[i % n_batches]
+            zero_grad()
+            with torch.autocast("cuda", dtype=torch.float16):
+                marched = r.march_train(o, d, perturb=True, max_steps=1024, plan_backward=True)
+                res = r.shade_train(marched, bg_color=1, gt=gt, scaler=scaler)
+            scaler.backward(res["loss"])
+            opt.step()
+        timing_split = backend.collect_kernel_timing()
+    else:
+        timing_split = {}
     backend.enable_kernel_timing(False)
     if graph:
         timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
@@ -1085,6 +1173,7 @@ def main():
                          "limiter": "on-chip: the 2 MiB level tables stay in the XCDs' L2s (measured traffic < algorithmic bytes); fine "
                                     "levels run at the L2 request rate, coarse levels at vector-memory issue (DESIGN.md 4)",
                          "timed": "HIP events on the launch stream around the call in 20 eager steps after the timed region"},
+            "roofline_more": roofline_more(timing_split, dev) if timing_split else None,
             "windows": {"ms_per_step": [round(wd / args.steps * 1e3, 4) for wd in windows],
                         "min": round(min(windows) / args.steps * 1e3, 4), "median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
                         "max": round(max(windows) / args.steps * 1e3, 4), "first": round(first_window / args.steps * 1e3, 4),

@@ -598,7 +598,7 @@ class _FFMLP:
 # HIP-event pairs recorded on torch's current stream (= the stream the kernels are launched on) around selected
 # backend calls; used by bench.py for the roofline figure.  Off by default: zero overhead in the product path.
 _timing = {"on": False, "only": None, "events": []}
-_UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "ffmlp_forward": 2, "ffmlp_inference": 2,
+_UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "grid_backward_plan": 2, "ffmlp_forward": 2, "ffmlp_inference": 2,
           "ffmlp_backward": 4, "nerf_head_forward": 4, "nerf_head_backward": 8, "nerf_density_forward": 2, "sh_encode_forward": 2, "march_rays_train": 6, "composite_rays_train_forward": 5,
           "composite_rays_train_backward": 9,
           "composite_rays_train_forward_blend": 5, "composite_rays_train_backward_blend": 9}

@@ -33,3 +33,13 @@ def test_bench_prints_one_contract_line():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert j["value"] > 100 * c["value"]
+    assert c["cpu_model"] and c["one_thread"]["value"] > 0 and c["one_thread"]["value"] <= 1.5 * c["value"]
+    assert j["windows"]["median"] == j["ms_per_step"] and j["world_size"] == 1 and j["backend"] is None
+    m = j["roofline_more"]                                           # the kernels furthest below their roofline
+    for k in ("grid_backward_main_stream", "grid_backward_total"):
+        assert m[k]["bound"] == "hbm" and m[k]["peak"] == 8000.0 and 0.02 < m[k]["frac"] < 1.0
+        assert abs(m[k]["achieved"] - 588 * m[k]["samples_per_launch"] / m[k]["avg_us"] / 1e3) < 0.02 * m[k]["achieved"]
+    assert m["grid_backward_total"]["avg_us"] > m["grid_backward_main_stream"]["avg_us"]
+    for k, flop in (("head_forward", 36864), ("head_backward", 73728)):
+        assert m[k]["bound"] == "mfma" and m[k]["peak"] == 2500.0 and m[k]["flop_per_sample"] == flop and 0.01 < m[k]["frac"] < 1.0
+    assert m["frame_encoder"]["bound"] == "hbm" and 0.1 < m["frame_encoder"]["frac"] < 1.0 and m["frame_encoder"]["launches"] > 10

@@ -8,7 +8,7 @@ import statistics
 import sys
 
 d = sys.argv[1]
-filt = sys.argv[2:] or ["k_mlp_bwd", "k_bin", "k_march", "k_grid_fwd", "k_nerf_head", "k_composite", "k_apply", "k_dw_reduce"]
+filt = sys.argv[2:] or ["k_mlp_bwd", "k_bwd_walk", "k_bwd_acc", "k_bwd_scan", "k_march", "k_grid_fwd", "k_nerf_head", "k_composite", "k_apply", "k_dw_reduce"]
 per = {}
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
