@@ -526,6 +526,64 @@ def style_step(dev, P=100000, steps=30):
             "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam, HIP-graph replay"}
 
 
+def edit_extract(dev, n_views=8, batch_views=2):
+    """configs[4] around its inner loop: the recolor flow is extraction -> 10 000 style steps -> distillation (scripts/run_mip360.sh:
+    58-59); `style_step` times the middle, this times the extraction -- EditDataset.__init__'s per-view loop (editing/
+    edit_dataset.py:74-234) as laenerf_amd.editing.extract_views over `n_views` bonsai-shaped 1080p poses at bound 2 with an edit
+    grid AND a grow grid (--smooth_trans_weight: two device-resident distill renders per batch, the reference's selection rules,
+    the nearest-grow-point distances, the crop terms).  `render_share`: the part of a view spent in get_rays + the two
+    lae_render_frame calls; the rest is the selection / cdist / crop tail."""
+    from laenerf_amd import raymarching, synthetic as S
+    from laenerf_amd.editing import edit_dataset as ED
+    net, r = eval_model(dev, bound=2, seed=1234)
+    r.density_scale = 30.0                                     # a trained scene: opaque surfaces (weights saturate)
+    H, W = 1080, 1920
+    f = 1111.1 * H / 800
+    intr = np.array([f, f, W / 2, H / 2], np.float32)
+    poses = np.zeros((n_views, 4, 4), np.float32)
+    for i in range(n_views):                                   # an orbit inside the bound-2 box, looking at the origin
+        a = 2 * np.pi * i / n_views
+        p = np.array([1.6 * np.cos(a), 1.6 * np.sin(a), 0.35 + 0.1 * np.sin(3 * a)])
+        fwd = -p / np.linalg.norm(p)
+        right = np.cross(np.array([0, 0, 1.0]), fwd); right /= np.linalg.norm(right)
+        up = np.cross(fwd, right)
+        poses[i, :3, 0], poses[i, :3, 1], poses[i, :3, 2], poses[i, :3, 3], poses[i, 3, 3] = right, up, fwd, p, 1
+    poses = torch.from_numpy(poses).to(dev)
+    dens = torch.from_numpy(S.flower_density_grid()).to(dev)                          # [2, 128^3], Morton order
+    coords = raymarching.morton3D_invert(torch.arange(128 ** 3, dtype=torch.int32, device=dev))
+    near_origin = ((coords.float() - 63.5).abs().amax(dim=1) < 20)                   # the edit region: a box around the centre ...
+    ring = ((coords.float() - 63.5).abs().amax(dim=1) < 26) & ~near_origin           # ... the grow region: the shell around it
+    edit = raymarching.packbits(torch.where(near_origin[None], dens, torch.zeros_like(dens)).contiguous(), 10.0)
+    grow = raymarching.packbits(torch.where(ring[None], dens, torch.zeros_like(dens)).contiguous(), 10.0)
+    images = torch.rand(n_views, H, W, 3, device=dev)
+
+    def run_all():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        views, occluded = ED.extract_views(r, poses, intr, H, W, edit, images, batch_views=batch_views, grow_grid=grow)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, views, occluded
+
+    def run_render_only():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i0 in range(0, n_views, batch_views):
+            ED._render_views(r, poses[i0:i0 + batch_views], intr, H, W, edit, grow)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run_all()                                                  # warm-up (workspaces, caches)
+    t_all, views, occluded = min((run_all() for _ in range(3)), key=lambda x: x[0])
+    t_render = min(run_render_only() for _ in range(3))
+    kept = [int(v["indices"].numel()) for v in views]
+    interp = [int(v["indices_interp"].numel()) for v in views if "indices_interp" in v]
+    return {"ms_per_view": round(t_all / n_views * 1e3, 2), "views": n_views, "batch_views": batch_views, "rays_per_view": H * W,
+            "render_ms_per_view": round(t_render / n_views * 1e3, 2), "render_share": round(t_render / t_all, 3),
+            "selection_cdist_crop_tail_ms_per_view": round((t_all - t_render) / n_views * 1e3, 2),
+            "views_kept": len(views), "views_occluded": len(occluded), "rays_kept_per_view": int(np.mean(kept)) if kept else 0,
+            "transition_pixels_per_view": int(np.mean(interp)) if interp else 0,
+            "note": "laenerf_amd.editing.extract_views: get_rays + two device-resident distill renders (edit grid, grow grid) per batch of "
+                    "views, then the reference's selection rules, nearest-grow-point distances and crop terms per view; fixed eval model "
+                    "(seed 1234, density scale 30), bound 2, synthetic occupancy, results stay on the device"}
+
+
 def grouped_pipeline(r, opt, batches, G, groups_ahead=2):
     """the headline's execution scheme for any renderer / optimizer pair (fused criterion): per group of G resident ray batches
     two captured HIP graphs -- G x {ray/box, march, counting half of the grid backward} and G x {encoder, head, compositing +
@@ -1192,6 +1250,7 @@ def main():
             out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)
         if world == 1 and not args.no_style:
             out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
+            out["edit_extract"] = edit_extract(dev)            # configs[4] extraction around it (not `value`)
             out["grid_update"] = grid_update(dev)
             out["flower_step"] = flower_step(dev)              # configs[2]-shaped train step (not `value`)
         if world == 1 and not args.no_cpu_baseline:

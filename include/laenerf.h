@@ -504,6 +504,13 @@ LAE_API int lae_grow_region(uint8_t* grid, const float* density_grid, uint32_t C
                     uint32_t* queue, uint32_t capacity, uint32_t* state, uint32_t grow_iterations, uint32_t max_batch,
                     void* stream);
 
+/* ---- EditDataset transition weights (editing/edit_dataset.py:122-146: torch.cdist in 1000-row chunks + min + clamp_max in the
+ * reference) ----
+ * out[i] = min(max_dist, min_j |pts[i] - set[j]|) for pts [n,3], set [m,3] fp32 (m == 0: out = max_dist), *out_max = the largest
+ * out[i]; scratch: 4 n bytes of device memory.  Squared distances as dx*dx + dy*dy + dz*dz with the last two products fused. */
+LAE_API int lae_min_dist_to_points(const float* pts, uint32_t n, const float* set, uint32_t m, float max_dist, float* out,
+                           float* out_max, void* scratch, void* stream);
+
 /* ---- occupancy-grid maintenance (nerf/renderer.py:482-649, Python in the reference) ----
  * positions: point j -> xyz = (2 c / (H-1) - 1) * (bound_c - bound_c/H) + (noise * 2 - 1) * bound_c/H and its Morton index
  *   (renderer.py:580-592).  coords NULL: c = (j / H^2, (j / H) % H, j % H) (full sweep, n <= H^3); else coords [n,3] int32.

@@ -80,6 +80,7 @@ SIGNATURES = {
     "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp, u32, f32, f32, vp],
     "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, i32, f32, f32, vp],
     "lae_grow_region": [vp, vp, u32, u32, f32, vp, u32, vp, u32, u32, vp],
+    "lae_min_dist_to_points": [vp, u32, vp, u32, f32, vp, vp, vp, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],
     "lae_adam_check_multi": [u32, vp, vp, vp, vp, vp],

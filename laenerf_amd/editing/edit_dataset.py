@@ -11,7 +11,7 @@ import torch
 
 from ..rays import get_rays
 
-__all__ = ["select_edit_pixels", "extract_view", "extract_views"]
+__all__ = ["select_edit_pixels", "extract_view", "extract_views", "min_dist_to_points"]
 
 
 def select_edit_pixels(weights_density, weights_edit, depth, min_near, depth_diff):
@@ -23,6 +23,21 @@ def select_edit_pixels(weights_density, weights_edit, depth, min_near, depth_dif
     w[depth.reshape(-1) < min_near] = 0
     w[w > 0] = weights_density[w > 0]
     return w, w.nonzero(as_tuple=True)[0]
+
+
+def min_dist_to_points(pts, points, max_dist):
+    """-> (min(max_dist, distance of every pts[i] to its nearest points[j]) [n], their maximum [1]) -- edit_dataset.py:131-143's
+    chunked torch.cdist + min + clamp_max as one kernel (lae_min_dist_to_points); fp32 cuda tensors [n,3], [m,3]"""
+    from .. import _lib
+    pts, points = pts.float().contiguous(), points.float().contiguous()
+    _lib.need_cuda(pts, points)
+    n, m = pts.shape[0], points.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=pts.device)
+    d_max = torch.empty(1, dtype=torch.float32, device=pts.device)
+    scratch = torch.empty(max(n, 1), dtype=torch.int32, device=pts.device)
+    _lib.check(_lib.load().lae_min_dist_to_points(_lib.ptr(pts), n, _lib.ptr(points) if m else None, m, float(max_dist), _lib.ptr(out), _lib.ptr(d_max),
+                                                  _lib.ptr(scratch), _lib.stream()), "min_dist_to_points")
+    return out, d_max
 
 
 def _crop_terms(h, w, mask, pred_w8s, target, d_mask, dist_factor=None):
@@ -69,10 +84,8 @@ def _pack_view(out, g, rays_d, H, W, image, depth_diff, max_dist, num_steps, to_
     if g is not None:                                                         # :122-146 smooth transition weights
         x_grow = g["x_term"][g["weights_edit"] > .99]
         if x_grow.shape[0]:
-            pts = out["x_term"][mask]
-            mins = [torch.cdist(pts[i:i + 1000], x_grow, compute_mode="donot_use_mm_for_euclid_dist").min(dim=-1).values for i in range(0, pts.shape[0], 1000)]
-            min_d = torch.clamp_max(torch.cat(mins), max_dist)
-            dist_factor = 1 - (min_d / min_d.max())
+            min_d, d_max = min_dist_to_points(out["x_term"][mask], x_grow, max_dist)      # :131-143 (cdist in 1000-row chunks there)
+            dist_factor = 1 - (min_d / d_max)
         else:
             dist_factor = torch.zeros_like(pred_w8s[mask])
         md = dist_factor.nonzero(as_tuple=True)[0]

@@ -137,3 +137,24 @@ def test_batched_views_equal_single_views_up_to_the_jitter(O):
         assert a["weights_densitygrid"].shape == b["weights_densitygrid"].shape == (H * W,)
         assert np.abs(N(a["weights_densitygrid"]) - N(b["weights_densitygrid"])).mean() < 5e-3
         assert set(a.keys()) == set(b.keys())
+
+
+@pytest.mark.parametrize("n,m", [(5003, 20011), (1, 7), (1024, 1024), (777, 0), (4096, 300000)])
+def test_min_dist_to_points_equals_the_chunked_cdist(n, m):
+    """lae_min_dist_to_points against the reference's lines (edit_dataset.py:131-143): torch.cdist in 1000-row chunks, min over
+    the grow points, clamp_max(max_dist), and the maximum it divides by.  Clustered points: many distances below max_dist."""
+    from laenerf_amd.editing.edit_dataset import min_dist_to_points
+    g = torch.Generator(device="cpu").manual_seed(n * 7 + m)
+    pts = (torch.rand(n, 3, generator=g) * 0.8 - 0.4).to(DEV)
+    points = (torch.rand(m, 3, generator=g) * 0.5 - 0.1).to(DEV)
+    got, got_max = min_dist_to_points(pts, points, 0.1)
+    if m == 0:
+        assert torch.equal(got, torch.full((n,), 0.1, device=DEV)) and float(got_max) == pytest.approx(0.1)
+        return
+    # in float64 (exact to fp32 rounding).  torch.cdist in fp32 on this stack returns zeros for a trailing chunk of a few rows
+    # (n = 5003: rows 5000-5002), so the reference's own fp32 call is not the yardstick here
+    mins = [torch.cdist(pts[i:i + 500].double(), points.double()).min(dim=-1).values for i in range(0, n, 500)]
+    ref = torch.clamp_max(torch.cat(mins), 0.1).float()
+    assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-6, atol=1e-8)
+    assert float(got_max) == float(got.max()) and float(got_max) == pytest.approx(float(ref.max()), rel=1e-6)
+    assert (got < 0.1).any() or n < 10

@@ -20,12 +20,17 @@ from laenerf_amd.backend import gridencoder_backend as G      # noqa: E402
 from laenerf_amd.gridencoder import GridEncoder               # noqa: E402
 
 dev = "cuda:0"
-o, d = S.lego_like_rays(4096, seed=0, n_views=1)
-bits = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
-n, f = rm.near_far_from_aabb(to, td, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
-c = torch.zeros(2, dtype=torch.int32, device=dev)
-xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, 1.0, bits, 1, 128, n, f, c, -1, True, 128, False, 0, 1024)
+if os.environ.get("LAE_STAMPS_SCENE") == "style":              # bench.py style_step's points: 100 k random points in a 0.3-radius ball
+    torch.manual_seed(7)
+    v = torch.randn(100000, 3, device=dev)
+    xyzs = (v / v.norm(dim=-1, keepdim=True) * 0.3 * torch.rand(100000, 1, device=dev) ** (1 / 3)).contiguous()
+else:
+    o, d = S.lego_like_rays(4096, seed=0, n_views=1)
+    bits = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+    to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    n, f = rm.near_far_from_aabb(to, td, torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev), 0.2)
+    c = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, 1.0, bits, 1, 128, n, f, c, -1, True, 128, False, 0, 1024)
 enc = GridEncoder(desired_resolution=2048).to(dev)
 M = xyzs.shape[0]
 grad = (torch.randn(16, M, 2, device=dev) * 1e-2).half()
@@ -81,7 +86,8 @@ offs = enc.offsets_host if hasattr(enc, "offsets_host") else enc.offsets.cpu().n
 offs = np.asarray(offs).astype(np.int64)
 sizes = offs[1:] - offs[:-1]
 P = (sizes + 4095) // 4096
-SUB = np.where(P >= 16, 1, (16 + P - 1) // np.maximum(P, 1))
+BK = 64 if M >= 400000 else 32                                   # BK_TARGET of the launch (gridencoder.hip)
+SUB = np.where(P >= BK, 1, (BK + P - 1) // np.maximum(P, 1))
 first = np.concatenate([[0], np.cumsum(P * SUB)])
 nacc = 512
 acc = st[4096:4096 + nacc]
