@@ -199,11 +199,13 @@ __global__ __launch_bounds__(256) void k_partial_positions(const int32_t* __rest
     const uint32_t mb = (n + 255u) / 256u;
     const uint32_t half = blockIdx.x / mb, jl = (blockIdx.x - half * mb) * 256u + threadIdx.x;      // point jl of its half
     float uj = 0.f;
+    double ujd = 0.0;                                      // the sorted draw in double: fp32 cannot address every cell / rank above 2^24 (H >= 512: ADVICE r4)
     if (rnd) {
         const uint32_t n1 = n + 1u;
         double tot;
         const double inc = block_incl_scan_f64(jl < n1 ? exp1_of(rnd[(size_t)half * n1 + jl]) : 0.0, &tot, dlds);
-        uj = fminf((float)((eprefix[(size_t)half * m_chunks + (jl / EXP_CHUNK)] + inc) / etotals[half]), 0.99999994f);
+        ujd = fmin((eprefix[(size_t)half * m_chunks + (jl / EXP_CHUNK)] + inc) / etotals[half], 0.99999999999999989);
+        uj = fminf((float)ujd, 0.99999994f);
     }
     if (jl >= n) return;
     const uint32_t j = half * n + jl;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void k_partial_positions(const int32_t* __rest
     bool valid = true;
     if (half == 0) {
         if (rnd) {
-            const uint32_t code = min((uint32_t)((double)uj * (double)cells), cells - 1u);
+            const uint32_t code = min((uint32_t)(ujd * (double)cells), cells - 1u);
             c[0] = (int32_t)compact_bits(code); c[1] = (int32_t)compact_bits(code >> 1); c[2] = (int32_t)compact_bits(code >> 2);
         } else { c[0] = coords_rand[3 * (size_t)jl]; c[1] = coords_rand[3 * (size_t)jl + 1]; c[2] = coords_rand[3 * (size_t)jl + 2]; }
     } else {
@@ -219,7 +221,8 @@ __global__ __launch_bounds__(256) void k_partial_positions(const int32_t* __rest
         const uint32_t K = *occ_total;
         valid = K > 0;
         uint32_t cell = 0;
-        if (valid) cell = (uint32_t)occ_list[min((uint32_t)(uj * (float)K), K - 1u)];
+        // rnd: the rank from the double draw; u (the caller's recorded fp32 draws): the reference's arithmetic (renderer.py:606)
+        if (valid) cell = (uint32_t)occ_list[min(rnd ? (uint32_t)(ujd * (double)K) : (uint32_t)(uj * (float)K), K - 1u)];
         c[0] = (int32_t)compact_bits(cell); c[1] = (int32_t)compact_bits(cell >> 1); c[2] = (int32_t)compact_bits(cell >> 2);   // morton3D_invert
     }
     const float hm1 = (float)(H - 1);
@@ -289,7 +292,8 @@ int lae_density_grid_positions(const int32_t* coords, uint32_t n, uint32_t H, fl
 
 uint64_t lae_density_grid_partial_scratch_bytes(uint32_t cells, uint32_t n) {
     const uint64_t m_chunks = lae::cdiv((uint64_t)n + 1, EXP_CHUNK);
-    return ((uint64_t)lae::cdiv(cells, OCC_CHUNK) + 64) * 4 + (uint64_t)cells * 4 + (2 * m_chunks + 8) * 8;
+    // counts + total words, the occupied-cell list, then (8-byte aligned: ADVICE r4) the double sums
+    return (((uint64_t)lae::cdiv(cells, OCC_CHUNK) + 64) * 4 + (uint64_t)cells * 4 + 7) / 8 * 8 + (2 * m_chunks + 8) * 8;
 }
 
 int lae_density_grid_partial_positions(const float* grid_c, uint32_t cells, const int32_t* coords_rand, const float* u, const float* rnd,
@@ -304,7 +308,9 @@ int lae_density_grid_partial_positions(const float* grid_c, uint32_t cells, cons
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratch);            // [n_chunks] counts -> prefix, then the total
     uint32_t* total = counts + n_chunks;
     int32_t* occ_list = reinterpret_cast<int32_t*>(counts + n_chunks + 64);
-    double* esums = reinterpret_cast<double*>(occ_list + cells);        // [2][m_chunks] block sums -> prefixes, then the two totals
+    // [2][m_chunks] block sums -> prefixes, then the two totals; n_chunks + 64 + cells words can be an ODD count (H = 2, 4, 8):
+    // the doubles start at the next 8-byte boundary (lae_density_grid_partial_scratch_bytes carries the pad)
+    double* esums = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(occ_list + cells) + 7u) & ~uintptr_t(7));
     double* etotals = esums + 2 * (size_t)lae::cdiv((uint64_t)n + 1, EXP_CHUNK);
     hipStream_t s = STREAM(stream);
     k_occ_count<<<n_chunks + 2 * m_chunks, 256, 0, s>>>(grid_c, cells, counts, n_chunks, rnd, n + 1, m_chunks, esums);

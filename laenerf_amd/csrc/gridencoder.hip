@@ -1717,7 +1717,11 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     // workgroups per level: 32 up to ~400 k samples, 64 beyond (same-box A/B in round 4: lego, 258 k samples, 0.3508 / 0.3547 ms per
     // step at 32 / 64; flower, 658 k, 0.666 / 0.647) -- the smallest levels' few cells take every sample's LDS atomics
     static const uint32_t bk_env = [] { const char* e = getenv("LAE_GRID_BWD_BK_TARGET"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), (int)SUB_RECS) : 0u; }();
-    const uint32_t bk_target = bk_env ? bk_env : (B >= 400000u ? 64u : BK_TARGET);
+    // a split level (P < bk_target) owns one merge record per partition and its arrival tickets are indexed with SUB_RECS: the
+    // choice made here may never exceed it.  The records are sized for MAX_LEVELS x SUB_RECS whatever the call
+    // (135 MB, zeroed once per buffer: their place must not move with B or L) -- 0.05 % of the card's HBM, a conscious choice.
+    static_assert(BK_TARGET <= SUB_RECS && 64u <= SUB_RECS, "bk_target choices must fit the merge records");
+    const uint32_t bk_target = std::min(bk_env ? bk_env : (B >= 400000u ? 64u : BK_TARGET), SUB_RECS);
     k_bwd_acc<T><<<(uint32_t)lae::num_cus() * 2, ACC_THREADS, 0, a.stream>>>(offsets, ge, L, a.sc, a.gridtype, a.align, plan, qvals, qkeys, partials, a.nf_flag, bk_target);
     // levels with more partitions than a directory row holds (more than 2^21 entries): generic atomic kernel.  With the
     // caller's host copy of the level sizes the launch is skipped when no level needs it; without one it is always made

@@ -353,7 +353,11 @@ __global__ __launch_bounds__(1024) void k_style_loss_final(const float* __restri
     const float s = scale ? scale[0] : 1.0f;
     const float mse = tot[0] / (3.0f * (float)M), uni = lw.w_uniform * tot[3 + jmax], non = lw.w_non_uniform * tot[2],
                 off = lw.c_offset * tot[1];
-    const float loss = (((mse + uni) + non) + off) + regv;
+    // nerf/utils.py:990-995: the criterion's fp32 value, then `loss += weights_loss(...).half()`, `+= offset_loss(...).half()`,
+    // `+= palet_loss(params).half()` -- each added term rounded to fp16 first (the casts' backward is the identity, so only the
+    // reported / scaled VALUE sees it; fin[] keeps the unrounded terms).  ADVICE r4.
+    const auto h = [](float v) { return (float)(half_t)v; };
+    const float loss = ((mse + h(uni + non)) + h(off)) + h(regv);
     fin[FIN_REG] = regv;
     fin[FIN_LOSS_SCALED] = loss * s; fin[FIN_LOSS] = loss; fin[FIN_MSE] = mse; fin[FIN_UNIFORM] = uni; fin[FIN_NON_UNIFORM] = non;
     fin[FIN_OFFSET] = off; fin[FIN_JMAX] = (float)jmax; fin[FIN_SCALE] = s;

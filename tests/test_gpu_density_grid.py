@@ -65,14 +65,16 @@ def test_partial_sweep_selection_on_the_device_equals_the_reference_statements(O
         assert int(idx2[n]) == int(occ[0]) and int(idx2[n + 1]) == int(occ[-1])
 
 
-def test_partial_sweep_sorted_draws_made_on_the_device():
+@pytest.mark.parametrize("H", [128, 8])
+def test_partial_sweep_sorted_draws_made_on_the_device(H):
     """rnd path of lae_density_grid_partial_positions: both halves drawn as SORTED i.i.d. uniforms from partial sums of exponentials
     (no sort, no host read).  Against a float64 numpy evaluation of the same order statistics fed through the explicit (coords, u)
     path: the same cells up to the summation order of the partial sums (a draw within rounding of a cell boundary may land next
     door: < 0.1 % of the points, never further than one code / rank); cells in Morton order, occupied draws occupied, and the
     sample is uniform (Kolmogorov distance)."""
     from laenerf_amd import raymarching as rm
-    H, bound_c = 128, 2.0
+    # H = 8: n_chunks + 64 + cells scratch words is an odd count -- the double sums behind them must still be 8-byte aligned (ADVICE r4)
+    bound_c = 2.0
     cells, n = H ** 3, H ** 3 // 4
     rng = np.random.default_rng(5)
     grid = np.where(rng.random(cells) < 0.07, 1.0, -1.0).astype(np.float32)
@@ -84,16 +86,17 @@ def test_partial_sweep_sorted_draws_made_on_the_device():
     xyz, idx = rm.density_grid_partial_positions(g, None, None, H, bound_c, noise=T(noise), rnd=T(rnd))
     idx = N(idx)
     c = np.cumsum(-np.log1p(-rnd.astype(np.float64)), axis=1)
-    u = np.minimum((c[:, :n] / c[:, n:]).astype(np.float32), np.float32(0.99999994))
-    codes = np.minimum((u[0].astype(np.float64) * cells).astype(np.int64), cells - 1)
-    ranks = np.minimum((u[1] * np.float32(K)).astype(np.int64), K - 1)
+    u = np.minimum(c[:, :n] / c[:, n:], 1.0 - 2.0 ** -53)                             # the draws stay in double (fp32 cannot address 2^24+ cells / ranks)
+    codes = np.minimum((u[0] * cells).astype(np.int64), cells - 1)
+    ranks = np.minimum((u[1] * K).astype(np.int64), K - 1)
     d0, d1 = np.abs(idx[:n].astype(np.int64) - codes), np.abs(np.searchsorted(occ, idx[n:]) - ranks)
-    assert (d0 > 0).mean() < 1e-3 and d0.max() <= 1 and (d1 > 0).mean() < 1e-3 and d1.max() <= 1
+    assert (d0 > 0).mean() < (1e-3 if H == 128 else 2e-2) and d0.max() <= 1 and (d1 > 0).mean() < (1e-3 if H == 128 else 2e-2) and d1.max() <= 1
     assert (np.diff(idx[:n]) >= 0).all() and (np.diff(idx[n:]) >= 0).all()            # Morton order within each half
     assert (grid[idx[n:]] > 0).all()
     ks = np.abs((np.arange(n) + 0.5) / n - (idx[:n] + 0.5) / cells).max()               # empirical vs uniform CDF
     assert ks < 4.0 / np.sqrt(n), ks
     # positions of the points whose cells agree: the explicit path's arithmetic, bit for bit
+    assert (d0 == 0).mean() > 0.9
     same = np.nonzero((d0 == 0))[0][:50000]
     coords = rm.morton3D_invert(T(codes[same].astype(np.int32)))
     rx, ri = rm.density_grid_positions(same.size, H, bound_c, noise=T(noise[same]), coords=coords)

@@ -207,14 +207,17 @@ def test_fused_point_losses_equal_the_torch_formulation(n, mask, palet):
                     assert loss.terms[8].item() == pytest.approx(m.palet_loss(params).item(), rel=1e-5)
             else:
                 pred, w, o = m.forward_train(x, d)
-                loss = (torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params) + m.offset_loss(o.float(), params)
-                        + (m.palet_loss(params) if palet else 0.0)) * scale
+                # nerf/utils.py:990-995: every added term goes through .half() (identity in the backward)
+                loss = torch.nn.functional.mse_loss(pred.float(), target) + m.weights_loss(w, params).half() + m.offset_loss(o.float(), params).half()
+                if palet:
+                    loss = loss + m.palet_loss(params).half()
+                loss = loss * scale
         (loss * 0.5).backward()
         res.append((loss.detach().float().clone(), pred.detach().clone(), [p.grad.clone() for p in (m.color_palette, m.weight_net.weights,
                                                                                                      m.offset_net.weights, m.encoder.embeddings)]))
     (l0, p0, g0), (l1, p1, g1) = res
     assert torch.equal(p0, p1)
-    assert l1.item() == pytest.approx(l0.item(), rel=2e-4)
+    assert l1.item() == pytest.approx(l0.item(), rel=2e-5)          # the fp16 roundings of the added terms are the reference's; was 2e-4
     terms = res[1][0]
     for a, b, name in zip(g0, g1, ("palette", "weight_net", "offset_net", "table")):
         a, b = N(a), N(b)
