@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) void k_frame_lookahead(
         // most of the wave is in transit: lanes are well used.  (A wave whose 64 neighbouring rays all leave a surface
         // together walks on for 16-25 rounds, 130-200 us, while the median wave is done after 11 us -- but handing such
         // waves to the finishing kernel after max_rounds rounds costs more than it saves: one wave per ray there is ~7x
-        // the work of a lane here.  Round 4, LAE_FRAME_MAX_ROUNDS = 1 / 2 / 3: 15.3 / 15.1 / 14.5 ms per 800x800 frame
+        // the work of a lane here.  Round 4, handing over after 1 / 2 / 3 lane rounds: 15.3 / 15.1 / 14.5 ms per 800x800 frame
         // against 11.9, 92 against 71 ms at 1080p.)
         if (__builtin_popcountll(um) > coop_max && !(q_tasks && st_rounds >= (uint32_t)max_rounds)) {
             // A wave whose rays left a surface together keeps every lane busy, but it is as slow as one ray's walk: ~1 us per visit,
@@ -2347,10 +2347,10 @@ static int render_frame_once(const float* rays_o, const float* rays_d, uint32_t 
     static const int spec_visits = [] { const char* e = getenv("LAE_FRAME_SPEC"); return e ? atoi(e) : 1; }();   // 0: every visit waits for its own probe (A/B)
     static const int coop_max_env = [] { const char* e = getenv("LAE_FRAME_COOP_MAX"); return e ? atoi(e) : -1; }();
     const int coop_max = coop_max_env >= 0 ? coop_max_env : (finish_queue ? FRAME_QUEUE_MAX : FRAME_COOP_MAX);
-    static const int max_rounds = [] { const char* e = getenv("LAE_FRAME_MAX_ROUNDS"); return e ? atoi(e) : FRAME_MAX_ROUNDS; }();
+    const int max_rounds = FRAME_MAX_ROUNDS;                // (sweep 4 / 6 / 8 / 12 closed in round 4: lanes keep walking, DESIGN_LOG)
     // the first walk of a frame is another regime: every ray that hits anything first crosses empty space, a wave's lanes finish
     // at very different times and a low bound sends tens of thousands of rays to the one-wave-per-ray kernel
-    static const int coop_max0 = [] { const char* e = getenv("LAE_FRAME_COOP_MAX0"); return e ? atoi(e) : 0; }();   // -1: as the loop's; sweep -1 / 0 / 2 / 4 / 8 / 32: 10.80 / 10.70 / 10.81 / 10.79 / 10.82 / 11.09 ms at 800x800
+    const int coop_max0 = 0;                                // every lane of the first walk finishes in the lane kernel (sweep -1 / 0 / 2 / 4 / 8 / 32: 10.80 / 10.70 / 10.81 / 10.79 / 10.82 / 11.09 ms at 800x800; closed)
     static const uint32_t admit_cap = [] { const char* e = getenv("LAE_FRAME_ADMIT_CAP"); return e ? (uint32_t)atoi(e) : 4096u; }();   // 0: never (A/B)
     static const int admit_round = [] { const char* e = getenv("LAE_FRAME_ADMIT_ROUND"); return e ? atoi(e) : 2; }();
     uint32_t look_no = 0;
@@ -2397,7 +2397,7 @@ static int render_frame_once(const float* rays_o, const float* rays_d, uint32_t 
     // rows of n_step >= 3 iterations through a wave-private LDS image (k_frame_emit); the host knows a lagging bound of n_alive,
     // so whether an iteration can have n_step >= 3 at all (budget / bound_alive >= 3) decides if the launch asks for the LDS
     static const int grid_tail = [] { const char* e = getenv("LAE_FRAME_GRID_TAIL"); return e ? atoi(e) : 1; }();   // 0: one encoder launch sized for the worst case (A/B)
-    static const int emit_lds_min = [] { const char* e = getenv("LAE_FRAME_EMIT_LDS"); return e ? atoi(e) : 3; }();   // smallest n_step that takes the LDS path; 0: never (A/B)
+    const int emit_lds_min = 3;                             // smallest n_step that takes the LDS path (sweep 3 / 5 / 7 / 8 / never closed in round 4)
     static const int go_early = [] { const char* e = getenv("LAE_FRAME_LOOK_EARLY"); return e ? (atoi(e) != 0) : 1; }();
     unsigned long long* flag_go = g_frame.flags;
     unsigned long long* flag_look = g_frame.flags + 1;

@@ -12,6 +12,9 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 frames=${1:-150}; out=${2:-gpurun_out/r5_grid_loop_fault.txt}
 B=tools/ubench/bin
 mkdir -p $B "$(dirname "$out")"
+for f in $B/liblaenerf_loop1_raw.so $B/liblaenerf_loop1_fix.so $B/liblaenerf_loop2_raw.so; do     # probe builds of older sources lack newer entry points
+  [ -f $f ] && [ $f -ot laenerf_amd/lib/liblaenerf_hip.so ] && rm -f $f
+done
 [ -f $B/liblaenerf_loop1_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop1_raw.so -DLAE_GRID_FWD_LOOP_PROBE=1 --no-pk-rewrite > /dev/null 2>&1 || exit 1
 [ -f $B/liblaenerf_loop1_fix.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop1_fix.so -DLAE_GRID_FWD_LOOP_PROBE=1 > /dev/null 2>&1 || exit 1
 [ -f $B/liblaenerf_loop2_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop2_raw.so -DLAE_GRID_FWD_LOOP_PROBE=2 --no-pk-rewrite > /dev/null 2>&1 || exit 1
