@@ -178,7 +178,7 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def roofline_more(tm, dev):
+def roofline_more(tm, dev, with_frame=True):
     """the kernels furthest below their roofline, priced like `roofline` (HIP events on the launch stream around each operator in
     20 eager steps): hash-grid backward against HBM on its 588 algorithmic bytes per sample (fill + accumulate
     on the main stream, and with the counting pass + scans that run ahead on the side stream), fused head forward / backward
@@ -208,6 +208,10 @@ def roofline_more(tm, dev):
             out[key] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS_F16, 4),
                         "avg_us": round(us, 2), "samples_per_launch": int(n), "flop_per_sample": flop, "kernels": kern}
     # the encoder on tile-ordered frame rows: the operator loop of one 800x800 frame goes through the timed backend operator
+    # (skipped with --no-frame: the kernel traces of the train step stay free of inference kernels)
+    if not with_frame:
+        out["timed"] = "HIP events on the launch stream around each operator, 20 eager steps after the timed region"
+        return out
     try:
         from laenerf_amd import backend, synthetic as S
         net, r = eval_model(dev)
@@ -1231,7 +1235,7 @@ def main():
                          "limiter": "on-chip: the 2 MiB level tables stay in the XCDs' L2s (measured traffic < algorithmic bytes); fine "
                                     "levels run at the L2 request rate, coarse levels at vector-memory issue (DESIGN.md 4)",
                          "timed": "HIP events on the launch stream around the call in 20 eager steps after the timed region"},
-            "roofline_more": roofline_more(timing_split, dev) if timing_split else None,
+            "roofline_more": roofline_more(timing_split, dev, with_frame=not args.no_frame) if timing_split else None,
             "windows": {"ms_per_step": [round(wd / args.steps * 1e3, 4) for wd in windows],
                         "min": round(min(windows) / args.steps * 1e3, 4), "median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
                         "max": round(max(windows) / args.steps * 1e3, 4), "first": round(first_window / args.steps * 1e3, 4),

@@ -42,4 +42,4 @@ def test_bench_prints_one_contract_line():
     assert m["grid_backward_total"]["avg_us"] > m["grid_backward_main_stream"]["avg_us"]
     for k, flop in (("head_forward", 36864), ("head_backward", 73728)):
         assert m[k]["bound"] == "mfma" and m[k]["peak"] == 2500.0 and m[k]["flop_per_sample"] == flop and 0.01 < m[k]["frac"] < 1.0
-    assert m["frame_encoder"]["bound"] == "hbm" and 0.1 < m["frame_encoder"]["frac"] < 1.0 and m["frame_encoder"]["launches"] > 10
+    assert "frame_encoder" not in m                                  # --no-frame: no inference kernels in this run (the default line has it)
