@@ -3,10 +3,11 @@
 hipcc cross-compiles without a GPU; the resulting .so is kept in-tree (git-ignored) so it
 travels to the GPU box with the snapshot.  `python -m laenerf_amd.build [--force]`.
 
-Device code goes through its ASSEMBLY (round 5): every .hip file is compiled to gfx950 assembly, `pk_erratum_rewrite` swaps the
-operands of the one packed-fp32 instruction form that returns wrong results while the matrix pipe is busy (see below), the
-assembly is assembled / linked / bundled with the LLVM tools of the ROCm image, and the host half of the file is compiled
-against that code object (`-fcuda-include-gpubinary`) -- the same steps `hipcc -c` runs internally, with one pass in between.
+Device code is compiled WITHOUT gfx950's packed-fp32 instructions (round 5; the erratum note below) and goes through its
+assembly: every .hip file's device half is compiled to gfx950 assembly with `-target-feature -packed-fp32-ops`, the assembly is
+checked (no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32 may be left), assembled / linked / bundled with the LLVM
+tools of the ROCm image, and the host half of the file is compiled against that code object (`-fcuda-include-gpubinary`) -- the
+steps `hipcc -c` runs internally, with the device half's own flags and one check in between.
 """
 import concurrent.futures
 import json
@@ -29,47 +30,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 LLVM_BIN = os.environ.get("LAE_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# gfx950 packed-fp32 operand-selection erratum (found in round 5; DESIGN.md section 8, tools/ubench/pk_opsel.hip,
-# profiles/r5_pk_opsel_erratum.txt).  While v_mfma instructions of ANOTHER wave are in flight on the SIMD (a kernel on a second
-# stream, or a second process on the GPU),
-#       v_pk_mul_f32 / v_pk_add_f32  vD, SRC0, SRC1  op_sel:[0,1] ...      with SRC1 a VGPR pair other than SRC0
-# sometimes computes its LOW result with SRC1's high half read as ZERO (3-10 % of the instructions beside back-to-back MFMA loops,
-# 0 of 1e9 alone).  Every other op_sel value, an SGPR SRC1, SRC1 == SRC0, v_pk_fma_f32 and v_pk_mov_b32 were never wrong.  The
-# compiler emits the form wherever it folds a lane shuffle into a packed multiply / add (55 places in this library: the fill pass
-# of the hash-grid backward, the SH encoder, the palette backward, the frustum marking).  Both operations commute, so the same
-# arithmetic is available as  vD, SRC1, SRC0  op_sel:[1,0]  with the per-source modifiers swapped -- bit-identical results, and
-# the form that was never wrong.  tests/test_isa_cpu.py scans the shipped code object for survivors.
-_PK = re.compile(r"^(\s*)(v_pk_(?:mul|add)_f32)(\s+)(v\[\d+:\d+\])\s*,\s*([vs]\[\d+:\d+\]|[^,\s]+)\s*,\s*([vs]\[\d+:\d+\]|[^,\s]+)((?:\s+\w+:\[[\d,]+\])*)\s*(;.*)?$")
-_MOD = re.compile(r"(\w+):\[(\d),(\d)\]")
+# gfx950 packed-fp32 operand-selection erratum (found in round 5; DESIGN.md section 8a, tools/ubench/pk_opsel.hip,
+# profiles/r5_pk_opsel_erratum.txt, profiles/r5_suite_beside_mfma.txt).  While v_mfma instructions of ANOTHER wave are in flight
+# on the SIMD (a kernel on a second stream, or a second process on the GPU), a packed-fp32 instruction whose LOW result takes the
+# HIGH half of SRC1 (op_sel = [0,1,..]) with SRC1 in VGPRs can compute that result with SRC1.hi read as ZERO: v_pk_mul_f32 /
+# v_pk_add_f32 in 0.06-10 % of the instructions of an isolated test, v_pk_fma_f32 in lanes 48-63 of EVERY wave of k_grid_fwd's
+# dy_dx chain (11 parity tests fail beside an MFMA-spinning process, every time).  The compiler emits such forms wherever it folds
+# a lane shuffle into a packed operation.  Which forms are safe could only be established empirically, so none is used: the
+# device half is compiled with the `packed-fp32-ops` target feature off (same-box A/B of the bench: train step 0.352 against
+# 0.355 ms, frames equal, style step +3 % -- nothing to lose).  LAE_BUILD_PACKED_FP32=1 / --packed-fp32 turn the feature back on
+# for the reproducers (tools/grid_loop_fault.sh, tools/mfma_neighbour_check.py --lib ...).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # device half only (x86 does not know the feature)
+_PK_FP32 = re.compile(r"^\s*v_pk_(?:mul_f32|add_f32|fma_f32|mov_b32)\b")
 
 
-def pk_erratum_is_vulnerable(line):
-    m = _PK.match(line.rstrip("\n"))
-    if not m:
-        return None
-    mods = dict((k, (a, b)) for k, a, b in _MOD.findall(m.group(7) or ""))
-    if mods.get("op_sel") != ("0", "1"):
-        return None
-    s0, s1 = m.group(5), m.group(6)
-    if not s1.startswith("v[") or s1 == s0:
-        return None
-    return m, mods
-
-
-def pk_erratum_rewrite(asm_text):
-    """-> (rewritten assembly, number of instructions rewritten)"""
-    out, n = [], 0
-    for line in asm_text.split("\n"):
-        hit = pk_erratum_is_vulnerable(line)
-        if hit is None:
-            out.append(line)
-            continue
-        m, mods = hit
-        mods.setdefault("op_sel_hi", ("1", "1"))
-        swapped = " ".join(f"{k}:[{b},{a}]" for k, (a, b) in mods.items())
-        out.append(f"{m.group(1)}{m.group(2)}{m.group(3)}{m.group(4)}, {m.group(6)}, {m.group(5)} {swapped}")
-        n += 1
-    return "\n".join(out), n
+def packed_fp32_instructions(asm_text):
+    """the packed-fp32 instructions of a piece of gfx950 assembly / disassembly (lines)"""
+    return [ln.strip() for ln in asm_text.split("\n") if _PK_FP32.match(ln.split(";")[0].split("//")[0])]
 
 
 def _deps():
@@ -86,19 +63,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False, out=None, extra_flags=(), rewrite=True):
-    """out / extra_flags / rewrite=False: probe builds (tools/grid_loop_fault.sh): another library file, never the in-tree default"""
+def build(force=False, verbose=False, out=None, extra_flags=(), packed_fp32=False):
+    """out / extra_flags / packed_fp32=True: probe builds (tools/grid_loop_fault.sh): another library file, never the in-tree default"""
     global SO
     if out is not None:
         saved, SO = SO, os.path.abspath(out)
         try:
             os.makedirs(os.path.dirname(SO), exist_ok=True)
-            return _build(verbose, list(extra_flags), rewrite)
+            return _build(verbose, list(extra_flags), packed_fp32)
         finally:
             SO = saved
     if not force and not needs_build():
         return SO
-    return _build(verbose, [], rewrite)
+    return _build(verbose, [], packed_fp32)
 
 
 def _run(cmd, verbose, what):
@@ -112,53 +89,50 @@ def _run(cmd, verbose, what):
         print(p.stdout.decode())
 
 
-def _compile_one(src, obj, flags, verbose, rewrite):
-    """one translation unit: device assembly -> erratum rewrite -> code object -> fat binary -> host object.  -> instructions rewritten"""
+def _compile_one(src, obj, flags, verbose, packed_fp32):
+    """one translation unit: device assembly (packed fp32 off) -> check -> code object -> fat binary -> host object.
+    -> packed-fp32 instructions in the device code (0 unless packed_fp32)"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     path = os.path.join(CSRC, src)
     stem = obj[:-2]
     asm, dev_o, co, fb = stem + ".s", stem + ".dev.o", stem + ".co", stem + ".hipfb"
     try:
-        _run([hipcc] + flags + ["-x", "hip", "--cuda-device-only", "-S", path, "-o", asm], verbose, f"hipcc (device) on {src}")
-        text = open(asm).read()
-        n = 0
-        if rewrite:
-            text, n = pk_erratum_rewrite(text)
-            left = sum(1 for ln in text.split("\n") if pk_erratum_is_vulnerable(ln))
-            if left:
-                raise RuntimeError(f"{src}: {left} vulnerable packed-fp32 instruction(s) survived the rewrite")
-            open(asm, "w").write(text)
+        _run([hipcc] + flags + ([] if packed_fp32 else NO_PACKED_FP32) + ["-x", "hip", "--cuda-device-only", "-S", path, "-o", asm], verbose,
+             f"hipcc (device) on {src}")
+        left = packed_fp32_instructions(open(asm).read())
+        if left and not packed_fp32:
+            raise RuntimeError(f"{src}: {len(left)} packed-fp32 instruction(s) in the device code although the feature is off: {left[:3]}")
         _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", dev_o], verbose, f"assembler on {src}")
         _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", co, dev_o], verbose, f"lld on {src}")
         _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
               "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={co}", f"-output={fb}"], verbose, f"bundler on {src}")
         _run([hipcc] + flags + ["-x", "hip", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", path, "-o", obj], verbose, f"hipcc (host) on {src}")
-        return n
+        return len(left)
     finally:
         for f in (asm, dev_o, co, fb):
             if os.path.exists(f):
                 os.remove(f)
 
 
-def _build(verbose, more, rewrite):
+def _build(verbose, more, packed_fp32):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("LAE_BUILD_EXTRA_FLAGS", "").split() + more      # probes only (e.g. -DLAE_GRID_STAMPS, tools/grid_bwd_stamps.py)
-    if os.environ.get("LAE_BUILD_NO_PK_REWRITE") == "1":                    # probes only: the compiler's own code (tools/grid_loop_fault.sh)
-        rewrite = False
+    if os.environ.get("LAE_BUILD_PACKED_FP32") == "1":                      # probes only: the compiler's default code (tools/grid_loop_fault.sh)
+        packed_fp32 = True
     os.makedirs(LIBDIR, exist_ok=True)
     tag = f"{os.getpid()}.{abs(hash(SO)) % 100000}"                         # per-process, per-target object names: concurrent builds do not share files
     objs = [os.path.join(LIBDIR, f"{src.rsplit('.', 1)[0]}.{tag}.o") for src in SOURCES]
-    rewritten = {}
+    counts = {}
     try:
         with concurrent.futures.ThreadPoolExecutor(len(SOURCES)) as ex:
-            futs = {src: ex.submit(_compile_one, src, obj, FLAGS + extra, verbose, rewrite) for src, obj in zip(SOURCES, objs)}
+            futs = {src: ex.submit(_compile_one, src, obj, FLAGS + extra, verbose, packed_fp32) for src, obj in zip(SOURCES, objs)}
             for src, f in futs.items():
-                rewritten[src] = f.result()
+                counts[src] = f.result()
         tmp_so = SO + f".{os.getpid()}.tmp"                      # link to a temp name, then rename: a reader never maps a half-written library
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_so] + objs)
         os.replace(tmp_so, SO)
         with open(SO + ".isa.json", "w") as f:
-            json.dump({"pk_erratum_rewrite": bool(rewrite), "instructions_rewritten": rewritten, "total": sum(rewritten.values())}, f)
+            json.dump({"packed_fp32_ops": bool(packed_fp32), "packed_fp32_instructions": counts, "total": sum(counts.values())}, f)
     finally:
         for o in objs:
             if os.path.exists(o):
@@ -167,8 +141,8 @@ def _build(verbose, more, rewrite):
 
 
 if __name__ == "__main__":
-    if "--out" in sys.argv:                                  # python -m laenerf_amd.build --out path.so [-DFLAG ...] [--no-pk-rewrite]
+    if "--out" in sys.argv:                                  # python -m laenerf_amd.build --out path.so [-DFLAG ...] [--packed-fp32]
         print(build(out=sys.argv[sys.argv.index("--out") + 1], extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")], verbose=True,
-                    rewrite="--no-pk-rewrite" not in sys.argv))
+                    packed_fp32="--packed-fp32" in sys.argv))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Reproducer of round 4's "two-process fault" and of its cause (DESIGN.md section 8; laenerf_amd/build.py "erratum").
+# Reproducer of round 4's "two-process fault" and of its cause (DESIGN.md section 8a; laenerf_amd/build.py "erratum").
 # Builds three probe libraries into tools/ubench/bin/ unless they exist:
-#   liblaenerf_loop1_raw.so   k_grid_fwd_lean in the failing loop form (LAE_GRID_FWD_LOOP_PROBE=1), compiler output untouched
-#   liblaenerf_loop1_fix.so   the same source with the build's packed-fp32 operand swap
-#   liblaenerf_loop2_raw.so   the loop around the __forceinline__ function (LAE_GRID_FWD_LOOP_PROBE=2), compiler output untouched
+#   liblaenerf_loop1_raw.so   k_grid_fwd_lean in the failing loop form (LAE_GRID_FWD_LOOP_PROBE=1), compiler defaults (packed fp32 ON)
+#   liblaenerf_loop1_fix.so   the same source built like the shipped library (packed fp32 OFF)
+#   liblaenerf_loop2_raw.so   the loop around the __forceinline__ function (LAE_GRID_FWD_LOOP_PROBE=2), compiler defaults
 # then renders the same frame 150 times per (library, neighbour) pair and counts frames that differ from the first
 # (tools/grid_loop_fault.py; one JSON line each), and runs the isolated instruction test (tools/ubench/pk_opsel).
 #   tools/grid_loop_fault.sh [frames] [out-file]
@@ -15,9 +15,9 @@ mkdir -p $B "$(dirname "$out")"
 for f in $B/liblaenerf_loop1_raw.so $B/liblaenerf_loop1_fix.so $B/liblaenerf_loop2_raw.so; do     # probe builds of older sources lack newer entry points
   [ -f $f ] && [ $f -ot laenerf_amd/lib/liblaenerf_hip.so ] && rm -f $f
 done
-[ -f $B/liblaenerf_loop1_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop1_raw.so -DLAE_GRID_FWD_LOOP_PROBE=1 --no-pk-rewrite > /dev/null 2>&1 || exit 1
+[ -f $B/liblaenerf_loop1_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop1_raw.so -DLAE_GRID_FWD_LOOP_PROBE=1 --packed-fp32 > /dev/null 2>&1 || exit 1
 [ -f $B/liblaenerf_loop1_fix.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop1_fix.so -DLAE_GRID_FWD_LOOP_PROBE=1 > /dev/null 2>&1 || exit 1
-[ -f $B/liblaenerf_loop2_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop2_raw.so -DLAE_GRID_FWD_LOOP_PROBE=2 --no-pk-rewrite > /dev/null 2>&1 || exit 1
+[ -f $B/liblaenerf_loop2_raw.so ] || python3 -m laenerf_amd.build --out $B/liblaenerf_loop2_raw.so -DLAE_GRID_FWD_LOOP_PROBE=2 --packed-fp32 > /dev/null 2>&1 || exit 1
 [ -x $B/spinner ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $B/spinner tools/ubench/spinner.hip || exit 1
 [ -x $B/pk_opsel ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $B/pk_opsel tools/ubench/pk_opsel.hip || exit 1
 : > "$out"
