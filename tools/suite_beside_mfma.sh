@@ -13,7 +13,7 @@ sp=$!
 sleep 2
 timeout -k 10 1000 python3 -m pytest -q -m gpu tests/test_gpu_raymarching.py tests/test_gpu_encoders.py tests/test_gpu_ffmlp.py tests/test_gpu_e2e.py \
     tests/test_gpu_optim.py tests/test_gpu_style.py tests/test_gpu_density_grid.py tests/test_gpu_rays.py tests/test_gpu_editgrid.py \
-    tests/test_gpu_edit_dataset.py tests/test_gpu_train_loop.py tests/test_gpu_frame.py -k "not degrades and not matrix_pipe and not two_processes and not variants" > "$out" 2>&1
+    tests/test_gpu_edit_dataset.py tests/test_gpu_train_loop.py tests/test_gpu_frame.py tests/test_gpu_frame1080.py -k "not degrades and not matrix_pipe and not two_processes and not variants and not two_ranks" > "$out" 2>&1
 rc=$?
 kill $sp 2>/dev/null; wait $sp 2>/dev/null
 echo "rc=$rc (beside spinner mfma)" >> "$out"
