@@ -54,6 +54,15 @@ def main():
         G.grid_encode_backward(g, x, table, offs, ge, B, 3, C, L, float(np.log2(pls)), 16, None, None, 0, False, 0)
         return ge
 
+    offsets_host = offsets.astype(np.int32)
+
+    def grid_bwd_count():
+        # the position-only half (COUNT pass + scans) that the pipelined train step runs on its side stream BESIDE the main stream's
+        # MFMA kernels: the plan's counters / offsets as bytes
+        plan = G.grid_backward_plan(x, offs, B, 3, C, L, float(np.log2(pls)), 16, 0, False, 0, True, offsets_host=offsets_host)
+        w0 = ((2 + 32 * 64) * 4 + 255) // 256 * 256 // 4          # plan_layout (gridencoder.hip): items per partition, then their queue offsets
+        return plan.view(torch.int32)[w0:w0 + 2 * L * 512].clone()
+
     x32 = x[:30000].contiguous()
     table32 = torch.from_numpy(rng.uniform(-1e-4, 1e-4, (int(offsets[-1]), C)).astype(np.float32)).to(dev)
 
@@ -97,7 +106,7 @@ def main():
     def frame():
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
             return r.render_eval(o, d, bg_color=1, max_steps=1024)["image"].clone()
-    work = {"grid_backward_fp16": grid_bwd, "grid_forward_fp32_dy_dx": grid_fwd_dy_dx, "sh_forward_deg4": sh_fwd, "palette_step_gradients": palette_grads, "inference_frame": frame}
+    work = {"grid_backward_fp16": grid_bwd, "grid_backward_count_pass": grid_bwd_count, "grid_forward_fp32_dy_dx": grid_fwd_dy_dx, "sh_forward_deg4": sh_fwd, "palette_step_gradients": palette_grads, "inference_frame": frame}
     ref = {k: f() for k, f in work.items()}
     torch.cuda.synchronize()
     child = None
