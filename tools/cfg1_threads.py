@@ -1,3 +1,4 @@
+"""cpu_baseline_cfg1 (bench.py) at 16 / 32 / 64 / 128 / 256 host threads: how the cfg1 CPU baseline scales on a box (round 4)"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import bench, torch

@@ -1,3 +1,4 @@
+"""median kernel durations of two rocprofv3 kernel traces side by side: python tools/cmp_kernel_trace.py a_kernel_trace.csv b_kernel_trace.csv"""
 import csv, collections, statistics, sys
 def med(path):
     d=collections.defaultdict(list)

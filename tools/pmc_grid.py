@@ -1,3 +1,4 @@
+"""profile target for `rocprofv3 --pmc ... -- python tools/pmc_grid.py`: hash-grid forward launches on one marched lego batch (round 1 counter passes)"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from laenerf_amd import synthetic as S
