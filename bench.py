@@ -484,7 +484,7 @@ def grid_update(dev):
             "note": "not inside `value`: the reference runs it between train steps (nerf/utils.py:1465)"}
 
 
-def style_step(dev, P=100000, steps=30):
+def style_step(dev, P=100000, steps=30, switches=None):
     """configs[4]: one optimisation step of LAENeRF's palette network (train_LAENeRF_step, nerf/utils.py:980-1043, point-wise
     losses) on P region-masked points: hash-grid encode -> weight / offset MLPs -> palette recomposition -> MSE + weight +
     offset + palette losses -> backward -> Adam(lr 1e-3) under a GradScaler.  Synthetic x_term in a 0.3-radius ball
@@ -497,6 +497,9 @@ def style_step(dev, P=100000, steps=30):
     torch.manual_seed(7)
     m = LAENeRF(params, dir_encoding="sphere_harmonics").to(dev)
     m.train()
+    for k, val in (switches or {}).items():                    # A/B runs (tools/style_step_ab.py): fused_inputs / ffmlp_shadows off
+        assert hasattr(m, k), k
+        setattr(m, k, val)
     opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
     v = torch.randn(P, 3, device=dev)
     x = v / v.norm(dim=-1, keepdim=True) * 0.3 * torch.rand(P, 1, device=dev) ** (1 / 3)

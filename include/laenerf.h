@@ -419,6 +419,15 @@ LAE_API int lae_ffmlp_backward(const void* grad, const void* inputs, const void*
                        uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
                        void* backward_buffer, void* grad_inputs, void* grad_weights,
                        void* stream);
+/* MI355X extension (round 5): accumulate != 0 ADDS the weight gradient to grad_weights (an optimizer-owned fp16 accumulator) instead
+ * of overwriting it; nonfinite_flag (device int32, may be NULL) is OR-ed with 1 when a stored weight gradient is not finite.  Both
+ * are served by the fused recompute backward only (hidden 64, ReLU, 1-2 hidden GEMMs, input 32 / 48 / 64): LAE_EINVAL otherwise. */
+LAE_API int lae_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights,
+                          const void* forward_buffer, uint32_t B, uint32_t input_dim,
+                          uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                          uint32_t activation, uint32_t output_activation, int calc_grad_inputs,
+                          void* backward_buffer, void* grad_inputs, void* grad_weights,
+                          int accumulate, int32_t* nonfinite_flag, void* stream);
 
 /* MI355X-native fusion of NeRFNetwork.forward after the encoder (nerf/network_ff.py:57-79): sigma FFMLP(32,64,2 layers)
  * -> sigma = density_scale * exp(h[0]); colour input = [SH degree 4 of dirs | h[1..15] | 0] -> colour FFMLP(32,64,3 layers)
@@ -491,6 +500,16 @@ LAE_API int lae_style_loss_backward(const void* w_logits, const void* o_raw, con
                             uint32_t M, const float* target, const float* fin, const float* upstream, float w_uniform,
                             float w_non_uniform, float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch,
                             int with_reg, float w_valid, float w_distinct, void* stream);
+
+/* ---- LAENeRF input assembly (editing/style_encoder.py:135-146: encoder rows, SH(3) of the directions, cast, pad, cat -- torch ops
+ * and separate launches in the reference) ----
+ * forward: feats_lm [16, M, 2] fp16 (the grid kernels' level-major output) + dirs [M,3] fp32 -> feat [Mp, 32] fp16 rows and
+ *   off_in [Mp, off_cols] fp16 rows = [feat | SH(degree)(dirs) | zeros]; rows M..Mp-1 zero (Mp >= M, the MLPs' multiple of 16).
+ *   degree 0: no directions, off_in is not written.  degree <= 4, off_cols even, 32 + degree^2 <= off_cols <= 48.
+ * backward: grad_lm [16, M, 2] fp16 = g_feat [Mp,32] + g_off [Mp,off_cols][:, :32] (fp32 add, one rounding; either may be NULL). */
+LAE_API int lae_style_assemble_forward(const void* feats_lm, const float* dirs, uint32_t M, uint32_t Mp, uint32_t degree, void* feat,
+                               void* off_in, uint32_t off_cols, void* stream);
+LAE_API int lae_style_assemble_backward(const void* g_feat, const void* g_off, uint32_t M, uint32_t off_cols, void* grad_lm, void* stream);
 
 /* ---- edit-grid region growing (editing/editgrid.py:274-340 EditGrid.grow_region_queue; Python + collections.deque
  * in the reference) ----

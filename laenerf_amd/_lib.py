@@ -65,6 +65,7 @@ SIGNATURES = {
     "lae_ffmlp_forward": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_inference": [vp, vp, u32, u32, u32, u32, u32, u32, u32, vp, vp, vp],
     "lae_ffmlp_backward": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, vp],
+    "lae_ffmlp_backward_ex": [vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, i32, vp, vp, vp, i32, vp, vp],
     "lae_nerf_head_forward": [vp, vp, vp, vp, u32, f32, vp, vp, vp, i32, vp],
     "lae_nerf_density_forward": [vp, vp, u32, f32, vp, vp, i32, vp],
     "lae_density_grid_positions": [vp, u32, u32, f32, vp, vp, vp, vp],
@@ -80,6 +81,8 @@ SIGNATURES = {
     "lae_style_loss_forward": [vp, vp, vp, vp, u32, u32, f32, f32, f32, vp, vp, vp, vp, u32, f32, f32, vp],
     "lae_style_loss_backward": [vp, vp, vp, u32, u32, u32, vp, vp, vp, f32, f32, f32, vp, vp, vp, vp, i32, f32, f32, vp],
     "lae_grow_region": [vp, vp, u32, u32, f32, vp, u32, vp, u32, u32, vp],
+    "lae_style_assemble_forward": [vp, vp, u32, u32, u32, vp, vp, u32, vp],
+    "lae_style_assemble_backward": [vp, vp, u32, u32, vp, vp],
     "lae_min_dist_to_points": [vp, u32, vp, u32, f32, vp, vp, vp, vp],
     "lae_mse_loss_forward": [vp, vp, u32, vp, vp, vp, vp],
     "lae_adam_check": [vp, i32, u64, vp, vp],

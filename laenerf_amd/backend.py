@@ -521,9 +521,18 @@ class _FFMLP:
 
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                       output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+                       output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, accumulate=False,
+                       nonfinite_flag=None):
+        """accumulate / nonfinite_flag (MI355X extensions, fused backward only): ADD the weight gradient to grad_weights (an
+        optimizer-owned fp16 accumulator); address (int) of a device int32 OR-ed with 1 when a stored gradient is not finite"""
         ts = (grad, inputs, weights, forward_buffer, backward_buffer, grad_inputs, grad_weights)
         need_cuda(*ts); need_contig(*ts); _FFMLP._half(*ts)
+        if accumulate or nonfinite_flag is not None:
+            check(_lib.load().lae_ffmlp_backward_ex(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim,
+                                                    output_dim, hidden_dim, num_layers, activation, output_activation,
+                                                    int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
+                                                    ptr(grad_weights), int(bool(accumulate)), nonfinite_flag, stream()), "ffmlp_backward")
+            return
         check(_lib.load().lae_ffmlp_backward(ptr(grad), ptr(inputs), ptr(weights), ptr(forward_buffer), B, input_dim,
                                              output_dim, hidden_dim, num_layers, activation, output_activation,
                                              int(bool(calc_grad_inputs)), ptr(backward_buffer), ptr(grad_inputs),
@@ -661,6 +670,24 @@ class _Style:
         check(lib.lae_palette_backward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(g_pred), ptr(g_w), ptr(g_o),
                                        ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws), stream()), "palette_backward")
 
+
+    @staticmethod
+    def style_assemble_forward(feats_lm, dirs, M, Mp, degree, feat, off_in, off_cols):
+        """level-major encoder output + directions -> the two MLPs' input rows in one launch (include/laenerf.h)"""
+        ts = (feats_lm, dirs, feat, off_in)
+        need_cuda(*ts); need_contig(*ts)
+        if feats_lm.dtype != _F16 or feat.dtype != _F16 or (off_in is not None and off_in.dtype != _F16) or (dirs is not None and dirs.dtype != torch.float32):
+            raise RuntimeError("style_assemble_forward: features float16, directions float32")
+        check(_lib.load().lae_style_assemble_forward(ptr(feats_lm), ptr(dirs), M, Mp, degree, ptr(feat), ptr(off_in), off_cols, stream()),
+              "style_assemble_forward")
+
+    @staticmethod
+    def style_assemble_backward(g_feat, g_off, M, off_cols, grad_lm):
+        ts = (g_feat, g_off, grad_lm)
+        need_cuda(*ts); need_contig(*ts)
+        if any(t is not None and t.dtype != _F16 for t in ts):
+            raise RuntimeError("style_assemble_backward: float16 gradients")
+        check(_lib.load().lae_style_assemble_backward(ptr(g_feat), ptr(g_off), M, off_cols, ptr(grad_lm), stream()), "style_assemble_backward")
 
     @staticmethod
     def style_loss_forward(pred, target, w_hat, o_hat, M, n_active, lw, scale, fin, reg_palette=None, reg_w=(0.0, 0.0)):

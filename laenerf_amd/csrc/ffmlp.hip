@@ -394,8 +394,8 @@ __device__ __forceinline__ void dw_reduce_body(const float* __restrict__ slabs, 
     }
 }
 __global__ __launch_bounds__(64 * DWR_GROUPS) void k_dw_reduce(const float* __restrict__ slabs, uint32_t n_slices, uint32_t nW,
-                                                               half_t* __restrict__ gw, int accumulate = 0) {
-    dw_reduce_body(slabs, n_slices, nW, gw, accumulate, blockIdx.x);
+                                                               half_t* __restrict__ gw, int accumulate = 0, int32_t* __restrict__ nf_flag = nullptr) {
+    dw_reduce_body(slabs, n_slices, nW, gw, accumulate, blockIdx.x, nf_flag);
 }
 // the same reduction for two networks in one launch (blocks [0, nb_a) reduce A, the rest B): one graph node less per step
 // One block more than the reduction needs takes the deferred loss value along (lae_composite_rays_train_step with
@@ -1193,7 +1193,8 @@ static int bwd_fused_variant() {
 
 template <int IN, int NH, int MODE = 0>
 int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint32_t B, half_t* grad_in, half_t* gw, hipStream_t s,
-                     HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0, float* slabs = nullptr, uint32_t* n_slices_out = nullptr) {
+                     HeadBwdArgs ha = HeadBwdArgs{}, int accumulate = 0, float* slabs = nullptr, uint32_t* n_slices_out = nullptr,
+                     int32_t* nf_flag = nullptr) {
     // slabs != nullptr: the partial slabs go to the caller's region (room for 2 * num_cus slices) and the reduction is
     // left to the caller (lae_nerf_head_backward reduces both networks in one launch)
     const uint32_t nW = 64 * (IN + 64 * NH + 16);
@@ -1231,7 +1232,7 @@ int launch_bwd_fused(const half_t* grad, const half_t* x, const half_t* W, uint3
         k_mlp_bwd_coop<IN, NH, MODE, WAVES><<<blocks, 64 * WAVES, lds_bytes, s>>>(grad, x, W, n_tiles, grad_in, ws, nW, ha);
     }
     if (n_slices_out) *n_slices_out = blocks;
-    if (!slabs) k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate);
+    if (!slabs) k_dw_reduce<<<lae::cdiv(nW, 64), 64 * DWR_GROUPS, 0, s>>>(ws, blocks, nW, gw, accumulate, nf_flag);
     return LAE_OK;
 }
 
@@ -1903,6 +1904,14 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
                        uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                        uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
                        void* grad_inputs, void* grad_weights, void* stream) {
+    return lae_ffmlp_backward_ex(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                 output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, 0, nullptr, stream);
+}
+
+int lae_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                          uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                          uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
+                          void* grad_inputs, void* grad_weights, int accumulate, int32_t* nonfinite_flag, void* stream) {
     (void)output_activation;   // the reference ignores it too (ffmlp.cu:781)
     if (B == 0) return LAE_OK;
     if (!grad || !inputs || !weights || !grad_weights) return LAE_ENULL;
@@ -1919,14 +1928,18 @@ int lae_ffmlp_backward(const void* grad, const void* inputs, const void* weights
     if (g_ffmlp_mode != 1 && hidden_dim == 64 && activation == LAE_ACT_RELU && (nh == 1 || nh == 2) &&
         (input_dim == 32 || input_dim == 48 || input_dim == 64)) {
         rc = LAE_EINVAL;
-        if (nh == 1 && input_dim == 32) rc = launch_bwd_fused<32, 1>(g, in, W, B, gi, gw, s);
-        else if (nh == 2 && input_dim == 32) rc = launch_bwd_fused<32, 2>(g, in, W, B, gi, gw, s);
-        else if (nh == 1 && input_dim == 48) rc = launch_bwd_fused<48, 1>(g, in, W, B, gi, gw, s);
-        else if (nh == 2 && input_dim == 48) rc = launch_bwd_fused<48, 2>(g, in, W, B, gi, gw, s);
-        else if (nh == 1 && input_dim == 64) rc = launch_bwd_fused<64, 1>(g, in, W, B, gi, gw, s);
-        else if (nh == 2 && input_dim == 64) rc = launch_bwd_fused<64, 2>(g, in, W, B, gi, gw, s);
+        if (nh == 1 && input_dim == 32) rc = launch_bwd_fused<32, 1>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
+        else if (nh == 2 && input_dim == 32) rc = launch_bwd_fused<32, 2>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
+        else if (nh == 1 && input_dim == 48) rc = launch_bwd_fused<48, 1>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
+        else if (nh == 2 && input_dim == 48) rc = launch_bwd_fused<48, 2>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
+        else if (nh == 1 && input_dim == 64) rc = launch_bwd_fused<64, 1>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
+        else if (nh == 2 && input_dim == 64) rc = launch_bwd_fused<64, 2>(g, in, W, B, gi, gw, s, HeadBwdArgs{}, accumulate, nullptr, nullptr, nonfinite_flag);
         if (rc) return rc;
         return lae::check_launch("ffmlp_backward(fused)");
+    }
+    if (accumulate || nonfinite_flag) {
+        lae::set_last_error_str("ffmlp_backward_ex: accumulate / nonfinite_flag are served by the fused backward only (hidden 64, ReLU, 1-2 hidden GEMMs, input 32 / 48 / 64)");
+        return LAE_EINVAL;
     }
     if (!forward_buffer || !backward_buffer) return LAE_ENULL;
     switch (hidden_dim) {

@@ -15,6 +15,7 @@
 namespace {
 
 typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 constexpr int PAL_MAX = 16;          // FFMLP output width
 constexpr int PAL_BLOCK = 256;
 
@@ -368,9 +369,120 @@ int check_palette(uint32_t P, uint32_t mask) {
     return (mask & ((1u << P) - 1u)) ? LAE_OK : LAE_EINVAL;        // at least one active base
 }
 
+
+// ---- LAENeRF input assembly (round 5): what sits between the hash-grid encoder and the two MLPs of LAENeRF.forward_train
+// (editing/style_encoder.py:135-146).  The reference takes the encoder's [M,32] rows, evaluates SH(3) of the directions, casts,
+// pads and concatenates: with this repo's operators that was a transpose of the encoder's level-major output, an SH launch, a
+// division by `size`, a cast, a zero fill and a cat (31 us, six launches per step of 100 k points) and, backwards, two slice
+// copies, an add and the inverse transpose (20 us, four launches).  Here: ONE kernel each way.  The values are the separate
+// operators' bit for bit (same SH evaluation, same fp16 roundings, the two gradients added in fp32 and rounded once like torch's
+// half add).
+#include "sh_table.inc"
+constexpr int SA_BLOCK = 256;
+// feats_lm [16][M] half2 (level-major) + dirs [M,3] -> feat [Mp,32] half rows and off_in [Mp,off_cols] half rows = [feat | SH(DEG) | 0];
+// rows M..Mp-1 (the MLPs want a multiple of 16 rows) are zero.  DEG = 0: no directions, off_in is not written.
+template <int DEG>
+__global__ __launch_bounds__(SA_BLOCK) void k_style_assemble_fwd(const uint32_t* __restrict__ feats_lm, const float* __restrict__ dirs, uint32_t M,
+                                                                 uint32_t Mp, uint32_t* __restrict__ feat, uint32_t* __restrict__ off_in,
+                                                                 uint32_t off_words) {
+    constexpr int C2 = DEG * DEG;
+    constexpr int MAXW = 24;                                // 48 halves
+    __shared__ uint32_t tile[SA_BLOCK * (MAXW + 1)];
+    const uint32_t base = blockIdx.x * SA_BLOCK, b = base + threadIdx.x;
+    uint32_t* row = tile + threadIdx.x * (MAXW + 1);
+    const bool live = b < M;
+#pragma unroll
+    for (int l = 0; l < 16; l++) row[l] = live ? feats_lm[(size_t)l * M + b] : 0u;
+    if constexpr (DEG > 0) {
+        float o[C2 > 0 ? C2 : 1], g0[1], g1[1], g2[1];
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (live) { x = dirs[3 * (size_t)b]; y = dirs[3 * (size_t)b + 1]; z = dirs[3 * (size_t)b + 2]; }
+        sh_eval<DEG, false>(x, y, z, o, g0, g1, g2);
+        // the basis value is ROUNDED TO fp32 FIRST, like the SH operator's output that torch then casts: without the barrier the
+        // compiler folds multiply + conversion into v_fma_mixlo_f16 (one rounding), which differs from the operator chain at fp32 ties
+        // (1 value in 36 864 in tests/test_gpu_style.py::test_fused_input_assembly_equals_the_operator_chain)
+        half_t hv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float v = (i < C2 && live) ? o[i < C2 ? i : 0] : 0.0f;
+            asm volatile("" : "+v"(v));
+            hv[i] = (half_t)v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const half2_t h2 = {hv[2 * i], hv[2 * i + 1]};
+            row[16 + i] = __builtin_bit_cast(uint32_t, h2);
+        }
+    }
+    __syncthreads();
+    const uint32_t nrow = min((uint32_t)SA_BLOCK, Mp > base ? Mp - base : 0u);
+    for (uint32_t e = threadIdx.x; e < nrow * 16u; e += SA_BLOCK) {
+        const uint32_t r = e >> 4, c = e & 15u;
+        feat[(size_t)(base + r) * 16u + c] = tile[r * (MAXW + 1) + c];
+    }
+    if constexpr (DEG > 0) {
+        for (uint32_t e = threadIdx.x; e < nrow * off_words; e += SA_BLOCK) {
+            const uint32_t r = e / off_words, c = e - r * off_words;
+            off_in[(size_t)(base + r) * off_words + c] = tile[r * (MAXW + 1) + c];
+        }
+    }
+}
+// grad_lm [16][M] half2 = g_feat [Mp,32] rows + the first 32 columns of g_off [Mp,off_cols] rows (either may be NULL)
+__global__ __launch_bounds__(SA_BLOCK) void k_style_assemble_bwd(const uint32_t* __restrict__ g_feat, const uint32_t* __restrict__ g_off, uint32_t M,
+                                                                 uint32_t off_words, uint32_t* __restrict__ grad_lm) {
+    __shared__ uint32_t tile[SA_BLOCK * 17];
+    const uint32_t base = blockIdx.x * SA_BLOCK;
+    const uint32_t nrow = min((uint32_t)SA_BLOCK, M - base);
+    for (uint32_t e = threadIdx.x; e < nrow * 16u; e += SA_BLOCK) {
+        const uint32_t r = e >> 4, c = e & 15u;
+        float a0 = 0.f, a1 = 0.f;
+        bool any = false;
+        if (g_feat) { const half2_t v = __builtin_bit_cast(half2_t, g_feat[(size_t)(base + r) * 16u + c]); a0 = (float)v[0]; a1 = (float)v[1]; any = true; }
+        if (g_off) {
+            const half2_t v = __builtin_bit_cast(half2_t, g_off[(size_t)(base + r) * off_words + c]);
+            if (any) { a0 += (float)v[0]; a1 += (float)v[1]; } else { a0 = (float)v[0]; a1 = (float)v[1]; }
+        }
+        const half2_t s = {(half_t)a0, (half_t)a1};
+        tile[r * 17 + c] = __builtin_bit_cast(uint32_t, s);
+    }
+    __syncthreads();
+    const uint32_t b = base + threadIdx.x;
+    if (b >= M) return;
+#pragma unroll
+    for (int l = 0; l < 16; l++) grad_lm[(size_t)l * M + b] = tile[threadIdx.x * 17 + l];
+}
+
 }  // namespace
 
 extern "C" {
+
+int lae_style_assemble_forward(const void* feats_lm, const float* dirs, uint32_t M, uint32_t Mp, uint32_t degree, void* feat, void* off_in,
+                               uint32_t off_cols, void* stream) {
+    if (Mp == 0) return LAE_OK;
+    if (!feats_lm || !feat || (degree && (!dirs || !off_in))) return LAE_ENULL;
+    if (Mp < M || degree > 4 || (degree && (off_cols % 2u || off_cols > 48u || off_cols < 32u + degree * degree))) return LAE_EINVAL;
+    const uint32_t nb = lae::cdiv(Mp, (uint32_t)SA_BLOCK), ow = off_cols / 2u;
+    hipStream_t s = STREAM(stream);
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(feats_lm);
+    uint32_t *fo = reinterpret_cast<uint32_t*>(feat), *oo = reinterpret_cast<uint32_t*>(off_in);
+    switch (degree) {
+        case 0: k_style_assemble_fwd<0><<<nb, SA_BLOCK, 0, s>>>(f, nullptr, M, Mp, fo, nullptr, 0u); break;
+        case 1: k_style_assemble_fwd<1><<<nb, SA_BLOCK, 0, s>>>(f, dirs, M, Mp, fo, oo, ow); break;
+        case 2: k_style_assemble_fwd<2><<<nb, SA_BLOCK, 0, s>>>(f, dirs, M, Mp, fo, oo, ow); break;
+        case 3: k_style_assemble_fwd<3><<<nb, SA_BLOCK, 0, s>>>(f, dirs, M, Mp, fo, oo, ow); break;
+        default: k_style_assemble_fwd<4><<<nb, SA_BLOCK, 0, s>>>(f, dirs, M, Mp, fo, oo, ow); break;
+    }
+    return lae::check_launch("style_assemble_forward");
+}
+
+int lae_style_assemble_backward(const void* g_feat, const void* g_off, uint32_t M, uint32_t off_cols, void* grad_lm, void* stream) {
+    if (M == 0) return LAE_OK;
+    if (!grad_lm || (!g_feat && !g_off)) return LAE_ENULL;
+    if (g_off && (off_cols % 2u || off_cols < 32u || off_cols > 48u)) return LAE_EINVAL;
+    k_style_assemble_bwd<<<lae::cdiv(M, (uint32_t)SA_BLOCK), SA_BLOCK, 0, STREAM(stream)>>>(
+        reinterpret_cast<const uint32_t*>(g_feat), reinterpret_cast<const uint32_t*>(g_off), M, off_cols / 2u, reinterpret_cast<uint32_t*>(grad_lm));
+    return lae::check_launch("style_assemble_backward");
+}
 
 int lae_palette_forward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask, uint32_t M,
                         void* pred, float* w_hat, void* o_hat, void* stream) {

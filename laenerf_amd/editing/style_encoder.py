@@ -104,6 +104,62 @@ def palette_recompose(w_logits, o_raw, palette, active_mask):
     return _palette_recompose.apply(w_logits, o_raw, palette, int(active_mask))
 
 
+class _style_features(Function):
+    """hash-grid encoder + the input assembly of LAENeRF.forward_train (style_encoder.py:135-146) as ONE autograd node (round 5):
+    the grid kernels' level-major features go straight into `lae_style_assemble_forward`, which writes the weight net's [Mp,32]
+    rows and the offset net's [Mp,48] rows = [features | SH(d) | 0] (before: transpose launch, SH launch, `d / size`, cast, zero
+    fill, cat); the backward adds the two nets' input gradients and transposes them back in one launch and hands them to the
+    binned grid backward (before: two slice copies, an add, a transpose launch).  Same values bit for bit
+    (tests/test_gpu_style.py::test_fused_input_assembly_equals_the_operator_chain)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, x, d, embeddings, enc, bound, degree, off_cols):
+        import numpy as np
+        from ..backend import gridencoder_backend as _grid
+        M = x.shape[0]
+        Mp = (M + 15) // 16 * 16
+        L = enc.num_levels
+        x = x.float().contiguous()
+        table = enc.shadow.table_half(embeddings) if enc.shadow is not None else embeddings.to(torch.half)
+        in_map = (float(bound), float(np.float32(1.0) / np.float32(2 * bound)))
+        S, H = np.log2(enc.per_level_scale), enc.base_resolution
+        feats = torch.empty(L, M, 2, device=x.device, dtype=torch.half)                 # level-major
+        _grid.grid_encode_forward(x, table, enc.offsets, feats, M, 3, 2, L, S, H, None, enc.gridtype_id, enc.align_corners,
+                                  enc.interp_id, blc=False, in_map=in_map, offsets_host=enc.offsets_host)
+        feat = torch.empty(Mp, 32, device=x.device, dtype=torch.half)
+        off_in = torch.empty(Mp, off_cols, device=x.device, dtype=torch.half) if degree else None
+        _backend.style_assemble_forward(feats, d.float().contiguous() if degree else None, M, Mp, degree, feat, off_in, off_cols)
+        ctx.save_for_backward(x, table)
+        ctx.enc, ctx.in_map, ctx.geom, ctx.off_cols = enc, in_map, (M, L, S, H), off_cols
+        return (feat, off_in) if degree else (feat, feat)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_feat, g_off):
+        from ..backend import gridencoder_backend as _grid
+        x, table = ctx.saved_tensors
+        enc = ctx.enc
+        M, L, S, H = ctx.geom
+        if g_feat is None and g_off is None:
+            return (None,) * 7
+        g_feat = None if g_feat is None else g_feat.to(torch.half).contiguous()
+        g_off = None if g_off is None else g_off.to(torch.half).contiguous()
+        off_cols = ctx.off_cols if g_off is not None and g_off.shape[1] != 32 else 32
+        grad_feats = torch.empty(L, M, 2, device=x.device, dtype=torch.half)
+        _backend.style_assemble_backward(g_feat, g_off, M, off_cols, grad_feats)
+        grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
+        flag = enc.shadow.flag_for_backward(M) if enc.shadow is not None else None
+        touched = enc.shadow.touched_for_backward(M) if flag is not None else None
+        if enc.shadow is not None and touched is None:
+            enc.shadow.unreported = enc.shadow.unreported or flag is None
+            enc.shadow.mark_all_touched()
+        _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
+                                   enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, offsets_host=enc.offsets_host,
+                                   nonfinite_flag=flag, touched_lines=touched)
+        return None, None, (None if enc.shadow is not None else grad_table), None, None, None, None
+
+
 class LAENeRF(nn.Module):
     """style_encoder.py:20-90.  `params` needs `.bound` and `.num_palette_bases` (and `style_weight`, which must be 0:
     the VGG style network is out of scope)."""
@@ -138,6 +194,16 @@ class LAENeRF(nn.Module):
     # ---- the two heads as the fused MLP writes them: [M,16] fp16 with padded columns
     def _logits(self, x, d):
         M = x.shape[0]
+        if self._fused_inputs_ok(x, d):
+            deg = self.dir_encoding.degree if self.dir_encoding is not None else 0
+            feat, off_in = _style_features.apply(x, d if deg else None, self.encoder.embeddings, self.encoder, self.bound, deg, self.offset_in_dim)
+            wn, on = self.weight_net, self.offset_net
+            from ..ffmlp.ffmlp import ffmlp_forward
+            w_logits = ffmlp_forward(feat, wn.weights, wn.input_dim, 16, wn.hidden_dim, wn.num_layers, wn.activation, wn.output_activation,
+                                     not self.training, True, wn.shadow if self.ffmlp_shadows else None)
+            o_raw = ffmlp_forward(off_in, on.weights, on.input_dim, 16, on.hidden_dim, on.num_layers, on.activation, on.output_activation,
+                                  not self.training, True, on.shadow if self.ffmlp_shadows else None)
+            return w_logits, o_raw, M
         pad = (16 - M % 16) % 16
         feat = self.encoder(x, bound=self.bound)
         if pad:
@@ -145,7 +211,7 @@ class LAENeRF(nn.Module):
         wn, on = self.weight_net, self.offset_net
         from ..ffmlp.ffmlp import ffmlp_forward
         w_logits = ffmlp_forward(feat, wn.weights, wn.input_dim, 16, wn.hidden_dim, wn.num_layers, wn.activation, wn.output_activation,
-                                 not self.training, feat.requires_grad)
+                                 not self.training, feat.requires_grad, wn.shadow if self.ffmlp_shadows else None)
         cols = [feat]
         if self.dir_encoding is not None:
             enc_d = self.dir_encoding(d).to(feat.dtype)
@@ -157,8 +223,26 @@ class LAENeRF(nn.Module):
             cols.append(feat.new_zeros(feat.shape[0], self.offset_in_dim - width))
         off_in = torch.cat(cols, -1) if len(cols) > 1 else feat
         o_raw = ffmlp_forward(off_in, on.weights, on.input_dim, 16, on.hidden_dim, on.num_layers, on.activation, on.output_activation,
-                              not self.training, off_in.requires_grad)
+                              not self.training, off_in.requires_grad, on.shadow if self.ffmlp_shadows else None)
         return w_logits, o_raw, M
+
+    fused_inputs = True       # False: the operator chain (GridEncoder -> SHEncoder -> cast / pad / cat), e.g. for A/B tests
+    ffmlp_shadows = True      # False: the MLPs' weight gradients go through autograd's fp32 .grad (the pre-round-5 path; A/B tests)
+
+    def _fused_inputs_ok(self, x, d):
+        """the one-node input assembly serves the shipped configuration: half-precision hash grid with 16 levels of 2 features under
+        autocast, SH directions of degree <= 4 (or none), coordinates that need no gradient"""
+        from ..gridencoder import GridEncoder
+        from ..shencoder import SHEncoder
+        enc = self.encoder
+        if not (self.fused_inputs and x.is_cuda and torch.is_autocast_enabled("cuda") and isinstance(enc, GridEncoder)):
+            return False
+        if enc.num_levels != 16 or enc.level_dim != 2 or enc.input_dim != 3 or x.requires_grad or x.dim() != 2:
+            return False
+        if self.dir_encoding is None:
+            return self.offset_in_dim == 32
+        return isinstance(self.dir_encoding, SHEncoder) and self.dir_encoding.degree <= 4 and d is not None and not d.requires_grad \
+            and 32 + self.dir_encoding.degree ** 2 <= self.offset_in_dim <= 48
 
     def forward_train(self, x, d=None):
         """style_encoder.py:135-158 -> (pred_colors [M,3], w_hat [M,n_active], o_hat [M,3])"""

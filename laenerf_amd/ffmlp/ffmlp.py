@@ -13,11 +13,20 @@ class _ffmlp_forward(Function):
     """ffmlp.py:15-83"""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.half)
+    @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False):
+                inference=False, calc_grad_inputs=False, shadow=None):
+        """shadow (MI355X-native, optional): the module's TableShadow once a FusedAdam owns the weights -- the forward then reads
+        the optimizer's fp16 copy (no cast launch per call) and the fused backward ADDS the weight gradient to the optimizer's
+        fp16 accumulator and reports non-finite values itself (no fp16 -> fp32 `.grad`, no fold, no scan: six launches per net
+        and step in the LAENeRF palette step)"""
         B = inputs.shape[0]
-        inputs, weights = inputs.contiguous(), weights.contiguous()
+        ctx.shadow = None
+        if shadow is not None and not inference and torch.is_autocast_enabled("cuda") and \
+                _backend.fused_backward_available(input_dim, hidden_dim, num_layers, activation):
+            ctx.shadow = shadow
+            weights = shadow.table_half(weights)
+        inputs, weights = inputs.to(torch.half).contiguous(), weights.to(torch.half).contiguous()     # (custom_fwd(cast_inputs=half) before round 5)
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if not inference:
             # the fused MI355X backward recomputes the hidden activations from `inputs` (64 B/row) instead of
@@ -45,11 +54,17 @@ class _ffmlp_forward(Function):
             inputs, weights, outputs, forward_buffer = ctx.saved_tensors
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.dims
         grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
-        grad_weights = torch.empty_like(weights)
         backward_buffer = None if ctx.fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
+        if ctx.shadow is not None:                     # straight into the optimizer's accumulator
+            flag = ctx.shadow.flag_for_backward()
+            _backend.ffmlp_backward(grad.to(torch.half), inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
+                                    activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs,
+                                    ctx.shadow.grad_half.view(-1), accumulate=True, nonfinite_flag=flag)
+            return (grad_inputs if calc_grad_inputs else None), None, None, None, None, None, None, None, None, None, None
+        grad_weights = torch.empty_like(weights)
+        _backend.ffmlp_backward(grad.to(torch.half), inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                                 activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
-        return (grad_inputs if calc_grad_inputs else None), grad_weights, None, None, None, None, None, None, None, None
+        return (grad_inputs if calc_grad_inputs else None), grad_weights, None, None, None, None, None, None, None, None, None
 
 
 ffmlp_forward = _ffmlp_forward.apply
@@ -119,7 +134,7 @@ class FFMLP(nn.Module):
         if tail:
             inputs = torch.cat([inputs, inputs.new_zeros(tail, inputs.shape[1])], dim=0)
         out = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
-                            self.activation, self.output_activation, not self.training, inputs.requires_grad)
+                            self.activation, self.output_activation, not self.training, inputs.requires_grad, self.shadow)
         if tail or self.padded_output_dim != self.output_dim:
             out = out[:rows, :self.output_dim]
         return out

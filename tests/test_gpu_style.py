@@ -248,3 +248,47 @@ def test_palette_and_loss_argument_errors():
     assert a.shape == (0, 3) and b.shape == (0, 8)
     (a.float().sum() + b.sum() + c.float().sum()).backward()
     assert torch.equal(p2.grad, torch.zeros_like(p2))
+
+
+@pytest.mark.parametrize("n,dirs", [(4096, True), (5003, True), (2000, False)])
+def test_fused_input_assembly_equals_the_operator_chain(n, dirs):
+    """round 5: `_style_features` (level-major encoder output -> lae_style_assemble_forward -> the two MLPs' input rows; backward:
+    the two input gradients added and transposed back in one launch) against the operator chain it replaces (GridEncoder rows, SHEncoder,
+    cast, zero pad, cat; slice copies, add, transpose) -- and the shadow-aware FFMLP backward (weight gradients ADDED to the optimizer's
+    fp16 accumulators, non-finite values reported by the kernel) against the autograd `.grad` + fold path: logits, prediction, the
+    table gradient and both MLPs' weight gradients BIT for bit, with a FusedAdam attached (the shipped configuration), and the
+    parameters after one optimizer step."""
+    from laenerf_amd.optim import FusedAdam
+    out = []
+    for new_path in (True, False):
+        m, _ = make_model(dir_encoding="sphere_harmonics" if dirs else None)
+        m.train()
+        m.fused_inputs = m.ffmlp_shadows = new_path
+        opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8, init_scale=128.0)
+        g = torch.Generator(device=DEV).manual_seed(n)
+        x = (torch.rand(n, 3, device=DEV, generator=g) - 0.5) * 1.2
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=g), dim=-1) if dirs else None
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert m._fused_inputs_ok(x, d) is new_path
+            w_logits, o_raw, M = m._logits(x, d)
+            pred, w_hat, o_hat = m.forward_train(x, d)
+            loss = ((pred.float() ** 2).mean() + (w_hat ** 2).mean() + (o_hat.float() ** 2).mean()) * opt._scale_view[0]
+        opt.backward(loss)
+        grads = [m.encoder.shadow.grad_half.clone(), m.weight_net.shadow.grad_half.clone(), m.offset_net.shadow.grad_half.clone()]
+        for k, net in ((1, m.weight_net), (2, m.offset_net)):
+            if net.weights.grad is not None:           # the old path leaves the MLP gradients in .grad: fold them like FusedAdam._grad does
+                assert not new_path
+                grads[k] = grads[k] + net.weights.grad.to(torch.half)
+            else:
+                assert new_path
+        opt.step()
+        out.append((w_logits.detach().clone(), o_raw.detach().clone(), pred.detach().clone(), grads,
+                    [p_.detach().clone() for p_ in (m.encoder.embeddings, m.weight_net.weights, m.offset_net.weights, m.color_palette)]))
+    a, b = out
+    assert a[0].shape == b[0].shape == ((n + 15) // 16 * 16, 16) and M == n
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for ga, gb, name in zip(a[3], b[3], ("table", "weight_net", "offset_net")):
+        assert torch.equal(ga, gb), (name, float((ga.float() - gb.float()).abs().max()))
+        assert float(ga.float().abs().sum()) > 0
+    for pa, pb in zip(a[4], b[4]):
+        assert torch.equal(pa, pb)

@@ -1,0 +1,23 @@
+"""A/B of the round-5 style-step glue removal: `bench.style_step` with the one-node input assembly
+(`LAENeRF.fused_inputs`) and the shadow-aware MLP backward (`LAENeRF.ffmlp_shadows`) on and off, three alternating runs each.
+    python tools/style_step_ab.py  >  profiles/r5_style_step_ab.txt"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+cases = [("operator chain, autograd .grad   ", dict(fused_inputs=False, ffmlp_shadows=False)),
+         ("operator chain, shadow-aware MLPs", dict(fused_inputs=False, ffmlp_shadows=True)),
+         ("one-node inputs, autograd .grad  ", dict(fused_inputs=True, ffmlp_shadows=False)),
+         ("one-node inputs, shadow-aware    ", dict(fused_inputs=True, ffmlp_shadows=True))]
+res = {name: [] for name, _ in cases}
+for rep in range(3):
+    for name, sw in cases:
+        res[name].append(bench.style_step(dev, steps=200, switches=sw)["ms_per_step"])
+print("style step (configs[4], 100 000 points, HIP-graph replay, 200 steps per run), ms per step, three alternating runs:")
+for name, _ in cases:
+    print(f"  {name}  " + "  ".join(f"{v:.4f}" for v in res[name]) + f"   best {min(res[name]):.4f}")
