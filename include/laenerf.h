@@ -487,11 +487,15 @@ LAE_API int lae_palette_backward(const void* w_logits, const void* o_raw, const 
 /* The point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996; style_encoder.py:183-205) fused behind the
  * recomposition: loss = MSE(pred, target) + w_uniform * max_j sum_i w_hat[i,j] + w_non_uniform * sum_i (1 - max_j w_hat[i,j])
  * + c_offset * sum o_hat^2 [+ the palette-only regulariser `palet_loss` (style_encoder.py:195-202) over all reg_P bases:
- * w_valid * sum floor(p) p + w_distinct * mean_ij (1 - |p_i - p_j|^2 / max), when reg_palette != NULL / with_reg != 0].
+ * w_valid * sum floor(p) p + w_distinct * mean_ij (1 - |p_i - p_j|^2 / max), when reg_palette != NULL / (flags & LAE_STYLE_WITH_REG)].
  * forward: fin[12] (device) = {loss * scale, loss, mse, uniform, non_uniform, offset terms, arg-max column, scale, regulariser,
  * ...}; scale: device scalar or NULL (1).  backward: gradients of (upstream * fin[0]) with respect to the two MLP outputs and the
- * palette in ONE kernel (no per-point gradient tensors); upstream: device scalar.
+ * palette in ONE kernel (no per-point gradient tensors); upstream: device scalar.  flags: LAE_STYLE_WITH_REG (value 1: what the
+ * `with_reg` argument of abi4 meant) | LAE_STYLE_ACCUMULATE_PALETTE (g_palette += instead of =: the caller hands its persistent
+ * fp32 gradient buffer over and saves autograd's add launch).
  * scratch: max(lae_style_loss_scratch_bytes(M), lae_palette_backward_scratch_bytes(M)). */
+#define LAE_STYLE_WITH_REG 1
+#define LAE_STYLE_ACCUMULATE_PALETTE 2
 LAE_API uint64_t lae_style_loss_scratch_bytes(uint32_t M);
 LAE_API int lae_style_loss_forward(const void* pred, const float* target, const float* w_hat, const void* o_hat, uint32_t M,
                            uint32_t n_active, float w_uniform, float w_non_uniform, float c_offset, const float* scale, float* fin,
@@ -499,7 +503,7 @@ LAE_API int lae_style_loss_forward(const void* pred, const float* target, const 
 LAE_API int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask,
                             uint32_t M, const float* target, const float* fin, const float* upstream, float w_uniform,
                             float w_non_uniform, float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch,
-                            int with_reg, float w_valid, float w_distinct, void* stream);
+                            int flags, float w_valid, float w_distinct, void* stream);
 
 /* ---- LAENeRF input assembly (editing/style_encoder.py:135-146: encoder rows, SH(3) of the directions, cast, pad, cat -- torch ops
  * and separate launches in the reference) ----

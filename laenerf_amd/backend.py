@@ -703,14 +703,15 @@ class _Style:
 
     @staticmethod
     def style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, upstream, lw, g_w_logits, g_o_raw, g_palette,
-                            reg_w=None):
+                            reg_w=None, accumulate=False):
+        """accumulate: g_palette += (LAE_STYLE_ACCUMULATE_PALETTE) -- the caller's persistent fp32 gradient buffer"""
         ts = (w_logits, o_raw, palette, target, fin, upstream, g_w_logits, g_o_raw, g_palette)
         need_cuda(*ts); need_contig(*ts)
         lib = _lib.load()
         ws = _workspace(w_logits.device, max(lib.lae_palette_backward_scratch_bytes(M), lib.lae_style_loss_scratch_bytes(M)))
         check(lib.lae_style_loss_backward(ptr(w_logits), ptr(o_raw), ptr(palette), P, active_mask, M, ptr(target), ptr(fin), ptr(upstream),
                                           float(lw[0]), float(lw[1]), float(lw[2]), ptr(g_w_logits), ptr(g_o_raw), ptr(g_palette), ptr(ws),
-                                          int(reg_w is not None), float(reg_w[0]) if reg_w else 0.0, float(reg_w[1]) if reg_w else 0.0,
+                                          int(reg_w is not None) | (2 if accumulate else 0), float(reg_w[0]) if reg_w else 0.0, float(reg_w[1]) if reg_w else 0.0,
                                           stream()), "style_loss_backward")
 
 

@@ -265,7 +265,7 @@ __device__ __forceinline__ float pal_reg_grad(const PalReg& r, const PalStats& s
 // + gmul[0] * gmul[1] * d(reg) / d(palette) on every entry (gmul = upstream, fin: the scaled upstream gradient of the criterion)
 __global__ __launch_bounds__(64) void k_palette_grad_reduce(const float* __restrict__ slab, uint32_t n_blocks, uint32_t P, uint32_t mask,
                                                             float* __restrict__ g_palette, PalReg reg, const float* __restrict__ upstream,
-                                                            const float* __restrict__ fin) {
+                                                            const float* __restrict__ fin, int accumulate) {
     __shared__ float spal[PAL_MAX * 3];                  // the regulariser's loops read the palette ~P^2 times: from LDS, not from memory
     if (reg.palette && threadIdx.x < reg.P * 3u) spal[threadIdx.x] = reg.palette[threadIdx.x];
     __syncthreads();
@@ -285,7 +285,10 @@ __global__ __launch_bounds__(64) void k_palette_grad_reduce(const float* __restr
         const bool mine = act ? seen == j : j == 0;
         if (mine) {
             const float g = reg.palette ? gmul * pal_reg_grad(reg, st, k, c, (int)threadIdx.x) : 0.0f;
-            if (threadIdx.x == 0) g_palette[k * 3 + c] = (act ? t : 0.0f) + g;
+            if (threadIdx.x == 0) {
+                const float v = (act ? t : 0.0f) + g;
+                g_palette[k * 3 + c] = accumulate ? g_palette[k * 3 + c] + v : v;    // accumulate: the caller's persistent .grad (fp32 add, like AccumulateGrad)
+            }
         }
         seen += act ? 1u : 0u;
     }
@@ -416,14 +419,20 @@ __global__ __launch_bounds__(SA_BLOCK) void k_style_assemble_fwd(const uint32_t*
     }
     __syncthreads();
     const uint32_t nrow = min((uint32_t)SA_BLOCK, Mp > base ? Mp - base : 0u);
-    for (uint32_t e = threadIdx.x; e < nrow * 16u; e += SA_BLOCK) {
-        const uint32_t r = e >> 4, c = e & 15u;
-        feat[(size_t)(base + r) * 16u + c] = tile[r * (MAXW + 1) + c];
+    // fixed trip counts, every LDS read issued before the first store waits for it (a loop of unknown length with a division
+    // by `off_words` inside was 40 % of this kernel)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t e = k * SA_BLOCK + threadIdx.x, r = e >> 4, c = e & 15u;
+        if (r < nrow) feat[(size_t)(base + r) * 16u + c] = tile[r * (MAXW + 1) + c];
     }
     if constexpr (DEG > 0) {
-        for (uint32_t e = threadIdx.x; e < nrow * off_words; e += SA_BLOCK) {
-            const uint32_t r = e / off_words, c = e - r * off_words;
-            off_in[(size_t)(base + r) * off_words + c] = tile[r * (MAXW + 1) + c];
+        const uint32_t inv = (uint32_t)((0x100000000ull + off_words - 1u) / off_words);      // e / off_words == umulhi(e, inv) for e < 2^16
+        const uint32_t total = nrow * off_words;
+#pragma unroll
+        for (int k = 0; k < MAXW; k++) {
+            const uint32_t e = k * SA_BLOCK + threadIdx.x, r = __umulhi(e, inv), c = e - r * off_words;
+            if (e < total) off_in[(size_t)(base + r) * off_words + c] = tile[r * (MAXW + 1) + c];
         }
     }
 }
@@ -433,17 +442,24 @@ __global__ __launch_bounds__(SA_BLOCK) void k_style_assemble_bwd(const uint32_t*
     __shared__ uint32_t tile[SA_BLOCK * 17];
     const uint32_t base = blockIdx.x * SA_BLOCK;
     const uint32_t nrow = min((uint32_t)SA_BLOCK, M - base);
-    for (uint32_t e = threadIdx.x; e < nrow * 16u; e += SA_BLOCK) {
-        const uint32_t r = e >> 4, c = e & 15u;
-        float a0 = 0.f, a1 = 0.f;
-        bool any = false;
-        if (g_feat) { const half2_t v = __builtin_bit_cast(half2_t, g_feat[(size_t)(base + r) * 16u + c]); a0 = (float)v[0]; a1 = (float)v[1]; any = true; }
-        if (g_off) {
-            const half2_t v = __builtin_bit_cast(half2_t, g_off[(size_t)(base + r) * off_words + c]);
-            if (any) { a0 += (float)v[0]; a1 += (float)v[1]; } else { a0 = (float)v[0]; a1 = (float)v[1]; }
-        }
-        const half2_t s = {(half_t)a0, (half_t)a1};
-        tile[r * 17 + c] = __builtin_bit_cast(uint32_t, s);
+    // 16 words per thread, all loads issued before the first use (a loop of unknown trip count serialises the load latencies:
+    // 14.0 -> see profiles/r5c_style_kernel_stats.csv)
+    uint32_t vf[16], vo[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t e = k * SA_BLOCK + threadIdx.x, r = e >> 4, c = e & 15u;
+        const bool in = r < nrow;
+        vf[k] = (g_feat && in) ? g_feat[(size_t)(base + r) * 16u + c] : 0u;
+        vo[k] = (g_off && in) ? g_off[(size_t)(base + r) * off_words + c] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t e = k * SA_BLOCK + threadIdx.x, r = e >> 4, c = e & 15u;
+        const half2_t a = __builtin_bit_cast(half2_t, vf[k]), b2 = __builtin_bit_cast(half2_t, vo[k]);
+        half2_t s2;
+        if (g_feat && g_off) s2 = half2_t{(half_t)((float)a[0] + (float)b2[0]), (half_t)((float)a[1] + (float)b2[1])};
+        else s2 = g_feat ? a : b2;
+        tile[r * 17 + c] = __builtin_bit_cast(uint32_t, s2);
     }
     __syncthreads();
     const uint32_t b = base + threadIdx.x;
@@ -510,7 +526,7 @@ int lae_palette_backward(const void* w_logits, const void* o_raw, const float* p
     k_palette_bwd<false><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M,
                                                   (const half_t*)g_pred, g_w, (const half_t*)g_o, (half_t*)g_w_logits, (half_t*)g_o_raw,
                                                   (float*)scratch, LossSrc{});
-    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette, PalReg{nullptr, 0, 0.f, 0.f}, nullptr, nullptr);
+    k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette, PalReg{nullptr, 0, 0.f, 0.f}, nullptr, nullptr, 0);
     return lae::check_launch("palette_backward");
 }
 
@@ -531,7 +547,7 @@ int lae_style_loss_forward(const void* pred, const float* target, const float* w
 
 int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float* palette, uint32_t P, uint32_t active_mask, uint32_t M,
                             const float* target, const float* fin, const float* upstream, float w_uniform, float w_non_uniform,
-                            float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch, int with_reg, float w_valid,
+                            float c_offset, void* g_w_logits, void* g_o_raw, float* g_palette, void* scratch, int flags, float w_valid,
                             float w_distinct, void* stream) {
     if (!w_logits || !o_raw || !palette || !target || !fin || !upstream || !g_w_logits || !g_o_raw || !g_palette || !scratch) return LAE_ENULL;
     if (M == 0) return LAE_EINVAL;
@@ -543,7 +559,8 @@ int lae_style_loss_backward(const void* w_logits, const void* o_raw, const float
     k_palette_bwd<true><<<nb, PAL_BLOCK, 0, s>>>((const half_t*)w_logits, (const half_t*)o_raw, palette, P, active_mask, M, nullptr, nullptr,
                                                  nullptr, (half_t*)g_w_logits, (half_t*)g_o_raw, (float*)scratch, ls);
     k_palette_grad_reduce<<<PAL_MAX * 3, 64, 0, s>>>((const float*)scratch, nb, P, active_mask, g_palette,
-                                                     PalReg{with_reg ? palette : nullptr, P, w_valid, w_distinct}, upstream, fin);
+                                                     PalReg{(flags & LAE_STYLE_WITH_REG) ? palette : nullptr, P, w_valid, w_distinct}, upstream, fin,
+                                                     (flags & LAE_STYLE_ACCUMULATE_PALETTE) ? 1 : 0);
     return lae::check_launch("style_loss_backward");
 }
 

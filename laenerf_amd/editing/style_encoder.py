@@ -66,6 +66,7 @@ class _palette_point_loss(Function):
     def forward(ctx, w_logits, o_raw, palette, active_mask, target, lw, scale, reg_w=None):
         M = w_logits.shape[0]
         w_logits, o_raw = w_logits.half().contiguous(), o_raw.half().contiguous()
+        palette_in = palette
         palette, target = palette.float().contiguous(), target.float().contiguous()
         P = palette.shape[0]
         n_active = bin(active_mask & ((1 << P) - 1)).count("1")
@@ -80,6 +81,9 @@ class _palette_point_loss(Function):
                                     reg_palette=palette if reg_w is not None else None, reg_w=reg_w or (0.0, 0.0))
         ctx.save_for_backward(w_logits, o_raw, palette, target, fin)
         ctx.meta = (P, active_mask, M, lw, reg_w)
+        # a palette parameter whose fp32 .grad is a FusedAdam's persistent buffer takes its gradient by an add inside the
+        # reduction launch (round 5) instead of through autograd's AccumulateGrad (one more launch on the step's critical path)
+        ctx.palette_param = palette_in if getattr(palette_in, "_lae_persistent_grad", False) and palette_in is palette else None
         ctx.mark_non_differentiable(pred, w_hat, o_hat, fin)
         ctx.set_materialize_grads(False)                 # no zero-filled gradients for the auxiliary outputs
         return fin[0], pred, w_hat, o_hat, fin
@@ -92,10 +96,13 @@ class _palette_point_loss(Function):
         w_logits, o_raw, palette, target, fin = ctx.saved_tensors
         P, active_mask, M, lw, reg_w = ctx.meta
         g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)
-        g_pal = torch.empty_like(palette)
+        owner = ctx.palette_param
+        direct = owner is not None and owner.grad is not None and owner.grad.dtype == torch.float32 and owner.grad.is_contiguous() \
+            and owner.grad.shape == palette.shape
+        g_pal = owner.grad if direct else torch.empty_like(palette)
         _backend.style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, g_loss.float().reshape(1).contiguous(), lw,
-                                     g_wl, g_ol, g_pal, reg_w=reg_w)
-        return g_wl, g_ol, g_pal, None, None, None, None, None
+                                     g_wl, g_ol, g_pal, reg_w=reg_w, accumulate=direct)
+        return g_wl, g_ol, (None if direct else g_pal), None, None, None, None, None
 
 
 def palette_recompose(w_logits, o_raw, palette, active_mask):

@@ -51,6 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
                     shadow = owner.attach_shadow()         # fp16 copy + fp16 gradient accumulator next to the parameter
                 else:
                     p.grad = torch.zeros_like(p)           # persistent fp32 gradient (stable address for graph replay)
+                    p._lae_persistent_grad = True          # fused criterion nodes may add into it themselves (style_encoder._palette_point_loss)
                 m, v = torch.zeros_like(p), torch.zeros_like(p)
                 self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}      # torch.optim.Adam's layout
                 self.items.append((p, m, v, shadow, gi))

@@ -292,3 +292,34 @@ def test_fused_input_assembly_equals_the_operator_chain(n, dirs):
         assert float(ga.float().abs().sum()) > 0
     for pa, pb in zip(a[4], b[4]):
         assert torch.equal(pa, pb)
+
+
+def test_palette_gradient_added_inside_the_criterion_equals_autograd_accumulation():
+    """round 5: with a FusedAdam attached the fused criterion adds the palette gradient into the optimizer's persistent fp32 `.grad`
+    inside its reduction launch (LAE_STYLE_ACCUMULATE_PALETTE) instead of handing it to autograd's AccumulateGrad: same values bit
+    for bit after one and after two backward passes (fp32 adds in the same order), and the buffer keeps its address."""
+    from laenerf_amd.optim import FusedAdam
+    got = []
+    for direct in (True, False):
+        m, params = make_model()
+        m.train()
+        opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8, init_scale=64.0)
+        assert m.color_palette._lae_persistent_grad
+        if not direct:
+            del m.color_palette._lae_persistent_grad
+        addr = m.color_palette.grad.data_ptr()
+        g = torch.Generator(device=DEV).manual_seed(3)
+        x = (torch.rand(4096, 3, device=DEV, generator=g) - 0.5) * 1.2
+        d = torch.nn.functional.normalize(torch.randn(4096, 3, device=DEV, generator=g), dim=-1)
+        target = torch.rand(4096, 3, device=DEV, generator=g)
+        snaps = []
+        for _ in range(2):
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, *_rest = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True)
+            opt.backward(loss)
+            assert m.color_palette.grad.data_ptr() == addr
+            snaps.append(m.color_palette.grad.clone())
+        got.append(snaps)
+    for a, b in zip(*got):
+        assert torch.equal(a, b) and float(a.abs().sum()) > 0
+    assert not torch.equal(got[0][0], got[0][1])
