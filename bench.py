@@ -484,11 +484,14 @@ def grid_update(dev):
             "note": "not inside `value`: the reference runs it between train steps (nerf/utils.py:1465)"}
 
 
-def style_step(dev, P=100000, steps=30, switches=None):
+def style_step(dev, P=100000, steps=30, switches=None, G=8, pipeline=True):
     """configs[4]: one optimisation step of LAENeRF's palette network (train_LAENeRF_step, nerf/utils.py:980-1043, point-wise
     losses) on P region-masked points: hash-grid encode -> weight / offset MLPs -> palette recomposition -> MSE + weight +
     offset + palette losses -> backward -> Adam(lr 1e-3) under a GradScaler.  Synthetic x_term in a 0.3-radius ball
-    (SURVEY.md 8d).  Captured once into a HIP graph and replayed, like the train step."""
+    (SURVEY.md 8d), 4 G point sets ("views": the reference's loader hands the step one view's points, editing/edit_dataset.py:
+    236-260, known before the step starts).  `one_graph_per_step_ms`: one captured graph per step, replayed (rounds 2-4's figure);
+    `ms_per_step` (round 5): the headline's grouped two-stream scheme -- the counting half of the hash-grid backward of the views of
+    group k+2 (positions only, LAENeRF.plan_backward) replayed on a side stream beside the steps of group k."""
     from types import SimpleNamespace
     from laenerf_amd.editing import LAENeRF
     from laenerf_amd.optim import FusedAdam
@@ -501,36 +504,55 @@ def style_step(dev, P=100000, steps=30, switches=None):
         assert hasattr(m, k), k
         setattr(m, k, val)
     opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8)
-    v = torch.randn(P, 3, device=dev)
-    x = v / v.norm(dim=-1, keepdim=True) * 0.3 * torch.rand(P, 1, device=dev) ** (1 / 3)
-    d = torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1)
-    target = torch.rand(P, 3, device=dev)
+    views = []
+    for _ in range(4 * G):
+        v = torch.randn(P, 3, device=dev)
+        views.append((v / v.norm(dim=-1, keepdim=True) * 0.3 * torch.rand(P, 1, device=dev) ** (1 / 3),
+                      torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1), torch.rand(P, 3, device=dev)))
 
-    def body():
+    def body(view, plan=None):
+        x, d, target = view
         with torch.autocast("cuda", dtype=torch.float16):
             # recomposition + MSE + weight + offset + palette losses as one node (palette.hip)
-            loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True)
+            loss, pred, w, o = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True, plan=plan)
         opt.backward(loss)
         opt.step()
+        return P
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3):
-            body()
+        for i in range(3):
+            body(views[i], m.plan_backward(views[i][0]) if i else None)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        body()
+        body(views[0])
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         g.replay()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(dt * 1e3, 4), "points": P, "Mpoints_per_s": round(P / dt / 1e6, 2),
-            "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam, HIP-graph replay"}
+    dt_one = (time.perf_counter() - t0) / steps
+    out = {"points": P, "one_graph_per_step_ms": round(dt_one * 1e3, 4)}
+    dt = dt_one
+    if pipeline and m.plan_backward(views[0][0]) is not None:
+        step, _ = grouped_pipeline(None, opt, views, G, ahead_fn=lambda view: m.plan_backward(view[0]), step_fn=body,
+                                   side_priority=-1)
+        n = (steps + G - 1) // G * G
+        for i in range(4 * G):
+            step(i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(n):
+            step(4 * G + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["steps_per_graph_replay"] = G
+    out.update({"ms_per_step": round(dt * 1e3, 4), "Mpoints_per_s": round(P / dt / 1e6, 2),
+                "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam; HIP-graph replay, the counting "
+                        "half of the grid backward of the views two groups ahead on a side stream (positions only), like the headline's march"})
+    return out
 
 
 def edit_extract(dev, n_views=8, batch_views=2):
@@ -591,32 +613,41 @@ def edit_extract(dev, n_views=8, batch_views=2):
                     "(seed 1234, density scale 30), bound 2, synthetic occupancy, results stay on the device"}
 
 
-def grouped_pipeline(r, opt, batches, G, groups_ahead=2):
+def grouped_pipeline(r, opt, batches, G, groups_ahead=2, ahead_fn=None, step_fn=None, side_priority=0):
     """the headline's execution scheme for any renderer / optimizer pair (fused criterion): per group of G resident ray batches
     two captured HIP graphs -- G x {ray/box, march, counting half of the grid backward} and G x {encoder, head, compositing +
     criterion, backward, Adam} -- the first replayed on a side stream `groups_ahead` groups before the second (it reads no
-    weight).  Returns step(i) (i = consecutive step numbers; a replay is issued at every G-th) and the samples per batch."""
+    weight).  Returns step(i) (i = consecutive step numbers; a replay is issued at every G-th) and the samples per batch.
+    ahead_fn(batch) -> state / step_fn(batch, state) -> units: another pair of halves with the same property (the first reads no
+    weight), e.g. the LAENeRF step's counting half of the grid backward and the step itself (style_step)."""
     n_batches = len(batches)
     assert n_batches % G == 0 and n_batches // G >= 2 * groups_ahead
-    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    side_priority = int(os.environ.get("LAE_BENCH_SIDE_PRIO", side_priority))                # A/B switch
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream(priority=side_priority)
     P = n_batches // G
+    if ahead_fn is None:
+        def ahead_fn(batch):
+            return r.march_train(batch[0], batch[1], perturb=True, max_steps=1024, plan_backward=True)
+
+        def step_fn(batch, state):
+            with torch.autocast("cuda", dtype=torch.float16):
+                res = r.shade_train(state, bg_color=1, gt=batch[2], scaler=opt)
+            opt.backward(res["loss"])
+            opt.step()
+            return res["n_samples"]
     marched, n_samples, g_side, g_main = [], [], [], []
     side.wait_stream(main)
     for p_ in range(P):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=g_side[0].pool() if g_side else None):
             for b in range(p_ * G, (p_ + 1) * G):
-                marched.append(r.march_train(batches[b][0], batches[b][1], perturb=True, max_steps=1024, plan_backward=True))
+                marched.append(ahead_fn(batches[b]))
         g_side.append(g)
     for p_ in range(P):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=g_main[0].pool() if g_main else None):
             for b in range(p_ * G, (p_ + 1) * G):
-                with torch.autocast("cuda", dtype=torch.float16):
-                    res = r.shade_train(marched[b], bg_color=1, gt=batches[b][2], scaler=opt)
-                opt.backward(res["loss"])
-                opt.step()
-                n_samples.append(res["n_samples"])
+                n_samples.append(step_fn(batches[b], marched[b]))
         g_main.append(g)
     ev_side = [torch.cuda.Event() for _ in range(P)]
     ev_main = [torch.cuda.Event() for _ in range(P)]

@@ -121,7 +121,7 @@ class _style_features(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda")
-    def forward(ctx, x, d, embeddings, enc, bound, degree, off_cols):
+    def forward(ctx, x, d, embeddings, enc, bound, degree, off_cols, plan=None):
         import numpy as np
         from ..backend import gridencoder_backend as _grid
         M = x.shape[0]
@@ -138,7 +138,7 @@ class _style_features(Function):
         off_in = torch.empty(Mp, off_cols, device=x.device, dtype=torch.half) if degree else None
         _backend.style_assemble_forward(feats, d.float().contiguous() if degree else None, M, Mp, degree, feat, off_in, off_cols)
         ctx.save_for_backward(x, table)
-        ctx.enc, ctx.in_map, ctx.geom, ctx.off_cols = enc, in_map, (M, L, S, H), off_cols
+        ctx.enc, ctx.in_map, ctx.geom, ctx.off_cols, ctx.plan = enc, in_map, (M, L, S, H), off_cols, plan
         return (feat, off_in) if degree else (feat, feat)
 
     @staticmethod
@@ -149,7 +149,7 @@ class _style_features(Function):
         enc = ctx.enc
         M, L, S, H = ctx.geom
         if g_feat is None and g_off is None:
-            return (None,) * 7
+            return (None,) * 8
         g_feat = None if g_feat is None else g_feat.to(torch.half).contiguous()
         g_off = None if g_off is None else g_off.to(torch.half).contiguous()
         off_cols = ctx.off_cols if g_off is not None and g_off.shape[1] != 32 else 32
@@ -158,13 +158,15 @@ class _style_features(Function):
         grad_table = enc.shadow.grad_half if enc.shadow is not None else torch.zeros_like(table)
         flag = enc.shadow.flag_for_backward(M) if enc.shadow is not None else None
         touched = enc.shadow.touched_for_backward(M) if flag is not None else None
+        if ctx.plan is not None and touched is not None and not getattr(ctx.plan, "marks_touched", False):
+            touched = None                                 # a plan made without the bitmap: nothing was marked
         if enc.shadow is not None and touched is None:
             enc.shadow.unreported = enc.shadow.unreported or flag is None
             enc.shadow.mark_all_touched()
         _grid.grid_encode_backward(grad_feats, x, table, enc.offsets, grad_table, M, 3, 2, L, S, H, None, None, enc.gridtype_id,
                                    enc.align_corners, enc.interp_id, blc=False, in_map=ctx.in_map, offsets_host=enc.offsets_host,
-                                   nonfinite_flag=flag, touched_lines=touched)
-        return None, None, (None if enc.shadow is not None else grad_table), None, None, None, None
+                                   plan=ctx.plan, nonfinite_flag=flag, touched_lines=touched)
+        return None, None, (None if enc.shadow is not None else grad_table), None, None, None, None, None
 
 
 class LAENeRF(nn.Module):
@@ -199,11 +201,29 @@ class LAENeRF(nn.Module):
         self.weight_net = FFMLP(self.in_dim, self.num_color_bases, hidden_dim, num_layers - 1)
 
     # ---- the two heads as the fused MLP writes them: [M,16] fp16 with padded columns
-    def _logits(self, x, d):
+    def plan_backward(self, x):
+        """counting half of the hash-grid backward for the points x [M,3] (positions only: it can run ahead of the step, on
+        another stream -- the points of a view are known before its step starts); hand the result to forward_train(x, d, plan=...) /
+        forward_train_loss(..., plan=...).  None when the one-node input path does not apply (the step then plans for itself)."""
+        from ..field import field_backward_plan
+        if not (self.fused_inputs and x.is_cuda and x.dim() == 2 and self._encoder_fits()):
+            return None
+        return field_backward_plan(x, self.encoder, self.bound)
+
+    def _encoder_fits(self):
+        from ..gridencoder import GridEncoder
+        enc = self.encoder
+        return isinstance(enc, GridEncoder) and enc.num_levels == 16 and enc.level_dim == 2 and enc.input_dim == 3
+
+    def _logits(self, x, d, plan=None):
         M = x.shape[0]
-        if self._fused_inputs_ok(x, d):
+        fused = self._fused_inputs_ok(x, d)
+        if plan is not None and not fused:
+            raise RuntimeError("LAENeRF: a backward plan needs the one-node input path (half-precision hash grid under autocast)")
+        if fused:
             deg = self.dir_encoding.degree if self.dir_encoding is not None else 0
-            feat, off_in = _style_features.apply(x, d if deg else None, self.encoder.embeddings, self.encoder, self.bound, deg, self.offset_in_dim)
+            feat, off_in = _style_features.apply(x, d if deg else None, self.encoder.embeddings, self.encoder, self.bound, deg, self.offset_in_dim,
+                                                 plan)
             wn, on = self.weight_net, self.offset_net
             from ..ffmlp.ffmlp import ffmlp_forward
             w_logits = ffmlp_forward(feat, wn.weights, wn.input_dim, 16, wn.hidden_dim, wn.num_layers, wn.activation, wn.output_activation,
@@ -242,20 +262,20 @@ class LAENeRF(nn.Module):
         from ..gridencoder import GridEncoder
         from ..shencoder import SHEncoder
         enc = self.encoder
-        if not (self.fused_inputs and x.is_cuda and torch.is_autocast_enabled("cuda") and isinstance(enc, GridEncoder)):
+        if not (self.fused_inputs and x.is_cuda and torch.is_autocast_enabled("cuda") and self._encoder_fits()):
             return False
-        if enc.num_levels != 16 or enc.level_dim != 2 or enc.input_dim != 3 or x.requires_grad or x.dim() != 2:
+        if x.requires_grad or x.dim() != 2:
             return False
         if self.dir_encoding is None:
             return self.offset_in_dim == 32
         return isinstance(self.dir_encoding, SHEncoder) and self.dir_encoding.degree <= 4 and d is not None and not d.requires_grad \
             and 32 + self.dir_encoding.degree ** 2 <= self.offset_in_dim <= 48
 
-    def forward_train(self, x, d=None):
-        """style_encoder.py:135-158 -> (pred_colors [M,3], w_hat [M,n_active], o_hat [M,3])"""
+    def forward_train(self, x, d=None, plan=None):
+        """style_encoder.py:135-158 -> (pred_colors [M,3], w_hat [M,n_active], o_hat [M,3]); plan: `plan_backward(x)` (MI355X extension)"""
         if self.dir_encoding is not None:
             assert d is not None
-        w_logits, o_raw, M = self._logits(x, d)
+        w_logits, o_raw, M = self._logits(x, d, plan)
         pred, w_hat, o_hat = palette_recompose(w_logits, o_raw, self.color_palette, self._active_mask)
         return pred[:M], w_hat[:M], o_hat[:M]
 
@@ -263,7 +283,7 @@ class LAENeRF(nn.Module):
         """style_encoder.py:111-133"""
         return self.forward_train(x, d)[0]
 
-    def forward_train_loss(self, x, d, target, params, scaler=None, with_palet_loss=False):
+    def forward_train_loss(self, x, d, target, params, scaler=None, with_palet_loss=False, plan=None):
         """MI355X-native: forward_train + the point-wise losses of train_LAENeRF_step (nerf/utils.py:990-996) in one node:
         loss = MSE(pred, target) + weights_loss(w_hat) + offset_loss(o_hat) [+ palet_loss(params) with with_palet_loss=True: the
         palette-only term and its gradient then ride in the criterion's own launches instead of ~40 tiny torch kernels per step],
@@ -271,7 +291,7 @@ class LAENeRF(nn.Module):
         -> (loss, pred [M,3], w_hat, o_hat); loss.terms = [scaled loss, loss, mse, uniform, non-uniform, offset, jmax, scale, palet, ...]"""
         if self.dir_encoding is not None:
             assert d is not None
-        w_logits, o_raw, M = self._logits(x, d)
+        w_logits, o_raw, M = self._logits(x, d, plan)
         if w_logits.shape[0] != M:
             raise RuntimeError("forward_train_loss: the number of points must be a multiple of 16")
         scale = None

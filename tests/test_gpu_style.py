@@ -323,3 +323,43 @@ def test_palette_gradient_added_inside_the_criterion_equals_autograd_accumulatio
     for a, b in zip(*got):
         assert torch.equal(a, b) and float(a.abs().sum()) > 0
     assert not torch.equal(got[0][0], got[0][1])
+
+
+@pytest.mark.parametrize("n", [4096, 5008])
+def test_step_with_a_backward_plan_made_ahead_equals_the_step_that_plans_for_itself(n):
+    """round 5: LAENeRF.plan_backward(x) (counting half of the hash-grid backward, positions only) made on ANOTHER stream before
+    the step, handed to forward_train_loss(plan=...): table gradient, touched-lines bitmap and every parameter after the optimizer
+    step bit for bit equal to the step without a plan; a plan without the one-node input path is refused."""
+    from laenerf_amd.optim import FusedAdam
+    out = []
+    for planned in (True, False):
+        m, params = make_model()
+        m.train()
+        opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8, init_scale=128.0)
+        g = torch.Generator(device=DEV).manual_seed(n)
+        x = (torch.rand(n, 3, device=DEV, generator=g) - 0.5) * 1.2
+        d = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV, generator=g), dim=-1)
+        target = torch.rand(n, 3, device=DEV, generator=g)
+        plan = None
+        if planned:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                plan = m.plan_backward(x)
+            assert plan is not None and plan.marks_touched
+            torch.cuda.current_stream().wait_stream(side)
+            first_plan = plan
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, *_rest = m.forward_train_loss(x, d, target, params, opt, with_palet_loss=True, plan=plan)
+        opt.backward(loss)
+        grad = m.encoder.shadow.grad_half.clone()
+        touched = m.encoder.shadow.touched_lines.clone()
+        opt.step()
+        out.append([loss.detach().clone(), grad, touched] + [p_.detach().clone() for p_ in m.parameters()])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert float(out[0][1].float().abs().sum()) > 0
+    m.fused_inputs = False
+    assert m.plan_backward(x) is None
+    with torch.autocast("cuda", dtype=torch.float16), pytest.raises(RuntimeError):
+        m.forward_train_loss(x, d, target, params, opt, plan=first_plan)

@@ -17,7 +17,13 @@ cases = [("operator chain, autograd .grad   ", dict(fused_inputs=False, ffmlp_sh
 res = {name: [] for name, _ in cases}
 for rep in range(3):
     for name, sw in cases:
-        res[name].append(bench.style_step(dev, steps=200, switches=sw)["ms_per_step"])
-print("style step (configs[4], 100 000 points, HIP-graph replay, 200 steps per run), ms per step, three alternating runs:")
+        r = bench.style_step(dev, steps=200, switches=sw)
+        res[name].append((r["one_graph_per_step_ms"], r["ms_per_step"]))
+print("style step (configs[4], 100 000 points, HIP-graph replay, 200 steps per run), ms per step, three alternating runs")
+print("one graph per step:")
 for name, _ in cases:
-    print(f"  {name}  " + "  ".join(f"{v:.4f}" for v in res[name]) + f"   best {min(res[name]):.4f}")
+    print(f"  {name}  " + "  ".join(f"{v[0]:.4f}" for v in res[name]) + f"   best {min(v[0] for v in res[name]):.4f}")
+print("grouped two-stream scheme (counting half of the grid backward two groups ahead on a side stream; needs the one-node inputs):")
+for name, sw in cases:
+    if sw["fused_inputs"]:
+        print(f"  {name}  " + "  ".join(f"{v[1]:.4f}" for v in res[name]) + f"   best {min(v[1] for v in res[name]):.4f}")
