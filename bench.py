@@ -25,6 +25,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from laenerf_amd.streams import PROBES as SIDE_STREAM_PROBES, concurrent_side_stream      # noqa: E402  (no GPU call at import; why: its docstring)
 
 GRID_FWD_BYTES_FP16 = 588        # SURVEY.md 8d / BASELINE.md 4: 12 + 16*8*2*2 + 16*2*2 bytes per sample
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -537,18 +538,24 @@ def style_step(dev, P=100000, steps=30, switches=None, G=8, pipeline=True):
     dt_one = (time.perf_counter() - t0) / steps
     out = {"points": P, "one_graph_per_step_ms": round(dt_one * 1e3, 4)}
     dt = dt_one
-    if pipeline and m.plan_backward(views[0][0]) is not None:
-        step, _ = grouped_pipeline(None, opt, views, G, ahead_fn=lambda view: m.plan_backward(view[0]), step_fn=body,
-                                   side_priority=-1)
+    if pipeline and m.ffmlp_shadows and m.plan_backward(views[0][0]) is not None:      # (A/B switches: tools/style_step_ab.py says why)
+        step, _ = grouped_pipeline(None, opt, views, G, ahead_fn=lambda view: m.plan_backward(view[0]), step_fn=body)
         n = (steps + G - 1) // G * G
         for i in range(4 * G):
             step(i)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for i in range(n):
-            step(4 * G + i)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        wins = []
+        step.host.update(s=0.0, groups=0)
+        for w in range(3):                                     # three windows, the median counts: the first pipelined window of a process
+            torch.cuda.synchronize(); t0 = time.perf_counter()   # that has replayed other graphs before can carry a one-off ~150 ms stall
+            for i in range(n):
+                step(4 * G + w * n + i)
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / n)
+        dt = sorted(wins)[1]
         out["steps_per_graph_replay"] = G
+        out["windows_ms"] = [round(v * 1e3, 4) for v in wins]
+        out["side_stream"] = SIDE_STREAM_PROBES[-1] if SIDE_STREAM_PROBES else None
+        out["host_issue_ms_per_step"] = round(step.host["s"] / max(step.host["groups"], 1) / G * 1e3, 4)
     out.update({"ms_per_step": round(dt * 1e3, 4), "Mpoints_per_s": round(P / dt / 1e6, 2),
                 "note": "LAENeRF palette network: encode + 2 MLPs + palette recomposition, fwd + bwd + Adam; HIP-graph replay, the counting "
                         "half of the grid backward of the views two groups ahead on a side stream (positions only), like the headline's march"})
@@ -623,7 +630,8 @@ def grouped_pipeline(r, opt, batches, G, groups_ahead=2, ahead_fn=None, step_fn=
     n_batches = len(batches)
     assert n_batches % G == 0 and n_batches // G >= 2 * groups_ahead
     side_priority = int(os.environ.get("LAE_BENCH_SIDE_PRIO", side_priority))                # A/B switch
-    main, side = torch.cuda.current_stream(), torch.cuda.Stream(priority=side_priority)
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream(priority=side_priority) if side_priority else concurrent_side_stream()[0]
     P = n_batches // G
     if ahead_fn is None:
         def ahead_fn(batch):
@@ -664,6 +672,7 @@ def grouped_pipeline(r, opt, batches, G, groups_ahead=2, ahead_fn=None, step_fn=
         if b % G:
             return n_samples[b]
         p_ = b // G
+        t_host = time.perf_counter()
         if state["primed"] != p_:
             side.wait_stream(main)
             for a in range(A):
@@ -676,7 +685,10 @@ def grouped_pipeline(r, opt, batches, G, groups_ahead=2, ahead_fn=None, step_fn=
         side.wait_event(ev_main[nxt]) if i >= G else None
         launch_side(nxt)
         state["primed"] = (p_ + 1) % P
+        host["s"] += time.perf_counter() - t_host            # what the host spends issuing one group (two graph launches + events):
+        host["groups"] += 1                                  # above G x the step's GPU time the scheme is host-bound
         return n_samples[b]
+    host = step.host = {"s": 0.0, "groups": 0}
     for p_ in range(P):
         ev_main[p_].record(main)
     return step, n_samples
@@ -996,7 +1008,7 @@ def main():
         raise SystemExit("--dp needs the FusedAdam path")
     pipelined = not args.no_graph and not args.no_pipeline and not args.torch_optimizer and not args.no_optimizer and not args.dp
     if not args.no_graph:
-        side = torch.cuda.Stream()
+        side, side_probe = concurrent_side_stream() if pipelined else (torch.cuda.Stream(), None)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations, workspaces)
             for _ in range(3):
@@ -1275,6 +1287,7 @@ def main():
                         "max": round(max(windows) / args.steps * 1e3, 4), "first": round(first_window / args.steps * 1e3, 4),
                         "note": "5 consecutive windows of exactly K steps, each between barriers + synchronize, max over ranks; "
                                 "`value` / `ms_per_step` are the MEDIAN window"},
+            "side_stream": side_probe if not args.no_graph else None,        # concurrent_side_stream(): does the side stream run beside the main one?
             "operator_ms_per_step": {k: round(v["ms"] / n_diag, 4) for k, v in sorted(timing_all.items())},
         }
         if sharded is not None:
