@@ -278,8 +278,14 @@ def eval_frame(dev, H=800, W=800):
             "iterations": res["stats"]["iterations"], "samples_through_network": res["stats"]["rows"],
             "operator_loop_ms": round(t_op * 1e3, 2),
             "max_abs_image_diff_vs_operator_loop": float((res["image"] - res_op["image"]).abs().max()),
+            "side_stream": _frame_probe(),                       # which side-stream candidate the frame loop chose, and the timed hand-overs
             "note": "800x800 inference render of the fixed eval model (seed 4321, default init: independent of --steps), T_thresh 1e-4, "
                     "device-resident loop (lookahead marcher on a side stream)"}
+
+
+def _frame_probe():
+    from laenerf_amd.backend import raymarching_backend
+    return raymarching_backend.render_frame_probe()
 
 
 def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=False):

@@ -252,6 +252,13 @@ LAE_API int lae_render_frame_set_overlap(int on);
 /* how the most recent frame ran: 1 = lookahead on the side stream, 0 = in line (switched off, probed as not concurrent, or
  * degraded after a time-out); before the first frame: the configured mode */
 LAE_API int lae_render_frame_mode(void);
+/* Which side stream: with the first frame of a caller stream the library times 16 hand-overs caller -> side -> caller through the
+ * loop's own store / poll kernels on its highest-priority side stream (or the class LAE_FRAME_SIDE_PRIO names) and, when that
+ * stream does not run beside the caller's or is slow (~50 instead of ~11 us per hand-over: which hardware queue picks a dispatch
+ * up promptly depends on the streams the process already uses), on up to four streams of the caller's class created
+ * on demand; the first prompt one is used, else the fastest seen.  us[0..n): the times of the most recent probe in microseconds
+ * (candidate 0 first; < 0: not probed / not concurrent); returns the candidate in use, -1 before the first frame. */
+LAE_API int lae_render_frame_probe_us(float* us, uint32_t n);
 LAE_API int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
                      const uint8_t* grid, const uint8_t* edit_grid, float bound, float dt_gamma, uint32_t max_steps,
                      uint32_t C, uint32_t H, const void* table_f16, const int32_t* offsets, const int32_t* offsets_host,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "lae_render_frame_workspace_bytes": [u32, u32, u64],
     "lae_render_frame_set_overlap": [i32],
     "lae_render_frame_mode": [],
+    "lae_render_frame_probe_us": [vp, u32],
     "lae_render_frame": [vp, vp, u32, vp, f32, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, u32, f32, u32, u32, i32, u32, vp, vp, f32, f32,
                          u32, u64, vp, vp, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp, vp],
     "lae_compact_scratch_bytes": [u32],

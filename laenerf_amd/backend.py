@@ -360,6 +360,15 @@ class _RayMarching:
         check(_lib.load().lae_render_frame_set_overlap(int(bool(on))), "render_frame_set_overlap")
 
     @staticmethod
+    def render_frame_probe():
+        """-> {"in_use": candidate index or -1, "handshake_us": [...]}: the frame loop's most recent side-stream probe (candidate 0 =
+        highest priority, 1.. = the caller's class; -1.0 = not probed / not concurrent; include/laenerf.h lae_render_frame_probe_us)"""
+        import ctypes
+        us = (ctypes.c_float * 5)(*([-1.0] * 5))
+        used = int(_lib.load().lae_render_frame_probe_us(ctypes.cast(us, ctypes.c_void_p), 5))
+        return {"in_use": used, "handshake_us": [round(float(v), 1) for v in us]}
+
+    @staticmethod
     def render_frame_mode():
         """1 while frames overlap their lookahead on the side stream; 0 once switched off, probed as not concurrent, or degraded
         after a cross-stream wait timed out (include/laenerf.h)"""

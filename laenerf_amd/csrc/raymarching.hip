@@ -2223,10 +2223,16 @@ struct FrameHost {                                        // process-wide helper
     int last_mode = -1;                                   // how the most recent frame ran: 1 overlapped, 0 in line, -1 no frame yet
     bool degraded = false;                                // a frame's handshake gave up once: every later frame runs its lookahead in line
     bool warned = false;
-    hipStream_t probed[8] = {};                           // caller streams whose concurrency with `side` was probed, and the verdicts
+    hipStream_t probed[8] = {};                           // caller streams that were probed, the verdicts and the side stream chosen for each
     bool probed_ok[8] = {};
+    hipStream_t probed_side[8] = {};
     int n_probed = 0;
     uint64_t probe_counter = 0;
+    static constexpr int MAX_CAND = 5;
+    hipStream_t cand[MAX_CAND] = {};                      // side-stream candidates: [0] the configured priority (default highest), [1..] the caller's class, made on demand
+    int n_cand = 0;
+    int later_prio = 0;                                   // priority of candidates 1..
+    float last_probe_us[MAX_CAND] = {-1.f, -1.f, -1.f, -1.f, -1.f};   // handshake time of the most recent probe per candidate (lae_render_frame_probe_us)
     bool init() {
         if (ok) return true;
         void* hp = nullptr; void* dp = nullptr;
@@ -2237,8 +2243,12 @@ struct FrameHost {                                        // process-wide helper
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
         int prio = hi;
-        if (const char* e = getenv("LAE_FRAME_SIDE_PRIO")) { const int m = atoi(e); prio = m > 0 ? lo : m == 0 ? (lo + hi) / 2 : hi; }   // 1 lowest / 0 normal / -1 highest (default; measured: no difference)
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return false;
+        const char* e = getenv("LAE_FRAME_SIDE_PRIO");    // 1 lowest / 0 normal / -1 highest: ONE candidate of that class (A/B, tests)
+        if (e) { const int m = atoi(e); prio = m > 0 ? lo : m == 0 ? (lo + hi) / 2 : hi; }
+        if (hipStreamCreateWithPriority(&cand[0], hipStreamNonBlocking, prio) != hipSuccess) return false;
+        n_cand = 1;
+        later_prio = e ? prio : (lo + hi) / 2;            // further candidates (frame_pick_side makes them when candidate 0 is slow): the caller's class
+        side = cand[0];
         // The two streams hand each other work through two 64-bit words in device memory, not through events (k_frame_wait /
         // k_frame_signal above): an event record + wait is 10-12 us per dependency here, 2-3 of them per iteration.
         if (hipMalloc(reinterpret_cast<void**>(&flags), 256) != hipSuccess) return false;
@@ -2265,19 +2275,76 @@ void frame_warn_once(const char* why) {
 // live streams of one priority), when dispatch is serialised (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) or under a profiler
 // that collects counters.  Probed once per caller stream: a wait on `s`, THEN a signal on the side stream; ~15 us when it
 // passes, ~40 ms once when it does not.
-bool frame_streams_concurrent(hipStream_t s) {
-    for (int i = 0; i < g_frame.n_probed; i++)
-        if (g_frame.probed[i] == s) return g_frame.probed_ok[i];
+static bool frame_probe_concurrent(hipStream_t s, hipStream_t side) {
     volatile uint32_t* res_h = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(g_frame.mirror_h) + 128);
     volatile uint32_t* res_d = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(g_frame.mirror_d) + 128);
     *res_h = 0u;
     const unsigned long long v = ++g_frame.probe_counter;
     k_frame_probe_wait<<<1, 64, 0, s>>>(g_frame.flags + 3, v, res_d, 1u << 15);
-    k_frame_signal<<<1, 1, 0, g_frame.side>>>(g_frame.flags + 3, v);
-    bool ok = hipStreamSynchronize(g_frame.side) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && *res_h == 1u;
+    k_frame_signal<<<1, 1, 0, side>>>(g_frame.flags + 3, v);
+    return hipStreamSynchronize(side) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && *res_h == 1u;
+}
+// Microseconds for FRAME_PROBE_TRIPS hand-overs caller -> side -> caller through the loop's own mechanism (a one-thread store on
+// one stream, a polling wait on the other; everything queued up front, timed on the device between two events on `s`); < 0 on
+// failure.  Only called for streams that passed frame_probe_concurrent (a wait would otherwise run into its bound).
+constexpr int FRAME_PROBE_TRIPS = 16;
+static float frame_probe_handshake_us(hipStream_t s, hipStream_t side) {
+    volatile uint32_t* res_d = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(g_frame.mirror_d) + 132);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return -1.f; }
+    unsigned long long* fa = g_frame.flags + 3;          // caller waits, side stores
+    unsigned long long* fb = g_frame.flags + 4;          // side waits, caller stores (values only grow, like flags[3])
+    const unsigned long long base = g_frame.probe_counter;
+    g_frame.probe_counter += FRAME_PROBE_TRIPS;
+    bool ok = hipEventRecord(e0, s) == hipSuccess;
+    for (int i = 1; i <= FRAME_PROBE_TRIPS && ok; i++) {
+        if (i > 1) k_frame_probe_wait<<<1, 64, 0, side>>>(fb, base + i - 1, res_d, 1u << 15);
+        k_frame_signal<<<1, 1, 0, side>>>(fa, base + i);
+        k_frame_probe_wait<<<1, 64, 0, s>>>(fa, base + i, res_d, 1u << 15);
+        k_frame_signal<<<1, 1, 0, s>>>(fb, base + i);
+    }
+    ok = ok && hipEventRecord(e1, s) == hipSuccess && hipStreamSynchronize(side) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+    float ms = -1.f;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = -1.f;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms < 0.f ? -1.f : ms * 1000.f;
+}
+// Can the caller's stream and a side stream make progress side by side, and does the side stream pick its work up promptly?  The
+// handshake below needs the first: a wait kernel on one stream polls a word a kernel on the other stream stores.  Not when both
+// map to one hardware queue (GPU_MAX_HW_QUEUES=1, many live streams of one priority), when dispatch is serialised
+// (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING) or under a profiler that collects counters.  The second decides the frame time:
+// the lookahead stream wakes up once per iteration, and a hardware queue that is slow to pick a dispatch up costs ~50 us per
+// hand-over instead of ~11 (round 5, MI355X / ROCm 7.2: once three or more other streams had been used in the process the
+// highest-priority stream was such a queue -- a 9.8 ms frame took 23 ms -- while a stream of the caller's class was not; with two
+// used streams it was the other way round; in a fresh process both are fast).  So, once per caller stream: candidate 0 (the
+// configured priority, default highest) is probed -- ~15 us for the concurrency test, two timed runs of 16 hand-overs, ~0.2 ms each --
+// and taken if it is concurrent and fast (< FRAME_FAST_US for the 16); otherwise up to four streams of the caller's class are
+// created and probed in turn (a new stream lands on another hardware queue) and the first fast one is taken, else the fastest seen.
+// ~40 ms once per candidate that does not run beside the caller's stream.
+// -> the side stream to use, nullptr: run in line
+constexpr float FRAME_FAST_US = 400.f;                    // 16 hand-overs: ~170-200 us on a prompt queue, ~850 on a slow one
+hipStream_t frame_pick_side(hipStream_t s) {
+    for (int i = 0; i < g_frame.n_probed; i++)
+        if (g_frame.probed[i] == s) return g_frame.probed_ok[i] ? g_frame.probed_side[i] : nullptr;
+    hipStream_t best = nullptr;
+    float best_us = 0.f;
+    for (int c = 0; c < FrameHost::MAX_CAND; c++) {
+        if (c >= g_frame.n_cand) {
+            if (hipStreamCreateWithPriority(&g_frame.cand[c], hipStreamNonBlocking, g_frame.later_prio) != hipSuccess) break;
+            g_frame.n_cand = c + 1;
+        }
+        g_frame.last_probe_us[c] = -1.f;
+        if (!frame_probe_concurrent(s, g_frame.cand[c])) continue;
+        (void)frame_probe_handshake_us(s, g_frame.cand[c]);                  // first run: the queue wakes up, code objects load
+        const float us = frame_probe_handshake_us(s, g_frame.cand[c]);
+        g_frame.last_probe_us[c] = us;
+        if (us < 0.f) continue;
+        if (!best || us < best_us) { best = g_frame.cand[c]; best_us = us; }
+        if (us < FRAME_FAST_US) break;
+    }
     const int slot = g_frame.n_probed < 8 ? g_frame.n_probed++ : (int)(g_frame.probe_counter & 7u);
-    g_frame.probed[slot] = s; g_frame.probed_ok[slot] = ok;
-    return ok;
+    g_frame.probed[slot] = s; g_frame.probed_ok[slot] = best != nullptr; g_frame.probed_side[slot] = best;
+    return best;
 }
 }  // namespace
 
@@ -2287,6 +2354,16 @@ int lae_render_frame_set_overlap(int on) { g_frame_overlap = on ? 1 : 0; return 
 int lae_render_frame_mode(void) {
     std::lock_guard<std::mutex> lk(g_frame_mtx);
     return g_frame.last_mode >= 0 ? g_frame.last_mode : (g_frame_overlap != 0 && !g_frame.degraded ? 1 : 0);
+}
+
+// the most recent side-stream probe: microseconds for 16 hand-overs per candidate (0: configured priority, 1..4: the caller's class;
+// < 0 = not probed or not concurrent), up to n values; returns the candidate in use, -1 before the first frame
+int lae_render_frame_probe_us(float* us, uint32_t n) {
+    std::lock_guard<std::mutex> lk(g_frame_mtx);
+    for (uint32_t i = 0; us && i < n; i++) us[i] = i < (uint32_t)FrameHost::MAX_CAND ? g_frame.last_probe_us[i] : -1.f;
+    if (!g_frame.ok || g_frame.last_mode < 0) return -1;
+    for (int c = 0; c < g_frame.n_cand; c++) if (g_frame.side == g_frame.cand[c]) return c;
+    return -1;
 }
 
 static int render_frame_once(const float* rays_o, const float* rays_d, uint32_t N, const float* aabb, float min_near,
@@ -2574,9 +2651,13 @@ int lae_render_frame(const float* rays_o, const float* rays_d, uint32_t N, const
     // the same kernels run in line on the caller's stream: the image has the same bits, the frame is slower.
     static const int forced = [] { const char* e = getenv("LAE_FRAME_OVERLAP"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();   // 1: skip the probe (tests of the give-up path), 0: in line
     bool overlap = g_frame_overlap != 0 && !g_frame.degraded && forced != 0;
-    if (overlap && forced < 0 && !frame_streams_concurrent(s)) {
-        overlap = false;
-        frame_warn_once("the caller's stream and the side stream do not run concurrently (one hardware queue, serialised dispatch or a counter-collecting profiler)");
+    if (overlap && forced < 0) {
+        hipStream_t pick = frame_pick_side(s);
+        if (pick) g_frame.side = pick;
+        else {
+            overlap = false;
+            frame_warn_once("the caller's stream and the side stream do not run concurrently (one hardware queue, serialised dispatch or a counter-collecting profiler)");
+        }
     }
     bool gave_up = false;
 #define LAE_FRAME_ARGS rays_o, rays_d, N, aabb, min_near, grid, edit_grid, bound, dt_gamma, max_steps, C, H, table_f16, offsets, offsets_host, L, S, \

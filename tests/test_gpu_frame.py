@@ -257,6 +257,41 @@ def test_frames_on_two_streams():
         assert np.array_equal(N(res["image"]), N(ref["image"]))
 
 
+def test_side_stream_is_chosen_by_a_timed_handshake():
+    """round 5: with the first frame of a caller stream the library times 16 hand-overs through its own store / poll kernels on its
+    side-stream candidates (the highest-priority one first; streams of the caller's class are created when that one is not concurrent
+    or slow -- which happens once the process uses a few more streams: a 9.8 ms frame took 23 ms) and takes the first prompt one.
+    Here: eight other streams in use, a frame on a NEW caller stream -> a probe record whose chosen candidate is concurrent and at
+    most as slow as every other candidate measured; same image as the in-line loop bit for bit."""
+    from laenerf_amd.backend import raymarching_backend as B
+    net, r = make(bound=1, seed=8)
+    o, d = rays(3000, seed=4)
+    busy = [torch.cuda.Stream() for _ in range(8)]
+    for st in busy:
+        with torch.cuda.stream(st):
+            torch.zeros(16, device=DEV).add_(1)
+    torch.cuda.synchronize()
+    with torch.autocast("cuda", dtype=torch.float16):
+        B.render_frame_set_overlap(False)
+        try:
+            ref = r.render_eval(o, d, bg_color=1)
+        finally:
+            B.render_frame_set_overlap(True)
+        caller = torch.cuda.Stream()
+        caller.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(caller):
+            res = r.render_eval(o, d, bg_color=1)
+        torch.cuda.synchronize()
+    assert np.array_equal(N(res["image"]), N(ref["image"]))
+    probe = B.render_frame_probe()
+    print("side-stream probe:", probe)
+    assert B.render_frame_mode() == 1 and probe["in_use"] >= 0
+    us = probe["handshake_us"]
+    measured = [v for v in us if v >= 0]
+    assert us[probe["in_use"]] >= 0 and us[probe["in_use"]] <= min(measured) + 1e-3
+    assert us[probe["in_use"]] < 400.0 or len(measured) == len(us)          # a slow stream is only kept when every candidate was tried
+
+
 @pytest.mark.parametrize("kind", ["opaque", "empty"])
 def test_frame_loop_ends_when_every_ray_dies_at_once(kind):
     """all rays terminate in the first iteration (opaque field) or never find a sample (empty bitfield): n_alive drops to 0
