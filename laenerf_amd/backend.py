@@ -631,9 +631,15 @@ def collect_kernel_timing():
     """-> {name: {ms (sum of event-pair durations), calls, units (sum of B / N / M of the calls)}}; synchronises"""
     torch.cuda.synchronize()
     out = {}
+    each = {}
     for name, e0, e1, units in _timing["events"]:
         d = out.setdefault(name, {"ms": 0.0, "calls": 0, "units": 0})
-        d["ms"] += e0.elapsed_time(e1); d["calls"] += 1; d["units"] += units
+        t = e0.elapsed_time(e1)
+        d["ms"] += t; d["calls"] += 1; d["units"] += units
+        each.setdefault(name, []).append(t)
+    for name, ts in each.items():                          # spread of the intervals (a host stall inside one shows as max >> median)
+        ts.sort()
+        out[name]["median_ms"], out[name]["max_ms"], out[name]["min_ms"] = ts[len(ts) // 2], ts[-1], ts[0]
     _timing["events"] = []
     return out
 
@@ -646,8 +652,10 @@ def _wrap_timed(name, fn):
             return fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # keep the stream busy while the host enqueues {e0, kernels, e1}: with an idle GPU the interval would also hold
-        # the host's launch latency (Python + ctypes, 5-25 us), which is not kernel time
-        torch.cuda._sleep(_timing.get("sleep_cycles", 150000))
+        # the host's launch latency (Python + ctypes), which is not kernel time.  ~0.35 ms of spin (600 k shader cycles): rounds
+        # 1-4 used 150 k (~85 us), which the encoder's wrapper -- the longest host path -- only just fitted under: unrelated
+        # edits of bench.py moved its event time between 50 and 58 us while rocprofv3 kept seeing 49 us launches (round 5)
+        torch.cuda._sleep(_timing.get("sleep_cycles", 600000))
         e0.record()
         r = fn(*a, **k)
         e1.record()

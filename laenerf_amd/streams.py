@@ -14,6 +14,7 @@ MI355X / ROCm 7.2 (round 5):
 - a high-priority torch side stream avoids the first problem but ran whole runs 3x slower when it was the first such stream of a
   process that had replayed other graphs -- so the priority stays the default.
 `concurrent_side_stream()` probes a few pool streams and returns the best one."""
+import os
 import time
 
 import torch
@@ -53,6 +54,9 @@ def concurrent_side_stream(candidates=6):
     """-> (stream, record): the candidate that runs BESIDE the current stream (two ~0.4 ms single-thread spin kernels, one per
     stream, take one spin's time and not two) with the shortest cross-stream round trip; the last candidate if none runs beside it
     (e.g. under a serialising profiler) -- the record says so (`concurrent`)."""
+    candidates = int(os.environ.get("LAE_STREAM_CANDIDATES", candidates))      # A/B switch
+    if candidates <= 0:                                   # no probe: whatever torch hands out
+        return torch.cuda.Stream(), {"candidates": 0, "concurrent": None}
     main = torch.cuda.current_stream()
     cycles = 100000
     _spin([main], cycles)
@@ -63,7 +67,7 @@ def concurrent_side_stream(candidates=6):
     for _ in range(candidates):
         side = torch.cuda.Stream()
         pair = min(_spin([main, side], cycles) for _ in range(3))
-        hop = min(_round_trip(main, side) for _ in range(2))
+        hop = min(_round_trip(main, side) for _ in range(2)) if not os.environ.get("LAE_STREAM_NO_HOPS") else 0.0
         seen.append((pair < 1.5 * solo, hop, pair, side))
     good = [c for c in seen if c[0]]
     beside, hop, pair, side = min(good, key=lambda c: c[1]) if good else seen[-1]
