@@ -1214,12 +1214,7 @@ def main():
             zero_grad()
             step_body(o, d, gt)
         torch.cuda.synchronize()
-    # no collector pause between an event pair: one full collection landing inside ONE of the twenty encoder intervals (184 us
-    # among 52 us) moved the line's `roofline` between 0.38 and 0.32 with unrelated edits of this file -- where the allocation
-    # count trips the collector is an accident of the code before it (round 5; `launch_us_min_median_max` shows the spread)
-    import gc
-    gc.collect()
-    gc.disable()
+    # (the collector is off while the timing is on -- backend.enable_kernel_timing says why; `launch_us_min_median_max` shows the spread)
     backend.enable_kernel_timing(True, only=None)
     n_diag = 20
     for i in range(n_diag):
@@ -1242,7 +1237,6 @@ def main():
     else:
         timing_split = {}
     backend.enable_kernel_timing(False)
-    gc.enable()
     if graph:
         timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
     # N > 1: the north star's split, beside the replica `value` -- the configs[3] frame ray-sharded over the ranks with ONE

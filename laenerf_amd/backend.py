@@ -623,7 +623,16 @@ _UNITS = {"grid_encode_forward": 4, "grid_encode_backward": 5, "grid_backward_pl
 
 
 def enable_kernel_timing(on, only=("grid_encode_forward",)):
-    """only = tuple of backend function names to time, or None for all of them"""
+    """only = tuple of backend function names to time, or None for all of them.  While it is on, Python's collector is off (one
+    explicit collection first): a full collection landing between an event pair puts a 160-184 us interval among 52 us ones, and
+    where the allocation count trips the collector is an accident of the code that ran before (round 5: bench.py's `roofline`
+    moved between 0.38 and 0.32 with unrelated edits)."""
+    import gc
+    if on:
+        gc.collect()
+        gc.disable()
+    elif _timing["on"]:
+        gc.enable()
     _timing["on"], _timing["only"], _timing["events"] = bool(on), (set(only) if only else None), []
 
 
