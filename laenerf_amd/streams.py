@@ -13,13 +13,18 @@ MI355X / ROCm 7.2 (round 5):
   0.78 instead of 0.31 (LAENeRF step), with unchanged kernel times;
 - a high-priority torch side stream avoids the first problem but ran whole runs 3x slower when it was the first such stream of a
   process that had replayed other graphs -- so the priority stays the default.
-`concurrent_side_stream()` probes a few pool streams and returns the best one."""
+- the more streams a process has put to use, the likelier the NEXT stream of another priority class is such a slow queue (the frame
+  loop's own lookahead stream: 23 instead of 9.8 ms per frame once three other streams were in use; it now times its candidates
+  too) -- so the probe stops at the first candidate that is good enough instead of trying them all.
+`concurrent_side_stream()` probes pool streams until one runs beside the main stream with a prompt round trip (at most six) and
+returns the best one seen."""
 import os
 import time
 
 import torch
 
 PROBES = []          # one record per call, newest last (bench.py puts the headline's into its line)
+PROMPT_ROUND_TRIP_S = 45e-6      # event round trip main -> side -> main: 27-34 us on a prompt queue, 64-157 us on a slow one
 
 
 def _spin(streams, cycles):
@@ -51,9 +56,10 @@ def _round_trip(main, side, n=40):
 
 
 def concurrent_side_stream(candidates=6):
-    """-> (stream, record): the candidate that runs BESIDE the current stream (two ~0.4 ms single-thread spin kernels, one per
-    stream, take one spin's time and not two) with the shortest cross-stream round trip; the last candidate if none runs beside it
-    (e.g. under a serialising profiler) -- the record says so (`concurrent`)."""
+    """-> (stream, record): the first candidate that runs BESIDE the current stream (two ~0.4 ms single-thread spin kernels, one per
+    stream, take one spin's time and not two) with a prompt cross-stream round trip (< 45 us), else the concurrent one with the
+    shortest round trip; the last candidate if none runs beside it (e.g. under a serialising profiler) -- the record says so
+    (`concurrent`)."""
     candidates = int(os.environ.get("LAE_STREAM_CANDIDATES", candidates))      # A/B switch
     if candidates <= 0:                                   # no probe: whatever torch hands out
         return torch.cuda.Stream(), {"candidates": 0, "concurrent": None}
@@ -69,6 +75,8 @@ def concurrent_side_stream(candidates=6):
         pair = min(_spin([main, side], cycles) for _ in range(3))
         hop = min(_round_trip(main, side) for _ in range(2)) if not os.environ.get("LAE_STREAM_NO_HOPS") else 0.0
         seen.append((pair < 1.5 * solo, hop, pair, side))
+        if seen[-1][0] and hop < PROMPT_ROUND_TRIP_S:     # good enough: every further candidate put to use is one more hardware queue
+            break                                         # in play for everybody else (the frame loop's side stream, see above)
     good = [c for c in seen if c[0]]
     beside, hop, pair, side = min(good, key=lambda c: c[1]) if good else seen[-1]
     rec = {"candidates": len(seen), "concurrent": bool(beside), "solo_ms": round(solo * 1e3, 3), "pair_ms": round(pair * 1e3, 3),

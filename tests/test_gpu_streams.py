@@ -13,7 +13,7 @@ def test_concurrent_side_stream_runs_beside_the_current_stream():
     side, rec = concurrent_side_stream(candidates=4)
     assert len(PROBES) == n0 + 1 and PROBES[-1] is rec
     main = torch.cuda.current_stream()
-    assert side != main and rec["candidates"] == 4 and len(rec["round_trips_seen_us"]) == 4
+    assert side != main and 1 <= rec["candidates"] <= 4 and len(rec["round_trips_seen_us"]) == rec["candidates"]
     assert rec["concurrent"], rec                                   # an MI355X box runs two streams side by side
     assert rec["pair_ms"] < 1.5 * rec["solo_ms"]
     assert rec["round_trip_us"] <= min(rec["round_trips_seen_us"]) * 1.5 + 1e-6 or rec["in_line_candidates"] > 0
