@@ -73,7 +73,7 @@ def concurrent_side_stream(candidates=6):
     for _ in range(candidates):
         side = torch.cuda.Stream()
         pair = min(_spin([main, side], cycles) for _ in range(3))
-        hop = min(_round_trip(main, side) for _ in range(2)) if not os.environ.get("LAE_STREAM_NO_HOPS") else 0.0
+        hop = min(_round_trip(main, side) for _ in range(2))
         seen.append((pair < 1.5 * solo, hop, pair, side))
         if seen[-1][0] and hop < PROMPT_ROUND_TRIP_S:     # good enough: every further candidate put to use is one more hardware queue
             break                                         # in play for everybody else (the frame loop's side stream, see above)
