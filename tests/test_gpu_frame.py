@@ -289,7 +289,7 @@ def test_side_stream_is_chosen_by_a_timed_handshake():
     us = probe["handshake_us"]
     measured = [v for v in us if v >= 0]
     assert us[probe["in_use"]] >= 0 and us[probe["in_use"]] <= min(measured) + 1e-3
-    assert us[probe["in_use"]] < 400.0 or len(measured) == len(us)          # a slow stream is only kept when every candidate was tried
+    assert us[probe["in_use"]] < 400.0 or all(v >= 400.0 for v in measured)  # a slow stream is only kept when no prompt one was found
 
 
 @pytest.mark.parametrize("kind", ["opaque", "empty"])
