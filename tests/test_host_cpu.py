@@ -152,3 +152,20 @@ def test_bench_refuses_a_rank_count_it_was_not_launched_with():
     if torch.cuda.device_count() < 64:
         out = subprocess.run([sys.executable, bench, "--gpus", "64"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 2 and "asks for 64" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_imports_touch_no_gpu():
+    """bench.py starts its ranks as a child process BEFORE any GPU call of the parent (round 5); what it imports at module level
+    -- laenerf_amd.streams among it -- must therefore not initialise the GPU, and the stream helper has no CPU fallback."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys, torch; sys.path.insert(0, %r); import bench; import laenerf_amd.streams as st; "
+            "print('init', torch.cuda.is_initialized()); "
+            "\ntry:\n    st.concurrent_side_stream()\n    print('no error')\nexcept Exception as e:\n    print('raised', type(e).__name__)") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert "init False" in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "raised" in out.stdout and "no error" not in out.stdout
