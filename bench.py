@@ -543,6 +543,39 @@ def style_step(dev, P=100000, steps=30, switches=None, G=8, pipeline=True):
     torch.cuda.synchronize()
     dt_one = (time.perf_counter() - t0) / steps
     out = {"points": P, "one_graph_per_step_ms": round(dt_one * 1e3, 4)}
+    # the same step on points as a view hands them over: termination points of neighbouring pixels lie next to each other on the
+    # region's surface (EditDataset keeps a view's selected pixels in pixel order, editing/edit_dataset.py:147-160) -- here a
+    # jittered row-major lattice on a spherical cap of the same 0.3 radius.  The hash-grid kernels run at the rate of their cache
+    # hits, so the random ball above is the pessimistic end (SURVEY 8d's definition; it stays the quoted figure).
+    side_n = int(P ** 0.5)
+    Pc = side_n * side_n // 16 * 16
+    u = torch.linspace(-0.9, 0.9, side_n, device=dev)
+    uu, vv = torch.meshgrid(u, u, indexing="ij")
+    cap = torch.stack([uu, vv, torch.sqrt((1.6 - uu * uu - vv * vv).clamp_min(0.0))], -1).reshape(-1, 3)[:Pc]
+    xc = (torch.nn.functional.normalize(cap, dim=-1) * 0.3 + 1e-4 * torch.randn(Pc, 3, device=dev)).contiguous()
+    coherent = (xc, torch.nn.functional.normalize(torch.randn(Pc, 3, device=dev), dim=-1), torch.rand(Pc, 3, device=dev))
+
+    def body_c():
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, pred, w, o = m.forward_train_loss(*coherent, params, opt, with_palet_loss=True)
+        opt.backward(loss)
+        opt.step()
+    with torch.cuda.stream(side):
+        for i in range(3):
+            body_c()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gc_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gc_):
+        body_c()
+    for _ in range(3):
+        gc_.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        gc_.replay()
+    torch.cuda.synchronize()
+    out["surface_ordered_points"] = {"points": Pc, "one_graph_per_step_ms": round((time.perf_counter() - t0) / steps * 1e3, 4),
+                                     "note": "pixel-ordered termination points on a spherical cap (what a view's batch looks like); not the quoted figure"}
     dt = dt_one
     if pipeline and m.ffmlp_shadows and m.plan_backward(views[0][0]) is not None:      # (A/B switches: tools/style_step_ab.py says why)
         step, _ = grouped_pipeline(None, opt, views, G, ahead_fn=lambda view: m.plan_backward(view[0]), step_fn=body)
