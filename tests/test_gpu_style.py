@@ -363,3 +363,39 @@ def test_step_with_a_backward_plan_made_ahead_equals_the_step_that_plans_for_its
     assert m.plan_backward(x) is None
     with torch.autocast("cuda", dtype=torch.float16), pytest.raises(RuntimeError):
         m.forward_train_loss(x, d, target, params, opt, plan=first_plan)
+
+
+def test_round5_entry_points_refuse_bad_arguments():
+    """error behaviour of the round-5 C entry points through the Python stubs: wrong shapes / dtypes / modes raise (no fallback)"""
+    from laenerf_amd.backend import style_backend as B, ffmlp_backend as F, raymarching_backend as R
+    M, Mp = 100, 112
+    feats = torch.zeros(16, M, 2, device=DEV, dtype=torch.half)
+    feat = torch.zeros(Mp, 32, device=DEV, dtype=torch.half)
+    off = torch.zeros(Mp, 48, device=DEV, dtype=torch.half)
+    dirs = torch.zeros(M, 3, device=DEV)
+    with pytest.raises(RuntimeError):
+        B.style_assemble_forward(feats, dirs, M, Mp, 5, feat, off, 48)                 # SH degree above 4
+    with pytest.raises(RuntimeError):
+        B.style_assemble_forward(feats, dirs, M, Mp, 4, feat, off[:, :40].contiguous(), 40)     # 32 + 16 columns do not fit 40
+    with pytest.raises(RuntimeError):
+        B.style_assemble_forward(feats, dirs, M, M - 4, 3, feat, off, 48)              # padded rows below the rows
+    with pytest.raises(RuntimeError):
+        B.style_assemble_forward(feats.float(), dirs, M, Mp, 3, feat, off, 48)         # fp32 features
+    with pytest.raises(RuntimeError):
+        B.style_assemble_backward(None, None, M, 48, feats)                            # no gradient at all
+    with pytest.raises(RuntimeError):
+        B.style_assemble_backward(feat, off, M, 50, feats)                             # more than 48 columns
+    B.style_assemble_forward(feats, dirs, M, Mp, 3, feat, off, 48)                     # the valid call goes through
+    B.style_assemble_backward(feat, off, M, 48, feats)
+    # accumulate / nonfinite_flag need the fused backward: a width it does not cover is refused, not silently overwritten
+    w = torch.zeros(32 * 16 + 16 * 16 + 16 * 16, device=DEV, dtype=torch.half)
+    x = torch.zeros(16, 32, device=DEV, dtype=torch.half)
+    g = torch.zeros(16, 16, device=DEV, dtype=torch.half)
+    if not F.fused_backward_available(32, 16, 2, 0):
+        fb = torch.zeros(2, 16, 16, device=DEV, dtype=torch.half)
+        with pytest.raises(RuntimeError):
+            F.ffmlp_backward(g, x, w, fb, 16, 32, 16, 16, 2, 0, 6, False, torch.zeros_like(fb), torch.zeros(1, device=DEV, dtype=torch.half),
+                             torch.zeros_like(w), accumulate=True)
+    probe = R.render_frame_probe()
+    assert set(probe) == {"in_use", "handshake_us"} and len(probe["handshake_us"]) == 5
+    torch.cuda.synchronize()
