@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-frame", action="store_true", help="skip the 800x800 inference-frame timing (extra field eval_frame)")
     p.add_argument("--no-style", action="store_true", help="skip the LAENeRF palette-network step timing (extra field style_step)")
+    p.add_argument("--no-dropin", action="store_true", help="skip the zero-edit drop-in train step (extra field drop_in_step)")
     p.add_argument("--cpu-rays", type=int, default=0, help="rays in the CPU-baseline sample (0 = auto, ~15 s)")
     p.add_argument("--no-optimizer", action="store_true", help="diagnostic only: skip Adam/GradScaler (not the reported metric)")
     p.add_argument("--workload", choices=["train", "frame1080", "flower"], default="train",
@@ -220,10 +221,9 @@ def roofline_more(tm, dev, with_frame=True):
         o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
         with torch.autocast("cuda", dtype=torch.float16), torch.no_grad():
             r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(800, 800), frame_loop=False)       # warm-up
-            backend.enable_kernel_timing(True, only=("grid_encode_forward",))
-            r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(800, 800), frame_loop=False)
-        e = backend.collect_kernel_timing().get("grid_encode_forward")
-        backend.enable_kernel_timing(False)
+            with backend.kernel_timing(only=("grid_encode_forward",)) as kt:
+                r.render_eval(o, d, bg_color=1, max_steps=1024, image_hw=(800, 800), frame_loop=False)
+        e = kt.result.get("grid_encode_forward")
         if e and e["calls"]:
             gbs = e["units"] * GRID_FWD_BYTES_FP16 / (e["ms"] * 1e-3) / 1e9
             out["frame_encoder"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -791,11 +791,10 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
         step(4 * G + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    backend.enable_kernel_timing(True, only=None)
-    for i in range(10):
-        body(i)
-    tm = backend.collect_kernel_timing()
-    backend.enable_kernel_timing(False)
+    with backend.kernel_timing(only=None) as kt:
+        for i in range(10):
+            body(i)
+    tm = kt.result
     gf = tm.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
     per_launch = gf["units"] / max(gf["calls"], 1)
     us = gf["ms"] / max(gf["calls"], 1) * 1e3
@@ -809,6 +808,111 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
             "operator_ms_per_step": {k: round(v["ms"] / 10, 4) for k, v in sorted(tm.items())},
             "note": "configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box; grouped two-stream pipeline like the "
                     "headline (march + counting pass of step k+2 beside shading / backward / Adam of step k)"}
+
+
+class _SegmentProbe:
+    """device time of an eager step that reads the device from the host in the middle: the stretch between two host reads is
+    bracketed by a HIP-event pair behind a spin kernel long enough for the host to enqueue the whole stretch (so the events see
+    kernels back to back, not the host's launch gaps); the step's device time is the sum of its stretches.
+    laenerf_amd/reference_chain.py calls cut() before each host read and begin() after it."""
+
+    def __init__(self, sleep_cycles):
+        self.sleep_cycles, self.pairs, self.open = int(sleep_cycles), [], None
+
+    def begin(self):
+        if self.open is None:
+            torch.cuda._sleep(self.sleep_cycles)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.open = e0
+
+    def cut(self):
+        if self.open is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((self.open, e1))
+            self.open = None
+
+    def take_ms(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        self.pairs = []
+        return ms
+
+
+def drop_in_step(dev, fused_ms, steps=40, n_rays=4096):
+    """The train step of a LAENeRF checkout that has added INTEGRATION.md 1's three lines and changed nothing else: the reference's
+    own operator sequence (nerf/renderer.py:259-333 -> nerf/network_ff.py:51-79 -> the wrappers' allocate-then-call rules ->
+    torch MSE -> GradScaler -> torch.optim.Adam, nerf/utils.py:1472-1478), eager, through the four reference-named backend modules
+    (laenerf_amd/reference_chain.py).  Same rays, occupancy, table and MLP shapes as the headline.  `ms_per_step`: wall clock of
+    K eager steps; `device_ms_per_step`: HIP events around the stretches between the step's host reads (two `torch.any` of
+    network_ff.py:72, GradScaler's found_inf), each behind a spin kernel so that launch gaps do not count."""
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.reference_chain import ReferenceChain, drop_in_train_step
+    out = {}
+    for nan_check in (True, False):
+        torch.manual_seed(1234)
+        chain = ReferenceChain(bound=1, min_near=0.2, nan_check=nan_check).to(dev).train()
+        chain.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+        opt = torch.optim.Adam(chain.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)       # main_nerf.py:223
+        scaler = torch.amp.GradScaler("cuda")
+        batches = []
+        for b in range(16):
+            o, d = S.lego_like_rays(n_rays, seed=b, n_views=1)
+            batches.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(n_rays, 3, device=dev)))
+        for i in range(34):                                   # 16 host-sized steps, then mean_count mode (renderer.py:644-647)
+            drop_in_train_step(chain, opt, scaler, batches[i % 16])
+            if (i + 1) % 16 == 0:
+                chain.update_mean_count()
+        rows = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            _, res = drop_in_train_step(chain, opt, scaler, batches[i % 16])
+            rows.append(res["n_rows"])
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        # device time: the same step with event pairs around its host-read-free stretches; unscale_ as its own call, so that the
+        # stretch up to GradScaler's host read ends there and the optimizer's kernels start a new one (optimizer pre-step hook)
+        probe = _SegmentProbe(sleep_cycles=8_000_000)         # ~4.5 ms of spin per stretch: > the host's enqueue time of any stretch
+        hook = opt.register_step_pre_hook(lambda *a, **k: probe.begin())
+        per_step = []
+        import gc
+        gc_was = gc.isenabled()
+        gc.collect(); gc.disable()
+        try:
+            for i in range(12):
+                probe.begin()
+                drop_in_train_step(chain, opt, scaler, batches[i % 16], probe=probe, split_unscale=True)
+                probe.cut()
+                per_step.append(probe.take_ms())
+        finally:
+            hook.remove()
+            if gc_was:
+                gc.enable()
+        per_step = per_step[2:]
+        dev_ms = sorted(sum(p) for p in per_step)[len(per_step) // 2]
+        key = "as_written" if nan_check else "without_nan_check"
+        out[key] = {"ms_per_step": round(wall * 1e3, 4), "Mrays_per_s": round(n_rays / wall / 1e6, 3),
+                    "device_ms_per_step": round(dev_ms, 4), "device_stretches_ms": [round(v, 4) for v in per_step[len(per_step) // 2]],
+                    "bound_by": "host (launch issue + host reads)" if wall * 1e3 > 1.15 * dev_ms else "device",
+                    "rows_per_step": int(np.mean(rows))}
+    aw = out["as_written"]
+    res = {"ms_per_step": aw["ms_per_step"], "Mrays_per_s": aw["Mrays_per_s"], "device_ms_per_step": aw["device_ms_per_step"],
+           "device_stretches_ms": aw["device_stretches_ms"], "bound_by": aw["bound_by"], "rows_per_step": aw["rows_per_step"],
+           "without_network_nan_check": out["without_nan_check"],
+           "fused_headline_ms_per_step": round(fused_ms, 4),
+           "device_time_vs_fused_step": round(aw["device_ms_per_step"] / fused_ms, 2),
+           "wall_time_vs_fused_step": round(aw["ms_per_step"] / fused_ms, 2), "rays": n_rays}
+    lp = os.path.join(ROOT, "profiles", "drop_in_launches.json")        # kernel count of one step from the committed rocprofv3 trace
+    if os.path.exists(lp):
+        try:
+            res["launches_per_step"] = json.load(open(lp))
+        except Exception:
+            pass
+    res["note"] = ("zero-edit drop-in: the reference's operator sequence and wrapper rules (per-call table cast, [L,B,C] output + permute, "
+                   "separate ffmlp / trunc_exp / SH / cat / composite launches, zero-filled buffers, torch MSE + GradScaler + torch.optim.Adam), "
+                   "eager, through the modules install_as_reference_backends() registers; `value` is this repository's fused driver instead")
+    return res
 
 
 def cpu_baseline_cfg1(n_threads, budget_s=8.0):
@@ -1213,7 +1317,7 @@ def main():
         for i in range(n_warm - 5, n_warm):                 # ends with the march of the first timed step in flight
             step(i)
         torch.cuda.synchronize()
-    backend.enable_kernel_timing(not graph)
+    backend.enable_kernel_timing(not graph)                 # (--no-graph only: events inside the timed region; switched off right after it)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -1238,6 +1342,7 @@ def main():
         sync_all()
         windows.append(time.perf_counter() - tw)
     timing_grid = backend.collect_kernel_timing() if not graph else {}
+    backend.enable_kernel_timing(False)
     # diagnostic (outside the timed region): per-operator device time of 20 eager steps (HIP events around each
     # operator on the launch stream); with graph replay this is also where the roofline kernel is timed, because
     # events cannot be read back from inside a replayed graph
@@ -1248,28 +1353,28 @@ def main():
             step_body(o, d, gt)
         torch.cuda.synchronize()
     # (the collector is off while the timing is on -- backend.enable_kernel_timing says why; `launch_us_min_median_max` shows the spread)
-    backend.enable_kernel_timing(True, only=None)
     n_diag = 20
-    for i in range(n_diag):
-        o, d, gt = batches[i % n_batches]
-        zero_grad()
-        step_body(o, d, gt)
-    timing_all = backend.collect_kernel_timing()
-    # the same 20 steps with the hash-grid backward in its two halves (counting pass + scans = what the side stream runs ahead;
-    # fill + accumulate = what stays on the main stream), HIP events around each: the `roofline_more` objects below
-    if fused_loss and not args.no_optimizer and not args.dp:
+    with backend.kernel_timing(only=None) as kt:
         for i in range(n_diag):
             o, d, gt = batches[i % n_batches]
             zero_grad()
-            with torch.autocast("cuda", dtype=torch.float16):
-                marched = r.march_train(o, d, perturb=True, max_steps=1024, plan_backward=True)
-                res = r.shade_train(marched, bg_color=1, gt=gt, scaler=scaler)
-            scaler.backward(res["loss"])
-            opt.step()
-        timing_split = backend.collect_kernel_timing()
+            step_body(o, d, gt)
+    timing_all = kt.result
+    # the same 20 steps with the hash-grid backward in its two halves (counting pass + scans = what the side stream runs ahead;
+    # fill + accumulate = what stays on the main stream), HIP events around each: the `roofline_more` objects below
+    if fused_loss and not args.no_optimizer and not args.dp:
+        with backend.kernel_timing(only=None) as kt:
+            for i in range(n_diag):
+                o, d, gt = batches[i % n_batches]
+                zero_grad()
+                with torch.autocast("cuda", dtype=torch.float16):
+                    marched = r.march_train(o, d, perturb=True, max_steps=1024, plan_backward=True)
+                    res = r.shade_train(marched, bg_color=1, gt=gt, scaler=scaler)
+                scaler.backward(res["loss"])
+                opt.step()
+        timing_split = kt.result
     else:
         timing_split = {}
-    backend.enable_kernel_timing(False)
     if graph:
         timing_grid = {"grid_encode_forward": timing_all.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})}
     # N > 1: the north star's split, beside the replica `value` -- the configs[3] frame ray-sharded over the ranks with ONE
@@ -1290,11 +1395,15 @@ def main():
         gf = timing_grid.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
         per_launch_bytes = gf["units"] / max(gf["calls"], 1) * GRID_FWD_BYTES_FP16
         achieved = per_launch_bytes / (gf["ms"] / max(gf["calls"], 1) * 1e-3) / 1e9 if gf["calls"] else float("nan")
-        traffic = None
+        traffic, traffic_source = None, None
         tp = os.path.join(ROOT, "profiles", "grid_fwd_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("hbm_bytes_per_launch")
+                # NOT a counter of this run: PMC passes need rocprofv3 around the process; the committed result of the most recent
+                # counter run of this same command is read back (its file says which run)
+                traffic_source = "read back from profiles/grid_fwd_traffic.json (%s), not counted in this run" % tj.get("source", tj.get("note", "committed PMC run"))
             except Exception:
                 traffic = None
         out = {
@@ -1303,6 +1412,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "world_size": (dist.get_world_size() if world > 1 else 1),
             "backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": n_warm,
+            "warmup_requested": args.warmup,               # `warmup` = the untimed steps actually run (>= 17 for mean_count mode + whole replay groups)
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 (table, MLP) / f32 (march, composite)", "data": "synthetic",
             "config": {"workload": "configs[1]: lego-like 800x800 pinhole rays, 4096 random pixels of one view per step, L=16 T=2^19 F=2 hash grid "
@@ -1317,7 +1427,7 @@ def main():
                                        f"{world} independent ray-batch replicas (no data-path collective)")},
             "roofline": {"kernel": "k_grid_fwd_lean (hash-grid encode forward, fp16 table)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_sample": GRID_FWD_BYTES_FP16,
                          "samples_per_launch": int(gf["units"] / max(gf["calls"], 1)),
                          "avg_launch_us": round(gf["ms"] / max(gf["calls"], 1) * 1e3, 2),
@@ -1343,6 +1453,8 @@ def main():
                                "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone on the reference schedule, "
                                "best_n1_ms_per_frame: on the fastest of {reference rule, 2N, 4N, 8N rows per iteration}; speedup_vs_n1 divides THAT by ms_per_frame")
             out["frame1080"] = sharded                         # the north star's 8-GPU split (not `value`)
+        if world == 1 and not args.no_dropin:
+            out["drop_in_step"] = drop_in_step(dev, ms)        # the reference's own operator sequence on the installed backends (not `value`)
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
             out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)

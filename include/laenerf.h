@@ -406,7 +406,10 @@ LAE_API int lae_sh_encode_backward(const float* grad, const float* inputs, uint3
 /* ------------------------------------------------------------------ */
 
 /* ffmlp.cu:635-671  ffmlp_forward(inputs[B,in], weights, B, input_dim, output_dim(=16 padded),
- * hidden_dim, num_layers, activation, output_activation, forward_buffer[num_layers,B,hidden], outputs[B,16]) */
+ * hidden_dim, num_layers, activation, output_activation, forward_buffer[num_layers,B,hidden], outputs[B,16]).
+ * forward_buffer may be NULL.  Round 6: for the shapes the recompute backward serves (hidden 64, ReLU, linear output, 1-2 hidden
+ * GEMMs, input 32 / 48 / 64) in the default mode (lae_ffmlp_set_mode(0)) the buffer is NOT written: lae_ffmlp_backward never reads
+ * it there and the reference's Python only hands it on (ffmlp.py:31-35).  lae_ffmlp_set_mode(1) fills it like the reference. */
 LAE_API int lae_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                       uint32_t activation, uint32_t output_activation, void* forward_buffer,

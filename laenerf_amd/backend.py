@@ -628,12 +628,34 @@ def enable_kernel_timing(on, only=("grid_encode_forward",)):
     where the allocation count trips the collector is an accident of the code that ran before (round 5: bench.py's `roofline`
     moved between 0.38 and 0.32 with unrelated edits)."""
     import gc
-    if on:
-        gc.collect()
+    if on and not _timing["on"]:
+        _timing["gc_was_enabled"] = gc.isenabled()       # restored when the timing is switched off (ADVICE r5): a caller that runs
+        gc.collect()                                     # with the collector off keeps it off
         gc.disable()
-    elif _timing["on"]:
-        gc.enable()
+    elif not on and _timing["on"]:
+        if _timing.pop("gc_was_enabled", True):
+            gc.enable()
     _timing["on"], _timing["only"], _timing["events"] = bool(on), (set(only) if only else None), []
+
+
+class kernel_timing:
+    """`with backend.kernel_timing(only=...):` -- enable_kernel_timing(True, only) on entry, (False) on exit, also when the body
+    raises (the collector state is restored either way); `.result` holds collect_kernel_timing() of the body"""
+
+    def __init__(self, only=("grid_encode_forward",)):
+        self.only, self.result = only, {}
+
+    def __enter__(self):
+        enable_kernel_timing(True, only=self.only)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        try:
+            if et is None:
+                self.result = collect_kernel_timing()
+        finally:
+            enable_kernel_timing(False)
+        return False
 
 
 def collect_kernel_timing():

@@ -64,18 +64,31 @@ def needs_build():
 
 
 def build(force=False, verbose=False, out=None, extra_flags=(), packed_fp32=False):
-    """out / extra_flags / packed_fp32=True: probe builds (tools/grid_loop_fault.sh): another library file, never the in-tree default"""
-    global SO
+    """out / extra_flags / packed_fp32=True: probe builds (tools/grid_loop_fault.sh) -- another library file, never the in-tree
+    default: packed_fp32 and LAE_BUILD_PACKED_FP32=1 are honoured only together with `out` (a default library built
+    with them would be newer than its sources and be loaded silently ever after).  The target path is an argument of _build,
+    not a module global: a probe build can run beside an automatic rebuild of the default library."""
+    want_packed = bool(packed_fp32) or os.environ.get("LAE_BUILD_PACKED_FP32") == "1"
     if out is not None:
-        saved, SO = SO, os.path.abspath(out)
-        try:
-            os.makedirs(os.path.dirname(SO), exist_ok=True)
-            return _build(verbose, list(extra_flags), packed_fp32)
-        finally:
-            SO = saved
-    if not force and not needs_build():
+        target = os.path.abspath(out)
+        if os.path.realpath(target) == os.path.realpath(SO) and want_packed:
+            raise RuntimeError("laenerf_amd.build: the packed-fp32 probe build must not replace the default library; pick another --out")
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        return _build(verbose, list(extra_flags), want_packed, target)
+    if want_packed:
+        raise RuntimeError("laenerf_amd.build: packed_fp32 / LAE_BUILD_PACKED_FP32=1 need out=<another library file> "
+                           "(`python -m laenerf_amd.build --out lib.so --packed-fp32`); the default library never has packed-fp32 code")
+    if not force and not needs_build() and not default_is_packed():
         return SO
-    return _build(verbose, [], packed_fp32)
+    return _build(verbose, [], False, SO)
+
+
+def default_is_packed(so=None):
+    """True when the record next to the (default) library says it was built WITH packed-fp32 instructions"""
+    try:
+        return bool(json.load(open((so or SO) + ".isa.json")).get("packed_fp32_ops"))
+    except (OSError, ValueError):
+        return False
 
 
 def _run(cmd, verbose, what):
@@ -114,11 +127,9 @@ def _compile_one(src, obj, flags, verbose, packed_fp32):
                 os.remove(f)
 
 
-def _build(verbose, more, packed_fp32):
+def _build(verbose, more, packed_fp32, SO):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("LAE_BUILD_EXTRA_FLAGS", "").split() + more      # probes only (e.g. -DLAE_GRID_STAMPS, tools/grid_bwd_stamps.py)
-    if os.environ.get("LAE_BUILD_PACKED_FP32") == "1":                      # probes only: the compiler's default code (tools/grid_loop_fault.sh)
-        packed_fp32 = True
     os.makedirs(LIBDIR, exist_ok=True)
     tag = f"{os.getpid()}.{abs(hash(SO)) % 100000}"                         # per-process, per-target object names: concurrent builds do not share files
     objs = [os.path.join(LIBDIR, f"{src.rsplit('.', 1)[0]}.{tag}.o") for src in SOURCES]

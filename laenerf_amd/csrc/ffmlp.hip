@@ -1758,6 +1758,10 @@ int forward_any(const void* inputs, const void* weights, uint32_t B, uint32_t in
     const uint32_t nh = num_layers - 1;
     if (hidden == 64 && act == LAE_ACT_RELU && out_act == 6 && (nh == 1 || nh == 2) && (in_dim == 32 || in_dim == 48 || in_dim == 64) &&
         g_ffmlp_mode != 1) {                                  // weights in LDS (< 48 KiB: no attribute needed)
+        // these are exactly the shapes lae_ffmlp_backward serves with the recompute backward, which never reads forward_buffer
+        // (nor does the reference's Python, ffmlp.py:31-35): in this mode the buffer is left untouched -- 256 / 384 bytes per row
+        // that the drop-in step (reference wrappers: the buffer is always passed) would write for nothing
+        fb = nullptr;
         if (in_dim == 32) nh == 1 ? launch_fwd64<2, 1>(in, W, B, fb, out, s) : launch_fwd64<2, 2>(in, W, B, fb, out, s);
         else if (in_dim == 48) nh == 1 ? launch_fwd64<3, 1>(in, W, B, fb, out, s) : launch_fwd64<3, 2>(in, W, B, fb, out, s);
         else nh == 1 ? launch_fwd64<4, 1>(in, W, B, fb, out, s) : launch_fwd64<4, 2>(in, W, B, fb, out, s);

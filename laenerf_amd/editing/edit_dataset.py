@@ -33,7 +33,7 @@ def min_dist_to_points(pts, points, max_dist):
     _lib.need_cuda(pts, points)
     n, m = pts.shape[0], points.shape[0]
     out = torch.empty(n, dtype=torch.float32, device=pts.device)
-    d_max = torch.empty(1, dtype=torch.float32, device=pts.device)
+    d_max = torch.zeros(1, dtype=torch.float32, device=pts.device)       # n == 0: the kernel does not run, the maximum of nothing is 0
     scratch = torch.empty(max(n, 1), dtype=torch.int32, device=pts.device)
     _lib.check(_lib.load().lae_min_dist_to_points(_lib.ptr(pts), n, _lib.ptr(points) if m else None, m, float(max_dist), _lib.ptr(out), _lib.ptr(d_max),
                                                   _lib.ptr(scratch), _lib.stream()), "min_dist_to_points")

@@ -97,8 +97,13 @@ class _palette_point_loss(Function):
         P, active_mask, M, lw, reg_w = ctx.meta
         g_wl, g_ol = torch.empty_like(w_logits), torch.empty_like(o_raw)
         owner = ctx.palette_param
-        direct = owner is not None and owner.grad is not None and owner.grad.dtype == torch.float32 and owner.grad.is_contiguous() \
-            and owner.grad.shape == palette.shape
+        # the in-kernel add into palette.grad happens only inside FusedAdam.backward() and for a parameter nobody hooked: everyone else
+        # (torch.autograd.grad, tensor / post-accumulate hooks, gradient all-reduce hooks, a second pass with retain_graph) gets the
+        # gradient from autograd as usual
+        from ..optim import _direct_grad
+        direct = owner is not None and _direct_grad["depth"] > 0 and owner.grad is not None and owner.grad.dtype == torch.float32 \
+            and owner.grad.is_contiguous() and owner.grad.shape == palette.shape and not owner._backward_hooks \
+            and not getattr(owner, "_post_accumulate_grad_hooks", None)
         g_pal = owner.grad if direct else torch.empty_like(palette)
         _backend.style_loss_backward(w_logits, o_raw, palette, P, active_mask, M, target, fin, g_loss.float().reshape(1).contiguous(), lw,
                                      g_wl, g_ol, g_pal, reg_w=reg_w, accumulate=direct)

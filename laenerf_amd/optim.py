@@ -25,6 +25,10 @@ from .ffmlp import FFMLP
 from .gridencoder import GridEncoder
 
 
+# > 0 while a FusedAdam.backward() is running its autograd pass (see there); read by laenerf_amd.editing.style_encoder
+_direct_grad = {"depth": 0}
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, param_groups=None,
                  grad_scaler=True, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
@@ -96,7 +100,14 @@ class FusedAdam(torch.optim.Optimizer):
             one = cache[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
             from .raymarching.raymarching import register_unit_root_grad
             register_unit_root_grad(one)                   # the fused criterion node skips the multiplication by it
-        loss.backward(gradient=one)
+        # fused criterion nodes may add a small fp32 gradient straight into a parameter's persistent .grad (style_encoder.
+        # _palette_point_loss) -- only inside THIS backward: torch.autograd.grad(), hooks and retain_graph users go through a plain
+        # loss.backward() / autograd.grad() and get the gradient from autograd as usual
+        _direct_grad["depth"] += 1
+        try:
+            loss.backward(gradient=one)
+        finally:
+            _direct_grad["depth"] -= 1
         self.finish_loss()
 
     @staticmethod

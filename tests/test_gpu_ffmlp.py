@@ -28,8 +28,20 @@ def test_ffmlp_forward_backward(O, IN, H, NL, B):
     Wh, Xh = O.to_f16_bits(W), O.to_f16_bits(X)
     ref_out, ref_fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL)
     out = torch.empty(B, 16, device=DEV, dtype=torch.half); fb = torch.empty(NL, B, H, device=DEV, dtype=torch.half)
-    F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, fb, out)
-    assert close_f16(N(fb), O.from_f16_bits(ref_fb)) and close_f16(N(out), O.from_f16_bits(ref_out))
+    # the reference fills forward_buffer (ffmlp.cu:635-671): mode 1 does for every shape; the default mode leaves it untouched for
+    # the shapes whose backward recomputes the activations (include/laenerf.h lae_ffmlp_forward) and fills it for the others
+    recompute = F.fused_backward_available(IN, H, NL, 0)
+    try:
+        F.ffmlp_set_mode(1)
+        F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, fb, out)
+        assert close_f16(N(fb), O.from_f16_bits(ref_fb)) and close_f16(N(out), O.from_f16_bits(ref_out))
+    finally:
+        F.ffmlp_set_mode(0)
+    out0 = torch.empty_like(out); fb0 = torch.full_like(fb, -7.0)
+    F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, fb0, out0)
+    assert close_f16(N(out0), O.from_f16_bits(ref_out))
+    assert bool((fb0 == -7.0).all()) if recompute else close_f16(N(fb0), O.from_f16_bits(ref_fb))
+    out = out0
     out_i = torch.empty(B, 16, device=DEV, dtype=torch.half)
     F.ffmlp_inference(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, 0, 6, None, out_i)
     assert torch.equal(out_i, out)
@@ -69,7 +81,11 @@ def test_ffmlp_activations(O, act):
     Wh = O.to_f16_bits(rng.uniform(-0.2, 0.2, nW).astype(np.float32)); Xh = O.to_f16_bits(rng.uniform(-1, 1, (B, IN)).astype(np.float32))
     ref_out, ref_fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL, activation=act)
     out = torch.empty(B, 16, device=DEV, dtype=torch.half); fb = torch.empty(NL, B, H, device=DEV, dtype=torch.half)
-    F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, act, 6, fb, out)
+    try:
+        F.ffmlp_set_mode(1 if act == 0 else 0)           # ReLU at this shape: only mode 1 fills forward_buffer (include/laenerf.h)
+        F.ffmlp_forward(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, act, 6, fb, out)
+    finally:
+        F.ffmlp_set_mode(0)
     assert close_f16(N(out), O.from_f16_bits(ref_out)) and close_f16(N(fb), O.from_f16_bits(ref_fb))
 
 

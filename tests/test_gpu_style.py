@@ -399,3 +399,36 @@ def test_round5_entry_points_refuse_bad_arguments():
     probe = R.render_frame_probe()
     assert set(probe) == {"in_use", "handshake_us"} and len(probe["handshake_us"]) == 5
     torch.cuda.synchronize()
+
+
+def test_palette_gradient_reaches_autograd_users_outside_the_fused_backward():
+    """the in-kernel add into the palette's persistent `.grad` is taken only inside FusedAdam.backward() and for a
+    parameter without hooks; torch.autograd.grad() returns the gradient (and leaves `.grad` alone), a tensor hook fires, and both see
+    the values the direct path adds."""
+    from laenerf_amd.optim import FusedAdam
+    m, params = make_model()
+    m.train()
+    opt = FusedAdam(m, param_groups=m.get_params(1e-3), betas=(0.9, 0.999), eps=1e-8, init_scale=64.0)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.rand(2048, 3, device=DEV, generator=g) - 0.5) * 1.2
+    d = torch.nn.functional.normalize(torch.randn(2048, 3, device=DEV, generator=g), dim=-1)
+    tgt = torch.rand(2048, 3, device=DEV, generator=g)
+
+    def loss_of():
+        with torch.autocast("cuda", dtype=torch.float16):
+            return m.forward_train_loss(x, d, tgt, params, opt, with_palet_loss=True)[0]
+    opt.backward(loss_of())                                    # direct path: the criterion adds into .grad itself
+    direct = m.color_palette.grad.clone()
+    assert float(direct.abs().sum()) > 0
+    m.color_palette.grad.zero_()
+    before = m.color_palette.grad.clone()
+    got, = torch.autograd.grad(loss_of(), m.color_palette)     # not inside FusedAdam.backward: autograd returns it ...
+    assert got is not None and torch.equal(got, direct)
+    assert torch.equal(m.color_palette.grad, before)           # ... and .grad was not touched
+    seen = []
+    h = m.color_palette.register_hook(lambda gr: seen.append(gr.clone()))
+    try:
+        opt.backward(loss_of())                                # a hooked parameter: through AccumulateGrad, the hook fires
+    finally:
+        h.remove()
+    assert len(seen) == 1 and torch.equal(seen[0], direct) and torch.equal(m.color_palette.grad, direct)

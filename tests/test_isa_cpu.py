@@ -5,6 +5,8 @@ profiles/r5_suite_beside_mfma.txt).  The compiler emits such forms for ordinary 
 empirically, so the library is built WITHOUT packed-fp32 instructions (laenerf_amd/build.py).  These tests pin the build's check
 and scan the SHIPPED code object with an independent pattern (tools/isa_pk_opsel_scan.py)."""
 import json
+
+import pytest
 import os
 import sys
 
@@ -51,3 +53,22 @@ def test_shipped_code_object_has_no_packed_fp32_instruction(hip_lib):
     assert counts.get("packed_fp32", 0) == 0
     meta = json.load(open(_lib.SO_PATH + ".isa.json"))
     assert meta["packed_fp32_ops"] is False and meta["total"] == 0
+
+
+def test_packed_fp32_build_never_targets_the_default_library(monkeypatch):
+    """packed_fp32 / LAE_BUILD_PACKED_FP32=1 are probe-build switches: refused without out=<another file> and for
+    out=<the default library>; nothing is compiled before the refusal"""
+    from laenerf_amd import build
+    called = []
+    monkeypatch.setattr(build, "_build", lambda *a, **k: called.append(a))
+    with pytest.raises(RuntimeError):
+        build.build(packed_fp32=True)
+    with pytest.raises(RuntimeError):
+        build.build(out=build.SO, packed_fp32=True)
+    monkeypatch.setenv("LAE_BUILD_PACKED_FP32", "1")
+    with pytest.raises(RuntimeError):
+        build.build(force=True)
+    assert not called
+    build.build(out="/tmp/lae_probe_never_built.so")          # with out= the variable is honoured: _build(verbose, flags, packed, target)
+    assert len(called) == 1 and called[0][2] is True and called[0][3] == "/tmp/lae_probe_never_built.so"
+    assert build.default_is_packed() is False                 # the shipped library's record
