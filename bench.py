@@ -309,7 +309,7 @@ def sharded_frame1080(world, rank, dev, backend_name, steps, warmup, with_n1=Fal
     # rows per iteration of the device-resident loop: the reference's rule sizes an iteration by the rays of THE CALL
     # (n_step = max(min(N // n_alive, 8), 1), renderer.py:363), so a rank holding 1/W of the rays would run the whole frame's
     # iteration count on 1/W of the work per iteration -- 177 launch-chain latencies for a ninth of the samples (`frame1080.
-    # shard_of_8.reference_schedule_ms` of the N = 1 line).  With W > 1 every rank therefore takes the WHOLE frame's row budget
+    # shards_of_8.reference_rule` of the N = 1 line).  With W > 1 every rank therefore takes the WHOLE frame's row budget
     # (row_budget = W x its rays): same per-ray sample sequences, <= 1e-5 image difference (rays_t rounding at other boundaries:
     # tests/test_gpu_frame.py::test_frame_loop_row_budget), a few times fewer iterations.  LAE_FRAME_REFERENCE_SCHEDULE=1 keeps
     # the reference's rule on every rank.
@@ -399,10 +399,11 @@ def frame_workload(args, world, rank, dev, backend_name):
 def frame1080(dev, frames=5):
     """configs[3] on ONE GPU, inside the default line so that the driver times it: the 1920x1080 bonsai-shaped frame of
     `--workload frame1080` (bound 2, 2 cascades, 6 328 848-entry table, camera inside the box) through
-    dist.render_frame_sharded at W = 1, median of `frames` frames after two warm-ups; plus ONE rank's share of an 8-way split
-    (tiles 0, 8, 16, ...: what each of 8 GPUs would render before the 5.18 MB all-gather) timed alone on this GPU."""
+    dist.render_frame_sharded at W = 1, median of `frames` frames after two warm-ups; plus EVERY rank's share of an 8-way split
+    (rank r: tiles r, r + 8, r + 16, ...: what each of 8 GPUs would render before the 5.18 MB all-gather) timed alone on this GPU,
+    one after the other, and the exchange around it (frame_exchange)."""
     from laenerf_amd import synthetic as S
-    from laenerf_amd.dist import render_frame_sharded, render_shard
+    from laenerf_amd.dist import render_frame_sharded
     net, r = eval_model(dev, bound=2, seed=1234)
     H, W = 1080, 1920
     o, d = S.frame_rays(H, W, focal=1111.1 * H / 800, radius=1.6)
@@ -437,14 +438,25 @@ def frame1080(dev, frames=5):
     budget["rows"] = 0
     best_key = min(boosted, key=lambda k: boosted[k]["ms"])
     best_ms = min(t * 1e3, boosted[best_key]["ms"])
-    from laenerf_amd.dist import pixel_tile_order
-    order = pixel_tile_order((H, W), dev)                      # a rank's shard = its tiles of the pixel-tile ray order
-    ot, dt_ = o[order[0]], d[order[0]]
-    t8, _ = timed(lambda: render_shard(render, ot, dt_, 0, 8))
-    ref8 = dict(stats)
-    budget["rows"] = H * W                                     # the whole frame's row budget on the shard (what --gpus 8 runs)
-    t8b, _ = timed(lambda: render_shard(render, ot, dt_, 0, 8))
+    # ---- all eight shards of an 8-way split, one after the other on this one GPU: what each of 8 GPUs would
+    # render before the all-gather; the projection rests on the SLOWEST one plus the measured exchange
+    from laenerf_amd.dist import frame_plan
+    shards = {"boosted": [], "reference_rule": []}
+    for rk in range(8):
+        take = frame_plan(H * W, rk, 8, dev, (H, W))["take"]
+        ot, dt_ = o[take], d[take]
+        for mode, rows in (("reference_rule", 0), ("boosted", H * W)):      # boosted = the whole frame's row budget (what --gpus 8 runs)
+            budget["rows"] = rows
+            tk, _ = timed(lambda: render(ot, dt_))
+            shards[mode].append({"rank": rk, "ms": round(tk * 1e3, 3), "iterations": stats["iterations"], "samples": stats["rows"]})
     budget["rows"] = 0
+
+    def spread(key, mode):
+        v = [e[key] for e in shards[mode]]
+        return {"max": max(v), "mean": round(float(np.mean(v)), 3), "min": min(v)}
+    exch = frame_exchange(dev, H, W)
+    slow_b, slow_r = spread("ms", "boosted")["max"], spread("ms", "reference_rule")["max"]
+    ex_ms = exch.get("total_ms_per_frame", 0.0) or 0.0
     return {"ms_per_frame": round(t * 1e3, 2), "rays": H * W, "Mrays_per_s": round(H * W / t / 1e6, 2),
             "iterations": whole["iterations"], "samples_through_network": whole["rows"],
             "Msamples_per_s": round(whole["rows"] / t / 1e6, 1),
@@ -452,20 +464,89 @@ def frame1080(dev, frames=5):
             "reference_schedule_ms": round(t * 1e3, 2), "row_budget_ms": boosted,
             "best_n1_ms_per_frame": round(best_ms, 2),
             "best_n1_schedule": ("reference rule (N rows per iteration)" if best_ms == t * 1e3 else f"{best_key} rows per iteration"),
-            "shard_of_8": {"ms": round(t8b * 1e3, 2), "iterations": stats["iterations"], "rays": int(-(-(-(-H * W // 128)) // 8) * 128),
-                           "reference_schedule_ms": round(t8 * 1e3, 2), "reference_schedule_iterations": ref8["iterations"],
-                           "projected_speedup_at_8": {"vs_best_n1": round(best_ms / (t8b * 1e3), 2),
-                                                      "reference_rule_both_sides": round(t / t8, 2),
-                                                      "note": "one GPU's whole-frame time / this shard's time, before the 5.18 MB all-gather; "
-                                                              "`vs_best_n1` divides the fastest one-GPU schedule by the shard on the frame's "
-                                                              "row budget, `reference_rule_both_sides` keeps renderer.py:363's rule on both"},
-                           "note": "rank 0's tiles of an 8-way round-robin split rendered alone on this one GPU, with the whole frame's "
-                                   "row budget per iteration (what `--workload frame1080 --gpus 8` runs per rank) and with the "
-                                   "reference's per-call rule"},
+            "shards_of_8": {"rays_per_shard": int(-(-(-(-H * W // 128)) // 8) * 128),
+                            "boosted_budget": {"ms": spread("ms", "boosted"), "samples": spread("samples", "boosted"),
+                                               "iterations": spread("iterations", "boosted"), "per_rank_ms": [e["ms"] for e in shards["boosted"]]},
+                            "reference_rule": {"ms": spread("ms", "reference_rule"), "iterations": spread("iterations", "reference_rule"),
+                                               "per_rank_ms": [e["ms"] for e in shards["reference_rule"]]},
+                            "note": "every rank's tiles of the 8-way round-robin split of the pixel-tile ray order, rendered alone on this one GPU "
+                                    "(median of 5 each), with the whole frame's row budget per iteration (what `--workload frame1080 --gpus 8` runs "
+                                    "per rank) and with the reference's per-call rule (renderer.py:363)"},
+            "exchange": exch,
+            "projected_speedup_at_8": {"vs_best_n1": round(best_ms / (slow_b + ex_ms), 2),
+                                       "reference_rule_both_sides": round(t * 1e3 / (slow_r + ex_ms), 2),
+                                       "slowest_shard_ms": slow_b, "exchange_ms": round(ex_ms, 3),
+                                       "without_exchange_from_rank0_only": round(best_ms / shards["boosted"][0]["ms"], 2),
+                                       "note": "one GPU's whole-frame time / (SLOWEST of the eight shards + the exchange measured at W = 1 on RCCL: "
+                                               "collective launch, the rank's ray gather, block pack, the gather into the caller's order on the "
+                                               "full-size buffer); the 7-link xGMI transfer of 5.18 MB per rank (~34 us at 7 x 153 GB/s, SURVEY 8e) "
+                                               "is NOT in it: no multi-GPU node.  `vs_best_n1` divides the fastest one-GPU schedule by the boosted "
+                                               "shard, `reference_rule_both_sides` keeps renderer.py:363's rule on both sides"},
             "gather_bytes_per_rank_at_8": int(-(-(-(-H * W // 128)) // 8) * 128 * 5 * 4),
             "note": "configs[3]-shaped (mip360/bonsai) 1080p inference frame, fixed eval model (seed 1234), device-resident loop, "
                     "through dist.render_frame_sharded (W = 1: no exchange); tests/test_gpu_frame1080.py checks the W = 2 / 8 "
                     "partitions against this frame"}
+
+
+def frame_exchange(dev, H, W, reps=20):
+    """what a rank of an 8-way sharded frame does besides rendering, timed on this one GPU (the reference's
+    dormant `dist.all_gather(preds)` + index bookkeeping, nerf/utils.py:1555-1570): (a) gathering its own rays out of the frame
+    (frame_plan `take`), (b) packing image / depth / weights into the [n/8, 5] block, (c) all_gather_into_tensor of that block on
+    RCCL with a ONE-rank group (LAE_DIST_FORCE_COLLECTIVES: the launch and RCCL's own kernel, no wire), (d) the gather of the
+    full-size [8 x n/8, 5] buffer into the caller's ray order (frame_plan `put`).  Median wall time of `reps` synchronised
+    repetitions each."""
+    import torch.distributed as dist
+    from laenerf_amd import dist as D
+    out = {}
+    made_group = False
+    try:
+        if not dist.is_initialized():
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            made_group = True
+        n = H * W
+        plan = D.frame_plan(n, 0, 8, dev, (H, W))
+        o = torch.rand(n, 3, device=dev); d = torch.rand(n, 3, device=dev)
+        ns = plan["n_shard"]
+        img, dep, ws = torch.rand(ns, 3, device=dev), torch.rand(ns, device=dev), torch.rand(ns, device=dev)
+        big = torch.rand(8 * ns, 5, device=dev)
+
+        def med(fn):
+            ts = []
+            for it in range(reps + 3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            return sorted(ts[3:])[reps // 2] * 1e3
+        out["take_rays_ms"] = round(med(lambda: (o[plan["take"]], d[plan["take"]])), 4)
+        out["pack_block_ms"] = round(med(lambda: torch.cat([img, dep[:, None], ws[:, None]], dim=1)), 4)
+        block = torch.cat([img, dep[:, None], ws[:, None]], dim=1)
+        was = D.FORCE_COLLECTIVES
+        D.FORCE_COLLECTIVES = True
+        try:
+            out["all_gather_w1_rccl_ms"] = round(med(lambda: D.exchange_blocks(block, 1)), 4)
+        finally:
+            D.FORCE_COLLECTIVES = was
+        out["put_full_frame_ms"] = round(med(lambda: big[plan["put"]]), 4)
+        # the sync + wall clock of one empty repetition is in every figure above: measure and subtract it once from the total
+        empty = med(lambda: None)
+        parts = [out["take_rays_ms"], out["pack_block_ms"], out["all_gather_w1_rccl_ms"], out["put_full_frame_ms"]]
+        out["sync_overhead_ms"] = round(empty, 4)
+        out["total_ms_per_frame"] = round(sum(max(p_ - empty, 0.0) for p_ in parts), 4)
+        out["backend"] = dist.get_backend()
+        out["note"] = "one-rank RCCL group on this GPU: launch + local copy of the collective, no xGMI transfer"
+    except Exception as ex:                                      # a diagnostic must never take the line down
+        out["error"] = repr(ex)
+    finally:
+        if made_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    return out
 
 
 def grid_update(dev):

@@ -61,16 +61,7 @@ def deinterleave(gathered, n_rays, world_size, tile=TILE):
 def gather_frame(local_block, n_rays, rank, world_size, tile=TILE, group=None):
     """local_block [n_shard, K] (rows in shard_indices order) -> full [n_rays, K] on every rank: ONE all_gather_into_tensor
     (RCCL over xGMI: every rank ships its block to its 7 peers over 7 links) + the de-interleave."""
-    local_block = local_block.contiguous()
-    if not _exchange(world_size):
-        return deinterleave(local_block.unsqueeze(0), n_rays, 1, tile)
-    dev = local_block.device
-    rehearsal = local_block.is_cuda and dist.get_backend(group) == "gloo"    # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
-    src = local_block.cpu() if rehearsal else local_block
-    out = torch.empty((world_size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)   # rank-major
-    dist.all_gather_into_tensor(out, src, group=group)
-    out = out.view((world_size,) + tuple(src.shape))
-    return deinterleave(out.to(dev) if rehearsal else out, n_rays, world_size, tile)
+    return deinterleave(exchange_blocks(local_block, world_size, group), n_rays, world_size, tile)
 
 
 def render_shard(render_fn, rays_o, rays_d, rank, world_size):
@@ -113,19 +104,70 @@ def pixel_tile_order(image_hw, device, tile_hw=PIXEL_TILE):
     return _tile_cache[key]
 
 
+_plan_cache = {}
+
+
+def frame_plan(n_rays, rank, world_size, device, image_hw=None, tile=TILE):
+    """the two index vectors of a sharded frame, composed once per (frame size, rank, world) and kept on the device:
+    `take` [n_shard]: the caller's ray ids this rank renders (its 128-ray tiles of the pixel-tile order when image_hw = (H, W)
+    divides into 8 x 8 tiles, of the caller's order otherwise; padding rows repeat ray 0);
+    `put` [n_rays]: row of the rank-major all-gather buffer that holds the caller's ray q -- the de-interleave of the tiles and the
+    way back from pixel-tile order as ONE gather.  Round 6: before, every rank gathered the WHOLE frame's rays into tile order, then
+    its shard from that, and undid the two permutations with a strided copy and a second full-frame gather."""
+    hw = tuple(image_hw) if image_hw is not None and image_hw[0] * image_hw[1] == n_rays else None
+    key = (n_rays, rank, world_size, tile, str(device), hw)
+    plan = _plan_cache.get(key)
+    if plan is None:
+        if len(_plan_cache) > 64:
+            _plan_cache.clear()
+        order = pixel_tile_order(hw, device) if hw is not None else None
+        n_tiles = (n_rays + tile - 1) // tile
+        per_rank = (n_tiles + world_size - 1) // world_size
+        n_shard = per_rank * tile
+        j = torch.arange(n_shard, device=device)
+        pos = ((j // tile) * world_size + rank) * tile + j % tile          # position in the (tile-ordered) frame of this rank's row j
+        pos_c = pos.clamp(max=n_rays - 1)
+        take = order[0][pos_c] if order is not None else pos_c
+        take = torch.where(pos < n_rays, take, torch.zeros_like(take))
+        # all ranks' rows: g = r * n_shard + j  <->  frame position ((j // tile) * W + r) * tile + j % tile
+        g = torch.arange(world_size * n_shard, device=device)
+        r_, j_ = g // n_shard, g % n_shard
+        p_all = ((j_ // tile) * world_size + r_) * tile + j_ % tile
+        valid = p_all < n_rays
+        put = torch.empty(n_rays, dtype=torch.long, device=device)
+        q = order[0][p_all[valid]] if order is not None else p_all[valid]
+        put[q] = g[valid]
+        plan = _plan_cache[key] = {"take": take, "put": put, "n_shard": n_shard}
+    return plan
+
+
 def render_frame_sharded(render_fn, rays_o, rays_d, rank, world_size, group=None, image_hw=None):
     """render_fn(rays_o, rays_d) -> dict(image [n,3], depth [n], weights_sum [n]); returns the full frame dict in the caller's ray
     order.  image_hw = (H, W): the rays are the pixels of one image in scanline order -- they are dealt to the ranks (and rendered)
-    in 2-D pixel-tile order (pixel_tile_order); per-ray results do not depend on the order."""
+    in 2-D pixel-tile order (pixel_tile_order); per-ray results do not depend on the order.  Per frame and rank: one gather of the
+    rank's own rays, the render, one `cat` into the [n_shard, 5] block, ONE all_gather_into_tensor, one gather into the caller's
+    order (frame_plan)."""
     n = rays_o.shape[0]
-    order = pixel_tile_order(image_hw, rays_o.device) if image_hw is not None and image_hw[0] * image_hw[1] == n else None
-    if order is not None:
-        rays_o, rays_d = rays_o.reshape(-1, 3)[order[0]], rays_d.reshape(-1, 3)[order[0]]
-    block = render_shard(render_fn, rays_o, rays_d, rank, world_size)
-    full = gather_frame(block, n, rank, world_size, group=group)
-    if order is not None:
-        full = full[order[1]]
+    plan = frame_plan(n, rank, world_size, rays_o.device, image_hw)
+    take = plan["take"]
+    res = render_fn(rays_o.reshape(-1, 3)[take], rays_d.reshape(-1, 3)[take])
+    block = torch.cat([res["image"].float(), res["depth"].float()[:, None], res["weights_sum"].float()[:, None]], dim=1)
+    full = exchange_blocks(block, world_size, group).reshape(-1, block.shape[1])[plan["put"]]
     return {"image": full[:, :3], "depth": full[:, 3], "weights_sum": full[:, 4]}
+
+
+def exchange_blocks(local_block, world_size, group=None):
+    """[n_shard, K] on every rank -> [W, n_shard, K] rank-major on every rank: the ONE collective of a sharded frame"""
+    local_block = local_block.contiguous()
+    if not _exchange(world_size):
+        return local_block.unsqueeze(0)
+    dev = local_block.device
+    rehearsal = local_block.is_cuda and dist.get_backend(group) == "gloo"    # CPU rehearsal of the RCCL path (tests, 1-GPU boxes)
+    src = local_block.cpu() if rehearsal else local_block
+    out = torch.empty((world_size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)   # rank-major
+    dist.all_gather_into_tensor(out, src, group=group)
+    out = out.view((world_size,) + tuple(src.shape))
+    return out.to(dev) if rehearsal else out
 
 
 @torch.no_grad()
