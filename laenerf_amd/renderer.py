@@ -353,8 +353,13 @@ class NeRFRenderer(nn.Module):
             return {k: (v[inv] if torch.is_tensor(v) and v.shape[:1] == inv.shape else v) for k, v in res.items()}
         """frame_loop=True (default, when the model is the default architecture under fp16 autocast): the whole loop runs
         as ONE backend call with its state on the device (lae_render_frame).  frame_loop=False: the reference's loop,
-        operator by operator, with one host read of n_alive per iteration.  row_budget (frame loop only): rows per
-        iteration, 0 = N as in the reference (`n_step = max(min(N // n_alive, 8), 1)`, renderer.py:363).  max_n_step: the 8 of
+        operator by operator, with one host read of n_alive per iteration.  row_budget (both loops; the same schedule, so the
+        same bits: tests/test_gpu_frame_fuzz.py): rows per iteration, 0 = N as in the reference (`n_step = max(min(N // n_alive, 8),
+        1)`, renderer.py:363).  A larger budget keeps every ray's sample sequence up to the rounding of rays_t EXCEPT (a) for rays
+        still alive at the `step < max_steps` cutoff (what a survivor has received by then depends on the schedule, in the reference
+        as well) and (b) with perturb=True: the jitter moves only the samples of the FIRST march call and is dropped from rays_t
+        afterwards (`last_t = t` after the jitter, raymarching.cu:747-749), so how many samples carry it is that call's n_step -- 1
+        under the reference's rule, up to max_n_step under a boosted budget.  max_n_step: the 8 of
         that rule; with 1 every iteration takes ONE sample per alive ray, so a ray's result no longer depends on how many
         other rays share the call (the reference's schedule ties `rays_t` rounding to N: a sharded frame differs from the
         whole one by <= 1e-5; with max_n_step=1 the two are the same bits, tests/test_gpu_frame1080.py)."""
@@ -373,8 +378,11 @@ class NeRFRenderer(nn.Module):
         rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
         rays_t = nears.clone()
         step = 0
+        iterations = rows = 0
+        budget = max(N, int(row_budget))                                             # rows per iteration; the reference: N
         while step < max_steps and n_alive > 0:
-            n_step = max(min(N // n_alive, max_n_step), 1)                           # renderer.py:363 (max_n_step = 8)
+            n_step = max(min(budget // n_alive, max_n_step), 1)                      # renderer.py:363 (budget = N, max_n_step = 8)
+            iterations += 1; rows += n_alive * n_step
             xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
                                                         grid, self.cascade, self.grid_size, nears, fars, 128,
                                                         perturb if step == 0 else False, dt_gamma, max_steps)
@@ -392,7 +400,14 @@ class NeRFRenderer(nn.Module):
         image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
         if scale_depth:
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        return {"image": image, "depth": depth, "weights_sum": weights_sum}
+        out = {"image": image, "depth": depth, "weights_sum": weights_sum}
+        if want_stats:
+            # alive_at_end > 0: the loop ended at the `step < max_steps` cutoff with rays still marching.  What such a ray has
+            # received by then (sum of the iterations' n_step, between max_steps and max_steps + 7) depends on the SCHEDULE --
+            # in the reference too (n_step follows N // n_alive) -- so only then does a boosted row budget change more than the
+            # rounding of rays_t (tests/test_gpu_frame_fuzz.py)
+            out["stats"] = {"iterations": iterations, "rows": rows, "steps": step, "alive_at_end": n_alive}
+        return out
 
     # ------------------------------------------------------------------ distillation render (renderer.py:394-480)
     @torch.no_grad()

@@ -1,0 +1,182 @@
+"""-m gpu: randomized differential test of the device-resident frame loop (`lae_render_frame`: lookahead marcher on a side stream,
+poll / poison hand-over, admission control, overflow launches, emit8, row budgets, degrade path) against the operator loop it must
+equal -- march_rays / network / composite_rays / compaction driven from Python, one host read per iteration, the reference's loop
+(nerf/renderer.py:335-387; run_cuda_distill :394-480).  300 seeded draws (hypothesis, derandomized) of: ray count, bound /
+cascades, occupancy pattern, table amplitude (how early rays saturate), T_thresh, perturb, max_steps, max_n_step, row budget,
+ray order (scanline / pixel tiles), caller stream (default / a side stream), distillation with a random edit grid (+ grow grid).
+
+Bar: bit-identical image / depth / weights (and weights_edit / depth_edit) in every draw -- the operator loop takes the same row
+budget (n_step = max(min(max(N, row_budget) // n_alive, max_n_step), 1) in both), so the two run the same iterations.
+Counter-examples found while writing this file are kept as fixed cases at the bottom."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from gpu_util import DEV, N, T
+
+pytestmark = pytest.mark.gpu
+
+_models = {}
+_streams = []
+
+
+def model(bound, amp):
+    """one small-table model per (bound, table amplitude); the occupancy bitfield is set per draw"""
+    key = (bound, amp)
+    if key not in _models:
+        from laenerf_amd.network import NeRFNetwork
+        from laenerf_amd.renderer import NeRFRenderer
+        torch.manual_seed(17 * bound + int(amp * 100))
+        net = NeRFNetwork(bound=bound, log2_hashmap_size=14).to(DEV)
+        net.encoder.embeddings.data.uniform_(-amp, amp)
+        r = NeRFRenderer(net, bound=bound, min_near=0.2).to(DEV)
+        net.eval(); r.eval()
+        _models[key] = r
+    return _models[key]
+
+
+def occupancy(kind, C, bound, p, seed):
+    from laenerf_amd import synthetic as S
+    n_bytes = C * 128 ** 3 // 8
+    rng = np.random.default_rng(seed)
+    if kind == "empty":
+        return np.zeros(n_bytes, np.uint8)
+    if kind == "full":
+        return np.full(n_bytes, 255, np.uint8)
+    if kind == "random":                                      # every cell occupied with probability p (no spatial coherence at all)
+        return np.packbits(rng.random(n_bytes * 8) < p, bitorder="little")
+    grid = S.sphere_density_grid(cascade=C, bound=float(bound), boxes=(kind == "boxes"), radius=0.6 if kind == "boxes" else 0.45)
+    return S.pack_bits_np(grid, 10.0)
+
+
+def side_stream(i):
+    while len(_streams) < 2:
+        _streams.append(torch.cuda.Stream())
+    return _streams[i % 2]
+
+
+draw = st.fixed_dictionaries({
+    "n": st.one_of(st.integers(1, 300), st.integers(301, 9000), st.integers(9001, 60000)),
+    "bound": st.sampled_from([1, 1, 2, 4]),
+    "occ": st.sampled_from(["sphere", "boxes", "random", "random", "empty", "full"]),
+    "p": st.floats(0.0, 0.5),
+    "amp": st.sampled_from([0.05, 0.5, 2.0]),
+    "T_thresh": st.sampled_from([1e-4, 1e-2, 0.3]),
+    "perturb": st.booleans(),
+    "max_steps": st.sampled_from([16, 64, 1024]),
+    "max_n_step": st.sampled_from([1, 2, 8, 8]),
+    "budget_k": st.sampled_from([0, 1, 3, 8]),
+    "tiled": st.booleans(),
+    "stream": st.sampled_from([None, 0, 1]),
+    "distill": st.sampled_from([0, 0, 1, 2]),                 # 0 = run_cuda, 1 = run_cuda_distill, 2 = distill through the grow grid
+    "seed": st.integers(0, 2 ** 20),
+    "bg": st.sampled_from(["white", "rgb", "per_ray"]),
+})
+
+
+def run_case(c):
+    from laenerf_amd import synthetic as S
+    from laenerf_amd.backend import raymarching_backend as rb
+    bound, n = c["bound"], c["n"]
+    r = model(bound, c["amp"])
+    C = r.cascade
+    bits = occupancy(c["occ"], C, bound, c["p"], c["seed"])
+    r.density_bitfield = T(bits)
+    image_hw = None
+    if c["tiled"] and not c["distill"] and n >= 32:           # rays = the pixels of an H x W image, rendered in 8 x 4 pixel tiles
+        H = 8 * max(1, int(np.sqrt(n) // 8))
+        W = 4 * max(1, n // H // 4)
+        n = H * W
+        o, d = S.frame_rays(H, W, focal=1111.1 * W / 800, radius=3.2 if bound == 1 else 2.6, theta=0.6 + (c["seed"] % 7) * 0.1, phi=0.3 * (c["seed"] % 11))
+        image_hw = (H, W)
+    else:
+        o, d = S.lego_like_rays(n, seed=c["seed"], radius=3.2 if bound == 1 else 2.6)
+    o, d = T(o), T(d)
+    ctx = torch.cuda.stream(side_stream(c["stream"])) if c["stream"] is not None else torch.cuda.stream(torch.cuda.current_stream())
+    if c["stream"] is not None:
+        side_stream(c["stream"]).wait_stream(torch.cuda.current_stream())
+    with ctx, torch.autocast("cuda", dtype=torch.float16):
+        if c["distill"]:
+            rng = np.random.default_rng(c["seed"] + 1)
+            edit = T(bits & np.packbits(rng.random(bits.size * 8) < 0.5, bitorder="little"))      # a random half of the occupied cells
+            kw = dict(perturb=c["perturb"], max_steps=c["max_steps"], T_thresh=c["T_thresh"], grow_grid=(c["distill"] == 2))
+            torch.manual_seed(c["seed"])
+            a = r.render_distill(o, d, edit, frame_loop=False, **kw)
+            torch.manual_seed(c["seed"])
+            b = r.render_distill(o, d, edit, frame_loop=True, **kw)
+            keys, exact = ("image", "depth", "depth_edit", "weights_edit", "weights", "x_term"), True
+        else:
+            bg = {"white": 1, "rgb": torch.tensor([0.1, 0.5, 0.9], device=DEV),
+                  "per_ray": torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(c["seed"]))}[c["bg"]]
+            if c["bg"] == "per_ray" and image_hw is not None:
+                bg = 1                                        # (render_eval renders per-ray backgrounds in the caller's order only)
+            kw = dict(bg_color=bg, perturb=c["perturb"], max_steps=c["max_steps"], T_thresh=c["T_thresh"], max_n_step=c["max_n_step"],
+                      image_hw=image_hw)
+            torch.manual_seed(c["seed"])
+            a = r.render_eval(o, d, frame_loop=False, want_stats=True, row_budget=c["budget_k"] * n, **kw)
+            torch.manual_seed(c["seed"])
+            b = r.render_eval(o, d, frame_loop=True, want_stats=True, row_budget=c["budget_k"] * n, **kw)
+            keys, exact = ("image", "depth", "weights_sum"), True
+            # both loops follow n_step = max(min(max(N, row_budget) // n_alive, max_n_step), 1): the same iterations, the same bits.
+            # (The first version of this test ran the operator loop on the reference's budget and asked boosted frames for 1e-5: its
+            # first two counter-examples -- a survivor at the max_steps cutoff, and perturb=True under a boosted budget, where the
+            # jitter rides on n_step samples of the first call instead of one -- are schedule properties of the reference's loop, not
+            # of the device loop: renderer.py render_eval's docstring.  Both are fixed cases below.)
+            assert b["stats"]["iterations"] == a["stats"]["iterations"], (a["stats"], b["stats"])
+            st_ = b["stats"]
+            assert 0 <= st_["iterations"] <= c["max_steps"] and st_["iterations_launched"] >= st_["iterations"], st_
+    if c["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(side_stream(c["stream"]))
+    torch.cuda.synchronize()
+    assert rb.render_frame_mode() in (0, 1)
+    for k in keys:
+        x, y = N(a[k]), N(b[k])
+        assert x.shape == y.shape, (k, x.shape, y.shape)
+        nan = np.isnan(x)
+        assert np.array_equal(nan, np.isnan(y)), (k, "NaN pattern", c)          # missed rays: depth 0 / 0 in both loops
+        if exact:
+            assert np.array_equal(x[~nan], y[~nan]), (k, float(np.abs(x[~nan] - y[~nan]).max()), c)
+        else:
+            assert np.abs(x[~nan] - y[~nan]).max(initial=0.0) <= 1e-5, (k, float(np.abs(x[~nan] - y[~nan]).max()), c)
+    return a, b
+
+
+@settings(max_examples=300, deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
+@given(draw)
+def test_frame_loop_fuzz_against_operator_loop(c):
+    run_case(c)
+
+
+# ---- fixed cases: the corners the strategy reaches rarely, pinned so that every run covers them
+FIXED = [
+    # one ray, one cascade, full occupancy, every sample kept until max_steps
+    dict(n=1, bound=1, occ="full", p=0.0, amp=0.05, T_thresh=1e-4, perturb=False, max_steps=1024, max_n_step=8, budget_k=0, tiled=False,
+         stream=None, distill=0, seed=1, bg="white"),
+    # nothing occupied: every ray dead after the first march, depth 0 / 0
+    dict(n=4097, bound=2, occ="empty", p=0.0, amp=0.5, T_thresh=1e-4, perturb=True, max_steps=1024, max_n_step=8, budget_k=8, tiled=False,
+         stream=0, distill=0, seed=2, bg="per_ray"),
+    # three cascades, incoherent occupancy, boosted budget, side stream, pixel tiles
+    dict(n=60000, bound=4, occ="random", p=0.07, amp=2.0, T_thresh=1e-2, perturb=True, max_steps=1024, max_n_step=8, budget_k=3, tiled=True,
+         stream=1, distill=0, seed=3, bg="rgb"),
+    # max_steps below the 8-sample rule's first iteration
+    dict(n=5000, bound=1, occ="boxes", p=0.0, amp=0.5, T_thresh=0.3, perturb=False, max_steps=16, max_n_step=8, budget_k=8, tiled=False,
+         stream=None, distill=0, seed=4, bg="white"),
+    # distillation through the grow grid with an incoherent edit grid
+    dict(n=30000, bound=2, occ="random", p=0.3, amp=0.5, T_thresh=1e-4, perturb=True, max_steps=64, max_n_step=8, budget_k=0, tiled=False,
+         stream=1, distill=2, seed=5, bg="white"),
+    # the first two counter-examples of the fuzz run (see run_case): a survivor at the max_steps cutoff under a boosted budget;
+    # perturb=True under a boosted budget (the jitter rides on the first call's n_step samples)
+    dict(n=1, bound=1, occ="random", p=0.5, amp=0.05, T_thresh=1e-4, perturb=True, max_steps=16, max_n_step=2, budget_k=3, tiled=False,
+         stream=None, distill=0, seed=8654, bg="white"),
+    dict(n=1, bound=1, occ="sphere", p=0.0, amp=0.05, T_thresh=1e-4, perturb=False, max_steps=16, max_n_step=8, budget_k=3, tiled=False,
+         stream=None, distill=0, seed=0, bg="white"),
+    dict(n=777, bound=1, occ="sphere", p=0.0, amp=2.0, T_thresh=1e-4, perturb=False, max_steps=1024, max_n_step=1, budget_k=8, tiled=False,
+         stream=0, distill=1, seed=6, bg="white"),
+]
+
+
+@pytest.mark.parametrize("i", range(len(FIXED)))
+def test_frame_loop_fixed_corner_cases(i):
+    run_case(FIXED[i])
