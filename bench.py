@@ -251,13 +251,14 @@ def eval_model(dev, bound=1, seed=4321):
     return net, r
 
 
-def eval_frame(dev, H=800, W=800):
+def eval_frame(dev, H=800, W=800, density_scale=1.0):
     """whole-frame inference render (the march_rays / composite_rays loop of run_cuda, renderer.py:335-387) of one 800x800
     view with the fixed model of eval_model(); median of 5 frames after one warm-up.  `ms_per_frame`: the loop as
     ONE backend call with its state on the device (lae_render_frame, reference schedule); `operator_loop_ms`: the same
     kernels driven operator by operator from Python like the reference's loop (one host read of n_alive per iteration)."""
     from laenerf_amd import synthetic as S
     net, r = eval_model(dev)
+    r.density_scale = density_scale                           # > 1: a trained-shaped scene (rays saturate at a surface; `eval_frame_surface`)
     o, d = S.frame_rays(H, W)
     o, d = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
 
@@ -279,8 +280,11 @@ def eval_frame(dev, H=800, W=800):
             "operator_loop_ms": round(t_op * 1e3, 2),
             "max_abs_image_diff_vs_operator_loop": float((res["image"] - res_op["image"]).abs().max()),
             "side_stream": _frame_probe(),                       # which side-stream candidate the frame loop chose, and the timed hand-overs
+            "density_scale": density_scale,
             "note": "800x800 inference render of the fixed eval model (seed 4321, default init: independent of --steps), T_thresh 1e-4, "
-                    "device-resident loop (lookahead marcher on a side stream)"}
+                    "device-resident loop (lookahead marcher on a side stream)" +
+                    ("" if density_scale == 1.0 else f"; density scale {density_scale:g} as in edit_extract: rays end at a surface (early-termination "
+                                                     "branches of k_frame_head and the compaction carry the frame)")}
 
 
 def _frame_probe():
@@ -814,24 +818,22 @@ def grouped_pipeline(r, opt, batches, G, groups_ahead=2, ahead_fn=None, step_fn=
     return step, n_samples
 
 
-def flower_step(dev, steps=40, n_rays=4096, G=8):
-    """configs[2] (llff/flower: scripts/configs_llff/flower.sh -- bound 2 -> 2 cascades, offset (0, 0, 1.5): cameras inside
-    the box, min_near 0.2, table of 6 328 848 entries with finest resolution 4096): the same train step as the headline
-    (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam) on forward-facing synthetic rays, through the headline's
-    grouped two-stream pipeline (round 3; round 2 replayed one un-pipelined graph per step).  Extra field, not `value`; also
-    reports the roofline figure of its hash-grid forward (HIP events around the call in 10 eager steps)."""
-    from laenerf_amd import backend, synthetic as S
+def _pipelined_train_step(dev, bound, bitfield_np, make_rays, steps, n_rays, G, seed, with_operator_timing=True):
+    """the headline's train step (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam, grouped two-stream pipeline) on
+    another scene: model of `bound`, occupancy `bitfield_np`, ray batches from make_rays(b).  Returns the timing dict pieces the
+    `flower_step` / `sparse_step` objects are built from."""
+    from laenerf_amd import backend
     from laenerf_amd.network import NeRFNetwork
     from laenerf_amd.optim import FusedAdam
     from laenerf_amd.renderer import NeRFRenderer
-    torch.manual_seed(99)
-    net = NeRFNetwork(bound=2).to(dev)
-    r = NeRFRenderer(net, bound=2, min_near=0.2).to(dev)
-    r.density_bitfield = torch.from_numpy(S.pack_bits_np(S.flower_density_grid(), 10.0)).to(dev)
+    torch.manual_seed(seed)
+    net = NeRFNetwork(bound=bound).to(dev)
+    r = NeRFRenderer(net, bound=bound, min_near=0.2).to(dev)
+    r.density_bitfield = torch.from_numpy(bitfield_np).to(dev)
     opt = FusedAdam(net, param_groups=net.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     batches = []
     for b in range(4 * G):
-        o, d = S.flower_like_rays(n_rays, seed=5 + b)
+        o, d = make_rays(b)
         batches.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev), torch.rand(n_rays, 3, device=dev)))
     net.train()
 
@@ -855,7 +857,7 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
     # one un-pipelined graph (the round-2 figure, for comparison)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        n_one = body(0)
+        body(0)
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -867,28 +869,61 @@ def flower_step(dev, steps=40, n_rays=4096, G=8):
     steps = (steps + G - 1) // G * G
     for i in range(4 * G):
         step(i)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(steps):
-        step(4 * G + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    with backend.kernel_timing(only=None) as kt:
-        for i in range(10):
-            body(i)
-    tm = kt.result
+    wins = []
+    for w in range(3):                                        # three windows, the median counts
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            step(4 * G + w * steps + i)
+        torch.cuda.synchronize()
+        wins.append((time.perf_counter() - t0) / steps)
+    dt = sorted(wins)[1]
+    tm = {}
+    if with_operator_timing:
+        with backend.kernel_timing(only=None) as kt:
+            for i in range(10):
+                body(i)
+        tm = kt.result
     gf = tm.get("grid_encode_forward", {"ms": float("nan"), "units": 0, "calls": 0})
     per_launch = gf["units"] / max(gf["calls"], 1)
     us = gf["ms"] / max(gf["calls"], 1) * 1e3
     gbs = per_launch * GRID_FWD_BYTES_FP16 / (us * 1e-6) / 1e9 if gf["calls"] else float("nan")
     return {"ms_per_step": round(dt * 1e3, 4), "Mrays_per_s": round(n_rays / dt / 1e6, 3), "rays": n_rays,
             "samples_per_step": int(np.mean(n_samples)), "one_graph_per_step_ms": round(dt_one * 1e3, 4),
-            "steps_per_graph_replay": G,
+            "steps_per_graph_replay": G, "windows_ms": [round(v * 1e3, 4) for v in wins],
             "grid_forward": {"avg_launch_us": round(us, 2), "samples_per_launch": int(per_launch), "achieved_GBs": round(gbs, 1),
                              "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_sample": GRID_FWD_BYTES_FP16,
-                             "table_entries": int(net.encoder.embeddings.shape[0]), "finest_resolution": 4096},
-            "operator_ms_per_step": {k: round(v["ms"] / 10, 4) for k, v in sorted(tm.items())},
-            "note": "configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box; grouped two-stream pipeline like the "
-                    "headline (march + counting pass of step k+2 beside shading / backward / Adam of step k)"}
+                             "table_entries": int(net.encoder.embeddings.shape[0]), "finest_resolution": 2048 * bound},
+            "operator_ms_per_step": {k: round(v["ms"] / 10, 4) for k, v in sorted(tm.items())}}
+
+
+def flower_step(dev, steps=40, n_rays=4096, G=8):
+    """configs[2] (llff/flower: scripts/configs_llff/flower.sh -- bound 2 -> 2 cascades, offset (0, 0, 1.5): cameras inside
+    the box, min_near 0.2, table of 6 328 848 entries with finest resolution 4096): the same train step as the headline
+    (march -> encode -> MLPs -> composite -> MSE -> backward -> Adam) on forward-facing synthetic rays, through the headline's
+    grouped two-stream pipeline (round 3; round 2 replayed one un-pipelined graph per step).  Extra field, not `value`; also
+    reports the roofline figure of its hash-grid forward (HIP events around the call in 10 eager steps)."""
+    from laenerf_amd import synthetic as S
+    out = _pipelined_train_step(dev, 2, S.pack_bits_np(S.flower_density_grid(), 10.0), lambda b: S.flower_like_rays(n_rays, seed=5 + b),
+                                steps, n_rays, G, seed=99)
+    out["note"] = ("configs[2]-shaped (llff/flower): bound 2, 2 cascades, cameras inside the box; grouped two-stream pipeline like the "
+                   "headline (march + counting pass of step k+2 beside shading / backward / Adam of step k)")
+    return out
+
+
+def sparse_step(dev, steps=40, n_rays=4096, G=8):
+    """SURVEY 8d's second occupancy preset on the headline's pipeline: configs[1]-shaped model and cameras, "lego-like sparse"
+    bitfield (laenerf_amd.synthetic.lego_sparse_density_grid: 3.05 % of the cells occupied, ~13 samples per ray against the
+    headline's 13 % / ~63).  Extra field, not `value`: with a fifth of the samples the step is bound by its launch chain and the
+    optimizer's pass over the table, not by the sample kernels."""
+    from laenerf_amd import synthetic as S
+    grid = S.lego_sparse_density_grid()
+    out = _pipelined_train_step(dev, 1, S.pack_bits_np(grid, 10.0), lambda b: S.lego_like_rays(n_rays, seed=700 + b, n_views=1),
+                                steps, n_rays, G, seed=77)
+    out["occupied_fraction"] = round(float((grid > 10.0).mean()), 4)
+    out["samples_per_ray"] = round(out["samples_per_step"] / n_rays, 1)
+    out["note"] = ("configs[1] model and cameras on the sparse occupancy preset (3 % of the cells), same grouped two-stream pipeline, "
+                   "optimizer inside; median of three windows")
+    return out
 
 
 class _SegmentProbe:
@@ -1538,12 +1573,14 @@ def main():
             out["drop_in_step"] = drop_in_step(dev, ms)        # the reference's own operator sequence on the installed backends (not `value`)
         if world == 1 and not args.no_frame:
             out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
+            out["eval_frame_surface"] = eval_frame(dev, density_scale=30.0)   # the same frame on a trained-shaped density
             out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)
         if world == 1 and not args.no_style:
             out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
             out["edit_extract"] = edit_extract(dev)            # configs[4] extraction around it (not `value`)
             out["grid_update"] = grid_update(dev)
             out["flower_step"] = flower_step(dev)              # configs[2]-shaped train step (not `value`)
+            out["sparse_step"] = sparse_step(dev)              # the sparse occupancy preset of SURVEY 8d (not `value`)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, host_threads())
             out["cpu_baseline"]["cfg1_run_path"] = cpu_baseline_cfg1(host_threads())
