@@ -75,10 +75,10 @@ extern "C" {
 
 /* library identification: returns the static string "laenerf-hip gfx950 " LAE_ABI_TAG.  The tag changes whenever a
  * signature of this header changes incompatibly (abi2: round 2 added pointer arguments in the middle of the optimizer /
- * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step; abi4: round 4, lae_ffmlp_set_mode values 2 and 16-18 removed; abi5: round 5, lae_render_frame_mode, frame-loop degrade path).  A binding compares
+ * grid-backward / frame entry points; abi3: round 3, optimizer state words and the compositing step; abi4: round 4, lae_ffmlp_set_mode values 2 and 16-18 removed; abi5: round 5, lae_render_frame_mode, frame-loop degrade path; abi6: round 6, lae_render_frame_last_status, lae_ffmlp_forward leaves forward_buffer untouched where the backward recomputes).  A binding compares
  * it with the tag it was written against BEFORE the first call: a stale .so used through newer prototypes would misalign
  * arguments silently (laenerf_amd/_lib.py does, and rebuilds or raises). */
-#define LAE_ABI_TAG "abi5"
+#define LAE_ABI_TAG "abi6"
 LAE_API const char* lae_version(void);
 /* last HIP error string recorded by a failed launch in this thread (or "") */
 LAE_API const char* lae_last_error(void);
@@ -252,6 +252,12 @@ LAE_API int lae_render_frame_set_overlap(int on);
 /* how the most recent frame ran: 1 = lookahead on the side stream, 0 = in line (switched off, probed as not concurrent, or
  * degraded after a time-out); before the first frame: the configured mode */
 LAE_API int lae_render_frame_mode(void);
+/* Round 6.  A cross-stream wait that times out while the host is still inside lae_render_frame makes the call render
+ * the frame again in line.  One that gives up AFTER the call has returned (only possible without stats_out, which waits for the
+ * loop's end) leaves that frame's outputs NaN -- never a wrong image -- and the call has already returned LAE_OK.  After
+ * synchronising the frame's stream: 0 = the most recent frame completed, 1 = it was poisoned by such a time-out (render it again;
+ * the process runs in line from the next frame on), -1 = no frame yet. */
+LAE_API int lae_render_frame_last_status(void);
 /* Which side stream: with the first frame of a caller stream the library times 16 hand-overs caller -> side -> caller through the
  * loop's own store / poll kernels on its highest-priority side stream (or the class LAE_FRAME_SIDE_PRIO names) and, when that
  * stream does not run beside the caller's or is slow (~50 instead of ~11 us per hand-over: which hardware queue picks a dispatch

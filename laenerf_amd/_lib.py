@@ -41,6 +41,7 @@ SIGNATURES = {
     "lae_render_frame_workspace_bytes": [u32, u32, u64],
     "lae_render_frame_set_overlap": [i32],
     "lae_render_frame_mode": [],
+    "lae_render_frame_last_status": [],
     "lae_render_frame_probe_us": [vp, u32],
     "lae_render_frame": [vp, vp, u32, vp, f32, vp, vp, f32, f32, u32, u32, u32, vp, vp, vp, u32, f32, u32, u32, i32, u32, vp, vp, f32, f32,
                          u32, u64, vp, vp, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp, vp],
@@ -116,7 +117,7 @@ _RESTYPES = {
 }
 
 _lib = None
-ABI_TAG = b"abi5"            # include/laenerf.h LAE_ABI_TAG: the prototypes in SIGNATURES are written against this tag
+ABI_TAG = b"abi6"            # include/laenerf.h LAE_ABI_TAG: the prototypes in SIGNATURES are written against this tag
 
 
 def _abi_of(path):

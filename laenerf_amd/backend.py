@@ -352,7 +352,12 @@ class _RayMarching:
                                    float(bg_rgb[1]), float(bg_rgb[2]), int(bool(blend_bg)), int(bool(scale_depth)), ptr(weights_sum),
                                    ptr(depth), ptr(image), ptr(weights_edit), ptr(depth_edit), ptr(ws), ws.numel(),
                                    ctypes.cast(stats, ctypes.c_void_p) if want_stats else None, stream()), "render_frame")
-        return {"iterations": stats[0], "rows": stats[1], "iterations_launched": stats[2]} if want_stats else None
+        if want_stats:
+            # the call waited for the loop's last iteration: a time-out after that point can only be the tail's
+            if lib.lae_render_frame_last_status() == 1:
+                raise RuntimeError("laenerf_amd.render_frame: a cross-stream wait timed out behind the call; the frame's outputs are NaN")
+            return {"iterations": stats[0], "rows": stats[1], "iterations_launched": stats[2]}
+        return None
 
     @staticmethod
     def render_frame_set_overlap(on):
@@ -373,6 +378,20 @@ class _RayMarching:
         """1 while frames overlap their lookahead on the side stream; 0 once switched off, probed as not concurrent, or degraded
         after a cross-stream wait timed out (include/laenerf.h)"""
         return int(_lib.load().lae_render_frame_mode())
+
+    @staticmethod
+    def render_frame_last_status():
+        """after synchronising the frame's stream: 0 = the most recent frame completed, 1 = a cross-stream wait of it timed out after
+        the call had returned (its outputs are NaN: render again), -1 = no frame yet (include/laenerf.h)"""
+        return int(_lib.load().lae_render_frame_last_status())
+
+    @staticmethod
+    def render_frame_check():
+        """synchronise the current stream and raise if the most recent frame was poisoned by a timed-out wait"""
+        torch.cuda.current_stream().synchronize()
+        if _lib.load().lae_render_frame_last_status() == 1:
+            raise RuntimeError("laenerf_amd.render_frame: a cross-stream wait of the most recent frame timed out after the call returned; "
+                               "its outputs are NaN -- render the frame again (the library runs in line from now on)")
 
     # MI355X-native extension (no reference counterpart): device-side alive-list compaction
     @staticmethod
@@ -768,7 +787,8 @@ style_backend = _Style
 for _cls in (_RayMarching, _GridEncoder, _SHEncoder, _FFMLP):
     for _k, _v in list(vars(_cls).items()):
         if isinstance(_v, staticmethod) and not _k.startswith("_") and _k not in ("fused_backward_available", "ffmlp_set_mode", "set_backward_mode",
-                                                                                   "allocate_splitk", "free_splitk"):
+                                                                                   "allocate_splitk", "free_splitk", "render_frame_last_status",
+                                                                                   "render_frame_check"):
             setattr(_cls, _k, staticmethod(_wrap_timed(_k, _v.__func__)))
 
 raymarching_backend = _RayMarching

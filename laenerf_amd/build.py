@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "liblaenerf_hip.so")
-SOURCES = ["raymarching.hip", "gridencoder.hip", "shencoder.hip", "freqencoder.hip", "ffmlp.hip", "densitygrid.hip", "optimizer.hip", "loss.hip", "palette.hip", "editgrid.hip", "lae_common.cpp"]
+SOURCES = ["raymarching.hip", "frame.hip", "gridencoder.hip", "shencoder.hip", "freqencoder.hip", "ffmlp.hip", "densitygrid.hip", "optimizer.hip", "loss.hip", "palette.hip", "editgrid.hip", "lae_common.cpp"]
 # -ffp-contract=off: only explicit fmaf() fuses -> bit-identical sample indices/positions vs the oracle
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nerf_head_fwd5(
 // 800x800 / 1080p frame (profiles/r4_*).
 // Work is dealt in CONTIGUOUS runs of groups, one run per wave (unit u = blockIdx.x * WAVES + wave), and a wave appends the
 // rays that go on to its own survivor segment [u * R, ...) + count (+ the workgroup's sum of counts): the next iteration's
-// per-ray kernels walk the segments in unit order (raymarching.hip frame_locate), so the alive list keeps its order -- stable
+// per-ray kernels walk the segments in unit order (frame.hip frame_locate), so the alive list keeps its order -- stable
 // compaction, no atomics, the same list every run.  (Compacting inside this launch -- every workgroup publishing its count
 // and waiting for the counts of the workgroups before it -- was built and measured in round 4: 12.65 against 12.26 ms per
 // 800x800 frame, and two processes sharing one GPU crawl when spinning workgroups keep each other's predecessors out.)
@@ -1859,7 +1859,7 @@ static int head_args_ok(const void* ws, const void* wc, uint64_t rows, const cha
     return LAE_OK;
 }
 
-// frame loop (raymarching.hip lae_render_frame): level-major features [16, M_cap, 2], loop state in device memory
+// frame loop (frame.hip lae_render_frame): level-major features [16, M_cap, 2], loop state in device memory
 uint32_t lae::frame_head_max_blocks() { return (uint32_t)lae::num_cus() * head_blocks_per_cu(); }
 
 template <bool EDIT, int WAVES>

@@ -1827,7 +1827,7 @@ static int tv_c(const float* inputs, const float* emb, float* grad, const int32_
 
 }  // namespace
 
-// frame loop (raymarching.hip lae_render_frame): fp16 table, D=3, C=2, level-major output [L, B_cap, 2]; rows beyond
+// frame loop (frame.hip lae_render_frame): fp16 table, D=3, C=2, level-major output [L, B_cap, 2]; rows beyond
 // *B_dev are not touched.  B_launch = host upper bound of *B_dev (sizes the launch only).
 int lae::grid_forward_frame(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B_cap,
                             uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,

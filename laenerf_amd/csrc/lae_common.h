@@ -28,7 +28,7 @@ int grid_forward_frame(const float* inputs, const void* embeddings, const int32_
                        uint32_t B_launch, const uint32_t* B_dev, uint32_t L, float S, uint32_t H, uint32_t gridtype,
                        int align_corners, uint32_t interp, float in_shift, float in_scale, hipStream_t stream,
                        const int32_t* offsets_host, uint32_t B_likely = 0);   // B_likely: rows the host expects (0: B_launch); sizes launches, never a result
-// Loop state of the frame loop, double-buffered in device memory (raymarching.hip k_frame_emit advances it).
+// Loop state of the frame loop, double-buffered in device memory (frame.hip k_frame_emit advances it).
 // Sample rows are RAY-MAJOR IN 64-ROW GROUPS: a group holds rpg = 64 / n_step whole rays (integer division), ray n's row j is
 // (n / rpg) * 64 + (n % rpg) * n_step + j; the 64 - rpg * n_step rows at a group's end (n_step = 3, 5, 6, 7 only) are padding.
 // A wave of the head kernel owns a group, so the compositing of a ray never crosses waves.

@@ -314,7 +314,7 @@ def test_frame_loop_ends_when_every_ray_dies_at_once(kind):
 
 @pytest.mark.parametrize("bound,density", [(1, 0.004), (2, 0.002), (2, 0.05), (1, 0.0), (2, 0.0)])
 def test_frame_loop_on_sparse_random_occupancy(bound, density):
-    """the lookahead's "nothing ahead" test (coarse occupancy field, csrc/raymarching.hip k_frame_coarse_*) must never end a walk
+    """the lookahead's "nothing ahead" test (coarse occupancy field, csrc/frame.hip k_frame_coarse_*) must never end a walk
     that still has a sample in front of it: isolated occupied cells scattered over every cascade (most rays cross long empty
     stretches between hits, many graze marked coarse cells), rays from outside the volume, from inside it, axis-parallel and
     nearly axis-parallel ones -- frame loop and operator loop bit for bit"""
@@ -444,13 +444,14 @@ def test_frame_loop_degrades_to_the_inline_lookahead_instead_of_failing():
     call, and the process stays in line; (e) 40 live torch streams, the frame on one of them.  Every frame of every child has
     the same bits; at most one warning per process."""
     base, w0 = _degrade_child({})
-    assert base["mode"] == 1 and not w0 and all(f["finite"] for f in base["frames"])
+    assert base["mode"] == 1 and not w0 and all(f["finite"] and f["status"] == 0 for f in base["frames"])
     sha = base["frames"][0]["sha"]
     assert all(f["sha"] == sha for f in base["frames"])
     report = {"default": base}
 
     def same_bits(res):
         assert [f["sha"] for f in res["frames"]] == [sha, sha] and all(f["finite"] for f in res["frames"]), res
+        assert all(f["status"] == 0 for f in res["frames"]), res        # lae_render_frame_last_status after the synchronise: completed
     ser, w1 = _degrade_child({"AMD_SERIALIZE_KERNEL": "3"})
     same_bits(ser)
     assert ser["mode"] == 0 and len(w1) == 1 and "do not run concurrently" in w1[0]

@@ -37,9 +37,9 @@ def main():
         h = hashlib.sha256()
         for key in ("image", "depth", "weights_sum"):
             h.update(res[key].float().cpu().numpy().tobytes())
+        from laenerf_amd.backend import raymarching_backend
         out.append({"sha": h.hexdigest()[:16], "finite": bool(torch.isfinite(res["image"]).all().item()),
-                    "seconds": round(time.perf_counter() - t0, 3)})
-    from laenerf_amd.backend import raymarching_backend
+                    "seconds": round(time.perf_counter() - t0, 3), "status": raymarching_backend.render_frame_last_status()})
     print(json.dumps({"frames": out, "mode": raymarching_backend.render_frame_mode()}), flush=True)
 
 
