@@ -1711,10 +1711,20 @@ static int launch_bwd_fast(const void* gT, const float* inputs, const int32_t* o
     const T* g = (const T*)gT;
     T* ge = (T*)gemb;
     if (!caller_plan) bwd_plan<T>(inputs, offsets, B, L, a, plan);
+#ifdef LAE_GRID_BWD_PHASE_PROBE
+    // probe builds only (tools/fill_beside_mlp_probe.py): LAE_GRID_BWD_PHASE=1 launches the fill pass alone, =2 the accumulate
+    // pass alone (on whatever the queue holds); results are meaningless, durations are what is measured
+    const char* phase_env = getenv("LAE_GRID_BWD_PHASE");
+    const int phase_probe = phase_env ? atoi(phase_env) : 0;
+    if (phase_probe != 2)
+#endif
     if (a.gridtype == 0 && !a.align && a.interp == 0)
         k_bwd_walk<T, true, true><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
     else
         k_bwd_walk<T, true, false><<<U / SEGS * L, FILL_THREADS, 0, a.stream>>>(g, inputs, offsets, B, L, a.sc, a.gridtype, a.align, a.interp, U, plan, qvals, qkeys, nullptr, nullptr);
+#ifdef LAE_GRID_BWD_PHASE_PROBE
+    if (phase_probe == 1) return lae::check_launch("grid backward (fill-only probe)");
+#endif
     // workgroups per level: 32 up to ~400 k samples, 64 beyond (same-box A/B in round 4: lego, 258 k samples, 0.3508 / 0.3547 ms per
     // step at 32 / 64; flower, 658 k, 0.666 / 0.647) -- the smallest levels' few cells take every sample's LDS atomics
     static const uint32_t bk_env = [] { const char* e = getenv("LAE_GRID_BWD_BK_TARGET"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), (int)SUB_RECS) : 0u; }();

@@ -325,6 +325,18 @@ class ReferenceChain(nn.Module):
         return loss.mean(), out
 
 
+def one_edit_train_step(chain, fused_adam, batch, probe=None):
+    """the same step after ONE of INTEGRATION.md 3b's edits: `laenerf_amd.optim.FusedAdam` in the place of torch.optim.Adam +
+    GradScaler (nerf/utils.py:1474-1478 becomes `opt.backward(opt.scale(loss)); opt.step()`); everything else as in
+    drop_in_train_step.  No host read is left in the optimizer (found_inf stays on the device)."""
+    probe = probe or Probe()
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss, out = chain.train_loss(*batch, probe=probe)
+    fused_adam.backward(fused_adam.scale(loss))
+    fused_adam.step()
+    return loss, out
+
+
 def drop_in_train_step(chain, optimizer, scaler, batch, probe=None, split_unscale=False):
     """one step of the reference's loop (nerf/utils.py:1472-1478).  split_unscale: `scaler.unscale_(optimizer)` as a call of its
     own before `scaler.step` (same kernels; lets a probe separate the stretch before GradScaler's host read from the one after)"""
