@@ -44,7 +44,8 @@ def main():
         w_kib = wr.get(gk[0], (0, 0))[1] + (wr.get(tk[0], (0, 0))[1] if tk else 0)
         js = {"kernel": "k_grid_fwd + k_out_transpose (one grid_encode_forward call)", "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
               "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024),
-              "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024; separate --pmc passes; medians per dispatch; source " + os.path.basename(out)}
+              "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024; separate --pmc passes; medians per dispatch; source " + os.path.basename(out),
+              "source": "profiles/" + os.path.basename(out)}      # bench.py quotes this in the line's `traffic_source`
         json.dump(js, open(os.path.join(root, "profiles", "grid_fwd_traffic.json"), "w"), indent=1)
         print(js)
     print("wrote", out)
