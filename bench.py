@@ -509,7 +509,9 @@ def frame_exchange(dev, H, W, reps=20):
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=60))
             made_group = True
         n = H * W
         plan = D.frame_plan(n, 0, 8, dev, (H, W))

@@ -175,3 +175,35 @@ def test_forced_collectives_with_one_rank():
     p = ctx.Process(target=_forced_w1_worker, args=(29500 + (os.getpid() + 999) % 2000, ret))
     p.start(); p.join(120)
     assert p.exitcode == 0 and ret[0]
+
+
+def test_frame_plan_composes_the_tile_deal_and_the_pixel_tile_order():
+    """round 6: dist.frame_plan's two index vectors (`take`: the caller's ray ids a rank renders; `put`: for every ray its row in the
+    rank-major all-gather buffer) == the two-step form they replace (pixel-tile order, then shard_indices; de-interleave, then the
+    inverse order), for frames that divide into 8 x 8 tiles, frames that do not, ragged tile counts and W = 1 ... 8"""
+    import torch
+    from laenerf_amd import dist as D
+    cpu = torch.device("cpu")
+    for (H, W) in ((24, 32), (12, 64), (40, 56), (7, 19)):
+        n = H * W
+        vals = torch.arange(n).float()
+        order = D.pixel_tile_order((H, W), cpu)
+        tiled = vals[order[0]] if order is not None else vals
+        for world in (1, 2, 3, 8):
+            blocks, old_blocks = [], []
+            for r in range(world):
+                plan = D.frame_plan(n, r, world, cpu, (H, W))
+                assert plan["take"].shape[0] == plan["n_shard"] and plan["n_shard"] % D.TILE == 0
+                blocks.append(vals[plan["take"]])
+                idx = D.shard_indices(n, r, world)
+                old_blocks.append(tiled[idx.clamp(min=0)])
+                valid = idx >= 0
+                assert torch.equal(blocks[-1][valid], old_blocks[-1][valid])        # same rays, same order (padding rows may differ)
+            assert len({b.shape[0] for b in blocks}) == 1                              # equal shards: the all-gather's requirement
+            full = torch.stack(blocks).reshape(-1)[plan["put"]]
+            assert torch.equal(full, vals), (H, W, world)
+            old = D.deinterleave(torch.stack(old_blocks)[:, :, None], n, world)[:, 0]
+            assert torch.equal(old[order[1]] if order is not None else old, vals)
+    # without image_hw (or with one that does not match the ray count) the deal is over the caller's order itself
+    plan = D.frame_plan(1000, 1, 4, cpu, None)
+    assert torch.equal(plan["take"][:128], torch.arange(128, 256))
