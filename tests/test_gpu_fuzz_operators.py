@@ -276,3 +276,62 @@ def test_fuzz_inference_operators(c):
     out, n_out = rm.compact_rays_alive(alive, na)
     keep = a0[a0 >= 0]
     assert int(n_out.item()) == keep.size and np.array_equal(N(out)[:keep.size], keep)
+
+
+@settings(max_examples=100, **FUZZ)
+@given(st.fixed_dictionaries({"degree": st.integers(1, 8), "B": st.integers(1, 3000), "unit": st.booleans(), "seed": st.integers(0, 2 ** 20)}))
+def test_fuzz_sh_encode(c):
+    """SH basis of degree 1-8 (shencoder.cu:27-439) and its input gradient, unit and non-unit directions (the polynomials are evaluated as
+    they stand; the reference normalises nothing)"""
+    O = _oracle()
+    from laenerf_amd.shencoder import sh_encode
+    rng = np.random.default_rng(c["seed"])
+    d = rng.standard_normal((c["B"], 3)).astype(np.float32)
+    if c["unit"]:
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6)
+    else:
+        d *= np.float32(0.7)
+    ref, ref_dd = O.sh_encode_forward(d, c["degree"], True)
+    scale = 1.0 + float(np.abs(ref).max())
+    di = T(d).requires_grad_()
+    y = sh_encode(di, c["degree"], True)
+    assert np.allclose(N(y), ref, rtol=2e-5, atol=2e-6 * scale)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.backward(T(g))
+    assert np.allclose(N(di.grad), O.sh_encode_backward(g, ref_dd, c["degree"]), rtol=1e-4, atol=1e-4 * (1 + np.abs(ref_dd).max()))
+
+
+def _close_f16(a, b, rel=4e-3, floor=2e-3):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.abs(a - b).max() <= rel * np.abs(b).max() + floor
+
+
+@settings(max_examples=100, **FUZZ)
+@given(st.fixed_dictionaries({"IN": st.sampled_from([16, 32, 48, 64]), "H": st.sampled_from([16, 32, 64, 64, 128]), "NL": st.integers(2, 4),
+                              "tiles": st.integers(1, 90), "act": st.sampled_from([0, 0, 0, 3, 6]), "seed": st.integers(0, 2 ** 20)}))
+def test_fuzz_ffmlp_forward_backward(c):
+    """the fully fused MLP (ffmlp.cu:331-407, 410-518) over widths, depths, input sizes and batch sizes (multiples of 16: what the MFMA
+    tiles own; the module pads): outputs, input gradient and weight gradient against the oracle, ReLU masks taken from the ORACLE's
+    activations by feeding its forward buffer where the backward reads one"""
+    O = _oracle()
+    from laenerf_amd.backend import ffmlp_backend as F
+    IN, H, NL, B, act = c["IN"], c["H"], c["NL"], 16 * c["tiles"], c["act"]
+    rng = np.random.default_rng(c["seed"])
+    nW = O.ffmlp_num_params(IN, H, NL)
+    Wh = O.to_f16_bits(rng.uniform(-np.sqrt(3 / H), np.sqrt(3 / H), nW).astype(np.float32))
+    Xh = O.to_f16_bits(rng.uniform(-1, 1, (B, IN)).astype(np.float32))
+    ref_out, ref_fb = O.ffmlp_forward(Xh, Wh, IN, 16, H, NL, activation=act)
+    out = torch.empty(B, 16, device=DEV, dtype=torch.half)
+    F.ffmlp_inference(half_from_bits(Xh), half_from_bits(Wh), B, IN, 16, H, NL, act, 6, None, out)
+    assert _close_f16(N(out), O.from_f16_bits(ref_out))
+    if act != 0:
+        return                                                 # the reference's backward knows ReLU only (ffmlp.cu:781: other activations are forward-only)
+    Gh = O.to_f16_bits((rng.standard_normal((B, 16)) * 0.05).astype(np.float32))
+    ref_gw, ref_gi, _ = O.ffmlp_backward(Gh, Xh, Wh, ref_fb, IN, 16, H, NL, calc_grad_inputs=True)
+    fused = F.fused_backward_available(IN, H, NL, 0)
+    gi = torch.zeros(B, IN, device=DEV, dtype=torch.half); gw = torch.zeros(nW, device=DEV, dtype=torch.half)
+    bb = None if fused else torch.empty(NL, B, H, device=DEV, dtype=torch.half)
+    F.ffmlp_backward(half_from_bits(Gh), half_from_bits(Xh), half_from_bits(Wh), None if fused else half_from_bits(ref_fb), B, IN, 16, H, NL, 0, 6, True,
+                     bb, gi, gw)
+    assert _close_f16(N(gi), O.from_f16_bits(ref_gi), floor=5e-4)
+    assert _close_f16(N(gw), O.from_f16_bits(ref_gw), rel=1e-2, floor=2e-3)
