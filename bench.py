@@ -1601,18 +1601,23 @@ def main():
                                "barriers, max over ranks; n1_ms_per_frame: the whole frame on rank 0 alone on the reference schedule, "
                                "best_n1_ms_per_frame: on the fastest of {reference rule, 2N, 4N, 8N rows per iteration}; speedup_vs_n1 divides THAT by ms_per_frame")
             out["frame1080"] = sharded                         # the north star's 8-GPU split (not `value`)
+        def extra(fn, *a, **k):                              # the objects beside `value`: a failure inside one of them must not take the line down (it shows as {"error": ...})
+            try:
+                return fn(*a, **k)
+            except Exception as ex:
+                return {"error": repr(ex)}
         if world == 1 and not args.no_dropin:
-            out["drop_in_step"] = drop_in_step(dev, ms)        # the reference's own operator sequence on the installed backends (not `value`)
+            out["drop_in_step"] = extra(drop_in_step, dev, ms)   # the reference's own operator sequence on the installed backends (not `value`)
         if world == 1 and not args.no_frame:
-            out["eval_frame"] = eval_frame(dev)                # the "ms/frame" half of BASELINE.json's metric (not `value`)
-            out["eval_frame_surface"] = eval_frame(dev, density_scale=30.0)   # the same frame on a trained-shaped density
-            out["frame1080"] = frame1080(dev)                  # configs[3] on one GPU (not `value`)
+            out["eval_frame"] = extra(eval_frame, dev)              # the "ms/frame" half of BASELINE.json's metric (not `value`)
+            out["eval_frame_surface"] = extra(eval_frame, dev, density_scale=30.0)   # the same frame on a trained-shaped density
+            out["frame1080"] = extra(frame1080, dev)               # configs[3] on one GPU (not `value`)
         if world == 1 and not args.no_style:
-            out["style_step"] = style_step(dev)                # configs[4] inner loop (not `value`)
-            out["edit_extract"] = edit_extract(dev)            # configs[4] extraction around it (not `value`)
-            out["grid_update"] = grid_update(dev)
-            out["flower_step"] = flower_step(dev)              # configs[2]-shaped train step (not `value`)
-            out["sparse_step"] = sparse_step(dev)              # the sparse occupancy preset of SURVEY 8d (not `value`)
+            out["style_step"] = extra(style_step, dev)              # configs[4] inner loop (not `value`)
+            out["edit_extract"] = extra(edit_extract, dev)          # configs[4] extraction around it (not `value`)
+            out["grid_update"] = extra(grid_update, dev)
+            out["flower_step"] = extra(flower_step, dev)            # configs[2]-shaped train step (not `value`)
+            out["sparse_step"] = extra(sparse_step, dev)       # the sparse occupancy preset of SURVEY 8d (not `value`)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, host_threads())
             out["cpu_baseline"]["cfg1_run_path"] = cpu_baseline_cfg1(host_threads())
