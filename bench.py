@@ -1014,40 +1014,43 @@ def drop_in_step(dev, fused_ms, steps=40, n_rays=4096):
                     "device_ms_per_step": round(dev_ms, 4), "device_stretches_ms": [round(v, 4) for v in per_step[len(per_step) // 2]],
                     "bound_by": "host (launch issue + host reads)" if wall * 1e3 > 1.15 * dev_ms else "device",
                     "rows_per_step": int(np.mean(rows))}
-    # one rung up INTEGRATION.md 3b's ladder of optional edits: FusedAdam in the place of torch.optim.Adam + GradScaler, nothing else
-    try:
-        from laenerf_amd.optim import FusedAdam
-        from laenerf_amd.reference_chain import one_edit_train_step
-        torch.manual_seed(1234)
-        chain = ReferenceChain(bound=1, min_near=0.2, nan_check=True).to(dev).train()
-        chain.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
-        fopt = FusedAdam(chain, param_groups=chain.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-        for i in range(34):
-            one_edit_train_step(chain, fopt, batches[i % 16])
-            if (i + 1) % 16 == 0:
-                chain.update_mean_count()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for i in range(steps):
-            one_edit_train_step(chain, fopt, batches[i % 16])
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / steps
-        probe = _SegmentProbe(sleep_cycles=8_000_000)
-        per_step = []
-        for i in range(12):
-            probe.begin()
-            one_edit_train_step(chain, fopt, batches[i % 16], probe=probe)
-            probe.cut()
-            per_step.append(probe.take_ms())
-        dev_ms = sorted(sum(p) for p in per_step[2:])[5]
-        out["fused_adam_edit"] = {"ms_per_step": round(wall * 1e3, 4), "Mrays_per_s": round(n_rays / wall / 1e6, 3), "device_ms_per_step": round(dev_ms, 4),
-                                  "edit": "laenerf_amd.optim.FusedAdam instead of torch.optim.Adam + GradScaler (INTEGRATION.md 3b); the reference's "
-                                          "renderer / network / wrappers unchanged"}
-    except Exception as ex:                                   # a diagnostic must never take the line down
-        out["fused_adam_edit"] = {"error": repr(ex)}
+    # INTEGRATION.md 3b's ladder of optional edits: FusedAdam in the place of torch.optim.Adam + GradScaler, nothing else; then also
+    # `nerf_head` in the place of network_ff.py:57-79
+    for key, fused_head in (("fused_adam_edit", False), ("fused_adam_and_head_edits", True)):
+        try:
+            from laenerf_amd.optim import FusedAdam
+            from laenerf_amd.reference_chain import one_edit_train_step
+            torch.manual_seed(1234)
+            chain = ReferenceChain(bound=1, min_near=0.2, nan_check=True, fused_head=fused_head).to(dev).train()
+            chain.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)
+            fopt = FusedAdam(chain, param_groups=chain.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+            for i in range(34):
+                one_edit_train_step(chain, fopt, batches[i % 16])
+                if (i + 1) % 16 == 0:
+                    chain.update_mean_count()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(steps):
+                one_edit_train_step(chain, fopt, batches[i % 16])
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            probe = _SegmentProbe(sleep_cycles=8_000_000)
+            per_step = []
+            for i in range(12):
+                probe.begin()
+                one_edit_train_step(chain, fopt, batches[i % 16], probe=probe)
+                probe.cut()
+                per_step.append(probe.take_ms())
+            dev_ms = sorted(sum(p) for p in per_step[2:])[5]
+            out[key] = {"ms_per_step": round(wall * 1e3, 4), "Mrays_per_s": round(n_rays / wall / 1e6, 3), "device_ms_per_step": round(dev_ms, 4),
+                        "edit": ("laenerf_amd.optim.FusedAdam instead of torch.optim.Adam + GradScaler" +
+                                 (" and laenerf_amd.ffmlp.nerf_head instead of network_ff.py:57-79" if fused_head else "") +
+                                 " (INTEGRATION.md 3b); the reference's renderer and operator wrappers unchanged")}
+        except Exception as ex:                                 # a diagnostic must never take the line down
+            out[key] = {"error": repr(ex)}
     aw = out["as_written"]
     res = {"ms_per_step": aw["ms_per_step"], "Mrays_per_s": aw["Mrays_per_s"], "device_ms_per_step": aw["device_ms_per_step"],
            "device_stretches_ms": aw["device_stretches_ms"], "bound_by": aw["bound_by"], "rows_per_step": aw["rows_per_step"],
-           "without_network_nan_check": out["without_nan_check"], "with_one_edit": out["fused_adam_edit"],
+           "without_network_nan_check": out["without_nan_check"], "with_one_edit": out["fused_adam_edit"], "with_two_edits": out["fused_adam_and_head_edits"],
            "fused_headline_ms_per_step": round(fused_ms, 4),
            "device_time_vs_fused_step": round(aw["device_ms_per_step"] / fused_ms, 2),
            "wall_time_vs_fused_step": round(aw["ms_per_step"] / fused_ms, 2), "rays": n_rays}

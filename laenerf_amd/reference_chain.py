@@ -254,8 +254,11 @@ class _RefFFMLPModule(nn.Module):
 class ReferenceChain(nn.Module):
     """`NeRFNetwork` of nerf/network_ff.py on `NeRFRenderer.run_cuda`'s training branch, through the reference-named backends"""
 
-    def __init__(self, bound=1, min_near=0.2, density_scale=1.0, nan_check=True):
+    def __init__(self, bound=1, min_near=0.2, density_scale=1.0, nan_check=True, fused_head=False):
+        """fused_head (one of INTEGRATION.md 3b's optional edits, off for the zero-edit step): `laenerf_amd.ffmlp.nerf_head` in the
+        place of network_ff.py:57-79 (sigma net, trunc_exp, SH, cat, colour net, the NaN check, sigmoid)"""
         super().__init__()
+        self.fused_head = fused_head
         from .gridencoder.grid import level_offsets
         self.bound, self.min_near, self.density_scale, self.nan_check = bound, min_near, density_scale, nan_check
         self.cascade = 1 + math.ceil(math.log2(bound))
@@ -285,6 +288,9 @@ class ReferenceChain(nn.Module):
     def network(self, x, d, probe):
         x01 = (x + self.bound) / (2 * self.bound)
         enc = _RefGridEncode.apply(x01.view(-1, 3), self.embeddings, self.offsets, self.per_level_scale, 16, x01.requires_grad, 0, False, 0)
+        if self.fused_head:
+            from .ffmlp import nerf_head
+            return nerf_head(enc, d, self.sigma_net.weights, self.color_net.weights)
         h = self.sigma_net(enc)
         sigma = _RefTruncExp.apply(h[..., 0])
         geo = h[..., 1:]
