@@ -932,7 +932,7 @@ class _SegmentProbe:
     """device time of an eager step that reads the device from the host in the middle: the stretch between two host reads is
     bracketed by a HIP-event pair behind a spin kernel long enough for the host to enqueue the whole stretch (so the events see
     kernels back to back, not the host's launch gaps); the step's device time is the sum of its stretches.
-    laenerf_amd/reference_chain.py calls cut() before each host read and begin() after it."""
+    tools/reference_chain.py calls cut() before each host read and begin() after it."""
 
     def __init__(self, sleep_cycles):
         self.sleep_cycles, self.pairs, self.open = int(sleep_cycles), [], None
@@ -962,11 +962,11 @@ def drop_in_step(dev, fused_ms, steps=40, n_rays=4096):
     """The train step of a LAENeRF checkout that has added INTEGRATION.md 1's three lines and changed nothing else: the reference's
     own operator sequence (nerf/renderer.py:259-333 -> nerf/network_ff.py:51-79 -> the wrappers' allocate-then-call rules ->
     torch MSE -> GradScaler -> torch.optim.Adam, nerf/utils.py:1472-1478), eager, through the four reference-named backend modules
-    (laenerf_amd/reference_chain.py).  Same rays, occupancy, table and MLP shapes as the headline.  `ms_per_step`: wall clock of
+    (tools/reference_chain.py).  Same rays, occupancy, table and MLP shapes as the headline.  `ms_per_step`: wall clock of
     K eager steps; `device_ms_per_step`: HIP events around the stretches between the step's host reads (two `torch.any` of
     network_ff.py:72, GradScaler's found_inf), each behind a spin kernel so that launch gaps do not count."""
     from laenerf_amd import synthetic as S
-    from laenerf_amd.reference_chain import ReferenceChain, drop_in_train_step
+    from tools.reference_chain import ReferenceChain, drop_in_train_step
     out = {}
     for nan_check in (True, False):
         torch.manual_seed(1234)
@@ -1019,7 +1019,7 @@ def drop_in_step(dev, fused_ms, steps=40, n_rays=4096):
     for key, fused_head in (("fused_adam_edit", False), ("fused_adam_and_head_edits", True)):
         try:
             from laenerf_amd.optim import FusedAdam
-            from laenerf_amd.reference_chain import one_edit_train_step
+            from tools.reference_chain import one_edit_train_step
             torch.manual_seed(1234)
             chain = ReferenceChain(bound=1, min_near=0.2, nan_check=True, fused_head=fused_head).to(dev).train()
             chain.density_bitfield = torch.from_numpy(S.pack_bits_np(S.sphere_density_grid(), 10.0)).to(dev)

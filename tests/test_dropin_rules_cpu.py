@@ -1,4 +1,4 @@
-"""CPU: the measurement harness of the zero-edit drop-in step (laenerf_amd/reference_chain.py) follows the allocate-then-call rules of
+"""CPU: the measurement harness of the zero-edit drop-in step (tools/reference_chain.py) follows the allocate-then-call rules of
 the reference's operator wrappers as the fixtures recorded them from the reference's own Python (tests/golden/ops_wrappers.npz,
 ffmlp_init.npz: make_golden.py runs raymarching/raymarching.py and ffmlp/ffmlp.py unmodified over recording backends).
 
@@ -98,7 +98,7 @@ def chain_on_recorders(monkeypatch):
             "_ffmlp": ("allocate_splitk", "ffmlp_forward", "ffmlp_backward")}
     for name, fns in mods.items():
         monkeypatch.setitem(sys.modules, name, rec.module(name, fns))
-    from laenerf_amd.reference_chain import ReferenceChain
+    from tools.reference_chain import ReferenceChain
     chain = ReferenceChain(bound=1, min_near=0.2).train()
     chain.density_bitfield = torch.from_numpy(g["bitfield"])
     return chain, rec, g

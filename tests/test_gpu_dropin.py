@@ -1,4 +1,4 @@
-"""The zero-edit drop-in train step (laenerf_amd/reference_chain.py: the reference's operator sequence and wrapper rules through the
+"""The zero-edit drop-in train step (tools/reference_chain.py: the reference's operator sequence and wrapper rules through the
 backend modules under their reference names) computes the same step as this repository's fused driver.
 
 Reference: nerf/renderer.py:259-333, nerf/network_ff.py:51-79, gridencoder/grid.py:24-93, ffmlp/ffmlp.py:15-86, nerf/utils.py:1472-1478.
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _pair(n_rays=1024, seed=3, small=True):
     from laenerf_amd import synthetic as S
     from laenerf_amd.network import NeRFNetwork
-    from laenerf_amd.reference_chain import ReferenceChain
+    from tools.reference_chain import ReferenceChain
     from laenerf_amd.renderer import NeRFRenderer
     torch.manual_seed(seed)
     chain = ReferenceChain(bound=1, min_near=0.2).to(DEV).train()
@@ -75,7 +75,7 @@ def test_drop_in_backward_matches_fused_driver():
 
 def test_drop_in_step_runs_the_reference_sequence_and_learns():
     """a few optimizer steps through scaler.scale / backward / step / update: finite, sized by mean_count after 16 steps, loss falls"""
-    from laenerf_amd.reference_chain import drop_in_train_step
+    from tools.reference_chain import drop_in_train_step
     chain, r, o, d, gt = _pair(n_rays=512)
     gt = torch.full_like(gt, 0.25)
     opt = torch.optim.Adam(chain.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)

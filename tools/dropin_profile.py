@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K eager steps of the zero-edit drop-in train step (laenerf_amd/reference_chain.py) after its warm-up, for rocprofv3:
+"""K eager steps of the zero-edit drop-in train step (tools/reference_chain.py) after its warm-up, for rocprofv3:
 
     rocprofv3 --kernel-trace --stats -d gpurun_out/dropin_k10 -- python3 tools/dropin_profile.py --steps 10
     rocprofv3 --kernel-trace --stats -d gpurun_out/dropin_k30 -- python3 tools/dropin_profile.py --steps 30
@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--torch-profiler", action="store_true")
     a = ap.parse_args()
     from laenerf_amd import build, synthetic as S
-    from laenerf_amd.reference_chain import ReferenceChain, drop_in_train_step
+    from tools.reference_chain import ReferenceChain, drop_in_train_step
     build.build()
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)

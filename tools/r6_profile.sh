@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc $SQ -d gpurun_out/${tag}_pmc_sq_style -o style --
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_flower -o flower -- python3 bench.py --workload flower > gpurun_out/${tag}_flower.json 2>gpurun_out/${tag}_flower.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_style -o s -- python3 tools/style_prof.py > gpurun_out/${tag}_style.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_gridupd -o gu -- python3 tools/grid_update_bench.py > gpurun_out/${tag}_gridupd.log 2>&1
-# the zero-edit drop-in step (laenerf_amd/reference_chain.py): two traces, 10 and 30 steady steps -> per-step kernel table by difference
+# the zero-edit drop-in step (tools/reference_chain.py): two traces, 10 and 30 steady steps -> per-step kernel table by difference
 for k in 10 30; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_dropin_k$k -o d -- python3 tools/dropin_profile.py --steps $k > gpurun_out/${tag}_dropin_k$k.log 2>&1
 done

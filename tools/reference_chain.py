@@ -4,7 +4,8 @@ the HIP backend under the reference's four extension names --
 This module restates, as measurement harness, the CALLERS' side of the drop-in boundary: the allocate-then-call rules of the
 reference's operator wrappers and the operator sequence of its training step, going through the backend modules by their
 REFERENCE names and argument lists only (no `_ex` forms, no `blc`, no shadow table, no fused head / criterion / optimizer,
-no HIP graph).  Nothing here is used by the product path (`renderer.py`, `network.py`, `optim.py`); `bench.py`'s
+no HIP graph).  It lives under tools/ on purpose: nothing here is product code or used by the product path (`laenerf_amd/renderer.py`,
+`network.py`, `optim.py`); `bench.py`'s
 `drop_in_step` times it beside the fused headline and `tests/test_gpu_dropin.py` checks that both compute the same step.
 
     raymarching/raymarching.py:19-49,161-291    near_far_from_aabb, march_rays_train (three torch.zeros sample buffers, torch.rand
@@ -38,7 +39,7 @@ def _mods():
     """the four extension modules under the names the reference's wrappers import (installs them on first use)"""
     import sys
     if "_raymarching" not in sys.modules or "_ffmlp" not in sys.modules:
-        from . import backend
+        from laenerf_amd import backend
         backend.install_as_reference_backends()
     return sys.modules["_raymarching"], sys.modules["_gridencoder"], sys.modules["_shencoder"], sys.modules["_ffmlp"]
 
@@ -259,7 +260,7 @@ class ReferenceChain(nn.Module):
         place of network_ff.py:57-79 (sigma net, trunc_exp, SH, cat, colour net, the NaN check, sigmoid)"""
         super().__init__()
         self.fused_head = fused_head
-        from .gridencoder.grid import level_offsets
+        from laenerf_amd.gridencoder.grid import level_offsets
         self.bound, self.min_near, self.density_scale, self.nan_check = bound, min_near, density_scale, nan_check
         self.cascade = 1 + math.ceil(math.log2(bound))
         self.grid_size = 128
@@ -289,7 +290,7 @@ class ReferenceChain(nn.Module):
         x01 = (x + self.bound) / (2 * self.bound)
         enc = _RefGridEncode.apply(x01.view(-1, 3), self.embeddings, self.offsets, self.per_level_scale, 16, x01.requires_grad, 0, False, 0)
         if self.fused_head:
-            from .ffmlp import nerf_head
+            from laenerf_amd.ffmlp import nerf_head
             return nerf_head(enc, d, self.sigma_net.weights, self.color_net.weights)
         h = self.sigma_net(enc)
         sigma = _RefTruncExp.apply(h[..., 0])
