@@ -109,8 +109,8 @@ _plan_cache = {}
 
 def frame_plan(n_rays, rank, world_size, device, image_hw=None, tile=TILE):
     """the two index vectors of a sharded frame, composed once per (frame size, rank, world) and kept on the device:
-    `take` [n_shard]: the caller's ray ids this rank renders (its 128-ray tiles of the pixel-tile order when image_hw = (H, W)
-    divides into 8 x 8 tiles, of the caller's order otherwise; padding rows repeat ray 0);
+    `take` [n_shard]: the caller's ray ids this rank renders (its 128-ray units of the pixel-tile order when image_hw = (H, W)
+    divides into 8 x 8 tiles, of the caller's order otherwise; rotated round-robin, see below; padding rows repeat ray 0);
     `put` [n_rays]: row of the rank-major all-gather buffer that holds the caller's ray q -- the de-interleave of the tiles and the
     way back from pixel-tile order as ONE gather.  Round 6: before, every rank gathered the WHOLE frame's rays into tile order, then
     its shard from that, and undid the two permutations with a strided copy and a second full-frame gather."""
@@ -125,14 +125,20 @@ def frame_plan(n_rays, rank, world_size, device, image_hw=None, tile=TILE):
         per_rank = (n_tiles + world_size - 1) // world_size
         n_shard = per_rank * tile
         j = torch.arange(n_shard, device=device)
-        pos = ((j // tile) * world_size + rank) * tile + j % tile          # position in the (tile-ordered) frame of this rank's row j
+        # the deal: 128-ray unit u = q * W + r goes to rank (r + q) mod W -- round-robin ROTATED by one rank per group of W units.
+        # The plain deal (rank r takes units r, r + W, ...: shard_indices) hands a rank the same pixel columns of every tile row
+        # whenever the units per tile row divide by W (1080p: 120 per row, W = 8): vertical stripes, and the eight shards of the
+        # bench frame differed by 5 % in samples (7.80 ... 8.11 ms); rotated, every rank sees every column
+        q_own = j // tile
+        pos = (q_own * world_size + (rank - q_own) % world_size) * tile + j % tile      # position in the (tile-ordered) frame of this rank's row j
         pos_c = pos.clamp(max=n_rays - 1)
         take = order[0][pos_c] if order is not None else pos_c
         take = torch.where(pos < n_rays, take, torch.zeros_like(take))
         # all ranks' rows: g = r * n_shard + j  <->  frame position ((j // tile) * W + r) * tile + j % tile
         g = torch.arange(world_size * n_shard, device=device)
         r_, j_ = g // n_shard, g % n_shard
-        p_all = ((j_ // tile) * world_size + r_) * tile + j_ % tile
+        q_all = j_ // tile
+        p_all = (q_all * world_size + (r_ - q_all) % world_size) * tile + j_ % tile
         valid = p_all < n_rays
         put = torch.empty(n_rays, dtype=torch.long, device=device)
         q = order[0][p_all[valid]] if order is not None else p_all[valid]

@@ -179,31 +179,36 @@ def test_forced_collectives_with_one_rank():
 
 def test_frame_plan_composes_the_tile_deal_and_the_pixel_tile_order():
     """round 6: dist.frame_plan's two index vectors (`take`: the caller's ray ids a rank renders; `put`: for every ray its row in the
-    rank-major all-gather buffer) == the two-step form they replace (pixel-tile order, then shard_indices; de-interleave, then the
-    inverse order), for frames that divide into 8 x 8 tiles, frames that do not, ragged tile counts and W = 1 ... 8"""
+    rank-major all-gather buffer): the ranks' takes partition the frame (every ray exactly once, equal shard sizes), unit u = q W + r
+    of the pixel-tile order goes to rank (r + q) mod W (rotated round-robin: no rank keeps the same pixel columns in every tile row),
+    and `put` brings the gathered rows back into the caller's order -- for frames that divide into 8 x 8 tiles, frames that do not,
+    ragged unit counts and W = 1 ... 8"""
     import torch
     from laenerf_amd import dist as D
     cpu = torch.device("cpu")
-    for (H, W) in ((24, 32), (12, 64), (40, 56), (7, 19)):
+    for (H, W) in ((24, 32), (12, 64), (40, 56), (7, 19), (64, 128)):
         n = H * W
         vals = torch.arange(n).float()
         order = D.pixel_tile_order((H, W), cpu)
-        tiled = vals[order[0]] if order is not None else vals
+        tiled = vals[order[0]] if order is not None else vals              # ray id at every position of the dealt order
         for world in (1, 2, 3, 8):
-            blocks, old_blocks = [], []
+            blocks, seen = [], []
             for r in range(world):
                 plan = D.frame_plan(n, r, world, cpu, (H, W))
                 assert plan["take"].shape[0] == plan["n_shard"] and plan["n_shard"] % D.TILE == 0
                 blocks.append(vals[plan["take"]])
-                idx = D.shard_indices(n, r, world)
-                old_blocks.append(tiled[idx.clamp(min=0)])
-                valid = idx >= 0
-                assert torch.equal(blocks[-1][valid], old_blocks[-1][valid])        # same rays, same order (padding rows may differ)
+                n_units = -(-n // D.TILE)
+                for q in range(plan["n_shard"] // D.TILE):                  # this rank's q-th unit is unit q W + (r - q) mod W
+                    u = q * world + (r - q) % world
+                    lo, hi = u * D.TILE, min((u + 1) * D.TILE, n)
+                    if u < n_units:
+                        assert torch.equal(blocks[-1][q * D.TILE:q * D.TILE + hi - lo], tiled[lo:hi]), (H, W, world, r, q)
+                        seen.append(torch.arange(lo, hi))
             assert len({b.shape[0] for b in blocks}) == 1                              # equal shards: the all-gather's requirement
+            assert torch.equal(torch.sort(torch.cat(seen)).values, torch.arange(n))   # a partition of the frame
             full = torch.stack(blocks).reshape(-1)[plan["put"]]
             assert torch.equal(full, vals), (H, W, world)
-            old = D.deinterleave(torch.stack(old_blocks)[:, :, None], n, world)[:, 0]
-            assert torch.equal(old[order[1]] if order is not None else old, vals)
-    # without image_hw (or with one that does not match the ray count) the deal is over the caller's order itself
+    # W = 1 is the plain order; without image_hw (or with one that does not match the ray count) the deal is over the caller's order
+    assert torch.equal(D.frame_plan(1000, 0, 1, cpu, None)["take"][:1000], torch.arange(1000))
     plan = D.frame_plan(1000, 1, 4, cpu, None)
-    assert torch.equal(plan["take"][:128], torch.arange(128, 256))
+    assert torch.equal(plan["take"][:128], torch.arange(128, 256)) and torch.equal(plan["take"][128:256], torch.arange(512, 640))   # q = 1: unit 4 + (1 - 1) % 4
