@@ -13,6 +13,9 @@ import pytest
 import torch
 from hypothesis import HealthCheck, given, settings, strategies as st
 
+import os
+FUZZ_SCALE = max(1, int(os.environ.get("LAE_FUZZ_SCALE", "1")))   # LAE_FUZZ_SCALE=20: a deep one-off run (profiles/r6_deep_fuzz.txt); the default stays quick
+
 from gpu_util import DEV, N, T
 
 pytestmark = pytest.mark.gpu
@@ -142,7 +145,7 @@ def run_case(c):
     return a, b
 
 
-@settings(max_examples=300, deadline=None, derandomize=True, database=None,
+@settings(max_examples=300 * FUZZ_SCALE, deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
 @given(draw)
 def test_frame_loop_fuzz_against_operator_loop(c):

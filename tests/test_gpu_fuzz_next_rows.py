@@ -8,6 +8,9 @@ import pytest
 import torch
 from hypothesis import HealthCheck, given, settings, strategies as st
 
+import os
+FUZZ_SCALE = max(1, int(os.environ.get("LAE_FUZZ_SCALE", "1")))   # LAE_FUZZ_SCALE=20: a deep one-off run (profiles/r6_deep_fuzz.txt); the default stays quick
+
 from gpu_util import DEV, N, T
 
 pytestmark = pytest.mark.gpu
@@ -33,7 +36,7 @@ def _poses(rng, B, radius):
     return poses
 
 
-@settings(max_examples=120, **FUZZ)
+@settings(max_examples=120 * FUZZ_SCALE, **FUZZ)
 @given(st.fixed_dictionaries({"B": st.integers(1, 4), "H": st.integers(2, 90), "W": st.integers(2, 120), "n": st.integers(0, 3000),
                               "per_pose": st.booleans(), "offset": st.booleans(), "aabb": st.booleans(), "seed": st.integers(0, 2 ** 20)}))
 def test_fuzz_get_rays(c):
@@ -69,7 +72,7 @@ def test_fuzz_get_rays(c):
         assert np.array_equal(N(nears).reshape(-1), n1) and np.array_equal(N(fars).reshape(-1), f1)
 
 
-@settings(max_examples=80, **FUZZ)
+@settings(max_examples=80 * FUZZ_SCALE, **FUZZ)
 @given(st.fixed_dictionaries({"H": st.sampled_from([8, 16, 32, 64]), "bound_c": st.sampled_from([0.5, 1.0, 2.0, 4.0]), "n": st.integers(1, 20000),
                               "noise": st.booleans(), "scale": st.floats(0.1, 30.0), "decay": st.sampled_from([0.5, 0.9, 0.95]), "seed": st.integers(0, 2 ** 20)}))
 def test_fuzz_density_grid_positions_and_update(c):
@@ -96,7 +99,7 @@ def test_fuzz_density_grid_positions_and_update(c):
     assert int(tmp.abs().sum().item()) == 0
 
 
-@settings(max_examples=40, **FUZZ)
+@settings(max_examples=40 * FUZZ_SCALE, **FUZZ)
 @given(st.fixed_dictionaries({"B": st.integers(1, 80), "C": st.sampled_from([1, 2, 3]), "H": st.sampled_from([16, 32]), "min_near": st.sampled_from([0.05, 0.2]),
                               "close": st.booleans(), "seed": st.integers(0, 2 ** 20)}))
 def test_fuzz_mark_untrained_grid(c):
@@ -124,7 +127,7 @@ def _small_net(seed):
     return net
 
 
-@settings(max_examples=60, **FUZZ)
+@settings(max_examples=60 * FUZZ_SCALE, **FUZZ)
 @given(st.fixed_dictionaries({"lr": st.sampled_from([1e-3, 1e-2, 5e-2]), "b1": st.sampled_from([0.8, 0.9]), "b2": st.sampled_from([0.99, 0.999]),
                               "eps": st.sampled_from([1e-15, 1e-8]), "init_scale": st.sampled_from([2.0 ** 7, 2.0 ** 12, 2.0 ** 16]), "growth": st.integers(1, 4),
                               "inf_at": st.integers(-1, 7), "nan": st.booleans(), "gscale": st.sampled_from([1e-5, 1e-3, 1e-1]), "seed": st.integers(0, 2 ** 20)}))
