@@ -43,3 +43,18 @@ def test_bench_prints_one_contract_line():
     for k, flop in (("head_forward", 36864), ("head_backward", 73728)):
         assert m[k]["bound"] == "mfma" and m[k]["peak"] == 2500.0 and m[k]["flop_per_sample"] == flop and 0.01 < m[k]["frac"] < 1.0
     assert "frame_encoder" not in m                                  # --no-frame: no inference kernels in this run (the default line has it)
+    # round 6: the line says what --warmup asked for beside what ran, where `traffic` comes from, and carries the zero-edit drop-in step
+    assert j["warmup_requested"] == 3 and j["warmup"] >= 17
+    assert r["traffic"] is None or "not counted in this run" in r["traffic_source"]
+    d = j["drop_in_step"]
+    assert "error" not in d, d
+    assert d["rays"] == 4096 and d["ms_per_step"] > j["ms_per_step"] and 0 < d["device_ms_per_step"] <= 1.05 * d["ms_per_step"]
+    assert abs(d["device_ms_per_step"] - sum(d["device_stretches_ms"])) < 0.05 * d["device_ms_per_step"] and len(d["device_stretches_ms"]) == 3
+    assert d["bound_by"].startswith("host") or d["bound_by"] == "device"
+    assert abs(d["device_time_vs_fused_step"] - d["device_ms_per_step"] / j["ms_per_step"]) < 0.02 * d["device_time_vs_fused_step"]
+    nn = d["without_network_nan_check"]
+    assert len(nn["device_stretches_ms"]) == 2 and nn["ms_per_step"] <= 1.1 * d["ms_per_step"]
+    for k in ("with_one_edit", "with_two_edits"):                    # the optional edits of INTEGRATION 3b, in the order they pay
+        assert "error" not in d[k] and 0 < d[k]["device_ms_per_step"] < d["device_ms_per_step"], (k, d[k])
+    assert d["with_two_edits"]["device_ms_per_step"] < d["with_one_edit"]["device_ms_per_step"]
+
